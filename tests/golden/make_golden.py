@@ -1,0 +1,218 @@
+#!/opt/conda/bin/python3.9
+"""Generate the golden fixtures in tests/golden/*.npz by RUNNING THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference and the conda python3.9 that
+has numpy 1.26 / scikit-image 0.18.3 / scikit-learn 0.24.2):
+
+    /opt/conda/bin/python3.9 tests/golden/make_golden.py
+
+The reference cannot be imported as-is: ``import cv2`` and ``import spams``
+(stainlib/utils/stain_utils.py:2-3) name wheels that exist nowhere in this image.
+Two stand-in modules are therefore injected into ``sys.modules`` *before* the import:
+
+  * ``cv2.cvtColor(I, COLOR_RGB2LAB)``  -> L channel from the OpenCV 8-bit fixed-point
+    restatement in oracle/stain_oracle.py (the SAME code the oracle uses: the tissue
+    mask is therefore NOT independently pinned -- "parity unpinned");
+  * ``spams.lasso(mode=2, pos=True)``   -> scikit-learn's coordinate-descent
+    ``Lasso(positive=True)`` run to 1e-14 -- an implementation INDEPENDENT of the
+    oracle's closed form, so the goldens do pin the oracle's lasso;
+  * ``spams.trainDL``                   -> not used for the goldens written here.
+
+Everything else -- convert_RGB_to_OD, np.cov/eigh, arctan2, percentiles, rescale,
+255*exp(-C@M), the truncating cast, StainAugmentor.pop, HedLighterColorAugmenter
+with the real scikit-image 0.18.3 -- is the reference's own code executing.
+Only arrays (inputs/outputs) are written; no reference source is copied.
+"""
+import hashlib
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+from oracle import stain_oracle as so  # noqa: E402  (only for the cv2 stand-in + tile generator)
+
+import scipy.sparse  # noqa: E402
+from sklearn.linear_model import Lasso  # noqa: E402
+
+
+def _install_standins():
+    cv2 = types.ModuleType("cv2")
+    cv2.COLOR_RGB2LAB = 45
+    cv2.COLOR_LAB2RGB = 57
+
+    def cvtColor(I, code):
+        assert code == cv2.COLOR_RGB2LAB
+        out = np.zeros_like(I)
+        out[:, :, 0] = so.lab_l8(I)
+        out[:, :, 1:] = 128
+        return out
+
+    cv2.cvtColor = cvtColor
+    sys.modules["cv2"] = cv2
+
+    spams = types.ModuleType("spams")
+
+    def lasso(X, D, mode, lambda1, pos):
+        assert mode == 2 and pos
+        # sklearn minimises 1/(2 n) ||y - Xw||^2 + alpha ||w||_1 with n = 3 rows
+        n = X.shape[0]
+        est = Lasso(alpha=lambda1 / n, fit_intercept=False, positive=True, tol=1e-14,
+                    max_iter=1000000, precompute=False)
+        est.fit(np.asarray(D), np.asarray(X))
+        return scipy.sparse.csc_matrix(est.coef_.T)
+
+    def trainDL(**kw):
+        raise RuntimeError("trainDL stand-in is not available for golden generation")
+
+    spams.lasso = lasso
+    spams.trainDL = trainDL
+    sys.modules["spams"] = spams
+
+
+_install_standins()
+sys.path.insert(0, "/root/reference")
+import stainlib  # noqa: E402
+from stainlib.augmentation.augmenter import HedLighterColorAugmenter, StainAugmentor  # noqa: E402
+from stainlib.extraction.macenko_stain_extractor import MacenkoStainExtractor  # noqa: E402
+from stainlib.normalization.normalizer import ExtractiveStainNormalizer  # noqa: E402
+from stainlib.utils import stain_utils as su  # noqa: E402
+from stainlib.utils.excepts import TissueMaskException  # noqa: E402
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def macenko_case(size, seed):
+    I = so.synth_tile(size, size, seed)
+    tgt = so.synth_tile(size, size, 1000 + seed, so.M_TRUE_TGT)
+    rec = {"size": size, "seed": seed, "input_sha": sha(I), "target_sha": sha(tgt)}
+    if size <= 64:
+        rec["input"] = I
+        rec["target"] = tgt
+    # --- stages, each through the reference's own functions -----------------
+    mask = su.LuminosityThresholdTissueLocator.get_tissue_mask(I)
+    rec["mask_count"] = int(mask.sum())
+    rec["mask_bits"] = np.packbits(mask.ravel())
+    OD = su.convert_RGB_to_OD(I).reshape((-1, 3))
+    rec["od_sub"] = OD[::97]
+    ODt = OD[mask.ravel()]
+    cov = np.cov(ODt, rowvar=False)
+    _, V = np.linalg.eigh(cov)
+    V = V[:, [2, 1]]
+    if V[0, 0] < 0:
+        V[:, 0] *= -1
+    if V[0, 1] < 0:
+        V[:, 1] *= -1
+    That = ODt @ V
+    phi = np.arctan2(That[:, 1], That[:, 0])
+    rec["cov"] = cov
+    rec["V"] = V
+    rec["phi_pct"] = np.array([np.percentile(phi, 1), np.percentile(phi, 99)])
+    M = MacenkoStainExtractor.get_stain_matrix(I)
+    rec["M"] = M
+    C = su.get_concentrations(I, M)
+    rec["C_sub"] = np.ascontiguousarray(C[::97])
+    rec["maxC"] = np.percentile(C, 99, axis=0).reshape((1, 2))
+    # --- fit / transform -----------------------------------------------------
+    nrm = ExtractiveStainNormalizer("macenko")
+    nrm.fit(tgt)
+    rec["M_target"] = nrm.stain_matrix_target
+    rec["maxC_target"] = nrm.maxC_target
+    out = nrm.transform(I)
+    rec["out"] = out
+    rec["out_sha"] = sha(out)
+    Cs = C * (nrm.maxC_target / rec["maxC"])
+    pre = 255 * np.exp(-1 * np.dot(Cs, nrm.stain_matrix_target))
+    rec["prequant_sub"] = pre[::97]
+    # self-transform (fit on the tile itself)
+    nrm2 = ExtractiveStainNormalizer("macenko")
+    nrm2.fit(I)
+    rec["out_self"] = nrm2.transform(I)
+    return rec
+
+
+def hed_case(size, seed, npseed):
+    I = so.synth_tile(size, size, seed)
+    aug = HedLighterColorAugmenter()
+    rec = {"size": size, "seed": seed, "npseed": npseed, "input_sha": sha(I)}
+    rec["out_unrandomized"] = aug.transform(I)          # sigma = beta = -0.03 (augmenter.py:194-198)
+    np.random.seed(npseed)
+    aug.randomize()
+    rec["sigmas"] = np.array(aug._sigmas)
+    rec["biases"] = np.array(aug._biases)
+    rec["out"] = aug.transform(I)
+    rec["hed_sub"] = __import__("skimage.color").color.rgb2hed(I).reshape(-1, 3)[::97]
+    white = np.full((16, 16, 3), 255, np.uint8)
+    rec["white_is_same_object"] = bool(aug.transform(white) is white)
+    dark = np.full((16, 16, 3), 3, np.uint8)
+    rec["dark_is_same_object"] = bool(aug.transform(dark) is dark)
+    f = I[:32, :32].astype(np.float64) / 255.0
+    rec["out_float"] = aug.transform(f)
+    return rec
+
+
+def stainaug_case(size, seed, npseed, background):
+    I = so.synth_tile(size, size, seed)
+    aug = StainAugmentor("macenko", augment_background=background)
+    aug.fit(I)
+    rec = {"size": size, "seed": seed, "npseed": npseed, "background": background,
+           "input_sha": sha(I), "M": aug.stain_matrix}
+    np.random.seed(npseed)
+    st = np.random.get_state()
+    rec["out0"] = aug.pop()
+    rec["out1"] = aug.pop()
+    np.random.set_state(st)
+    draws = [np.random.uniform(0.8, 1.2), np.random.uniform(-0.2, 0.2),
+             np.random.uniform(0.8, 1.2), np.random.uniform(-0.2, 0.2)]
+    rec["draws0"] = np.array(draws)                     # alpha0, beta0, alpha1, beta1
+    return rec
+
+
+def errors_case():
+    rec = {}
+    try:
+        su.LuminosityThresholdTissueLocator.get_tissue_mask(np.full((8, 8, 3), 255, np.uint8))
+        rec["white_raises"] = False
+    except TissueMaskException as e:
+        rec["white_raises"] = True
+        rec["white_msg"] = str(e)
+    try:
+        ExtractiveStainNormalizer("reinhard")
+        rec["bad_method_raises"] = False
+    except Exception as e:  # noqa: BLE001
+        rec["bad_method_raises"] = True
+        rec["bad_method_msg"] = str(e)
+    try:
+        MacenkoStainExtractor.get_stain_matrix(np.zeros((8, 8, 3), np.float32))
+        rec["float_raises"] = False
+    except AssertionError as e:
+        rec["float_raises"] = True
+        rec["float_msg"] = str(e)
+    return rec
+
+
+def save(name, rec):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **rec)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+def main():
+    print("reference:", stainlib.__file__)
+    for size in (64, 256):
+        for seed in (1, 2, 3):
+            save("macenko_%d_s%d" % (size, seed), macenko_case(size, seed))
+    save("hed_128_s2_np0", hed_case(128, 2, 0))
+    save("hed_128_s3_np123", hed_case(128, 3, 123))
+    save("stainaug_128_s2_np7", stainaug_case(128, 2, 7, False))
+    save("stainaug_128_s3_np7_bg", stainaug_case(128, 3, 7, True))
+    save("errors", errors_case())
+
+
+if __name__ == "__main__":
+    main()
