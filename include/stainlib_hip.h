@@ -1,0 +1,151 @@
+/*
+ * stainlib_hip.h -- C ABI of the MI355X-native H&E stain-normalization engine.
+ *
+ * This is the drop-in boundary for the hot path named by BASELINE.json.  The
+ * reference (sebastianffx/stainlib v0.6.1) has no FFI: its "operator API" is a
+ * handful of Python classes whose arithmetic lives in numpy / OpenCV / spams /
+ * scikit-image.  Each entry point below replaces one reference call chain
+ * (cited as file:line, relative to the reference checkout) and is what a
+ * ctypes binding inside stainlib would call (INTEGRATION.md shows the stubs).
+ *
+ * Conventions
+ *   - every data pointer is a DEVICE pointer (HBM), e.g. torch tensor.data_ptr();
+ *     SlParams is the only host pointer.
+ *   - images: n tiles, each h x w x 3 interleaved RGB uint8, tiles contiguous
+ *     (NHWC).  Stain matrices: row-major 2x3 double, row 0 = haematoxylin.
+ *   - the caller owns every buffer including the workspace; the library keeps
+ *     no state, allocates nothing, and is re-entrant per stream.
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL =
+ *     the default stream) and returns without synchronising the host.
+ *   - return value: 0 on success, SL_ERR_* (<0) otherwise.  No C++ exception
+ *     crosses this boundary.  Per-tile conditions are reported in status[i].
+ */
+#ifndef STAINLIB_HIP_H
+#define STAINLIB_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SL_VERSION 100 /* 0.1.0 */
+
+/* return codes */
+#define SL_OK 0
+#define SL_ERR_BADARG (-1)    /* null pointer, n/h/w <= 0, unknown op/mode */
+#define SL_ERR_WORKSPACE (-2) /* workspace missing or smaller than sl_workspace_bytes() */
+#define SL_ERR_NODEVICE (-3)  /* no HIP device / wrong architecture */
+#define SL_ERR_HIP_BASE (-1000) /* HIP runtime error e is returned as SL_ERR_HIP_BASE - e */
+
+/* per-tile status[i] */
+#define SL_TILE_OK 0
+#define SL_TILE_EMPTY_MASK 1     /* stain_utils.py:46-47 -> TissueMaskException */
+#define SL_TILE_DEGENERATE_COV 2 /* fewer than 2 tissue pixels: np.cov is NaN in the reference */
+#define SL_TILE_ZERO_MAXC 3      /* 99th percentile of a concentration is 0: normalizer.py:48 divides by it */
+
+/* ops for sl_workspace_bytes */
+#define SL_OP_MACENKO_FIT 1
+#define SL_OP_MACENKO_TRANSFORM 2
+#define SL_OP_VAHADANE_FIT 3
+#define SL_OP_VAHADANE_TRANSFORM 4
+#define SL_OP_HED_AUGMENT 5
+#define SL_OP_STAIN_AUGMENT 6
+
+/* skimage semantics selector for sl_hed_augment */
+#define SL_HED_SKIMAGE_018 0 /* ln(max(rgb,1e-6))/ln(1e-6) @ hed_from_rgb  (golden-pinned) */
+#define SL_HED_SKIMAGE_019 1 /* as 0.18 + stains clamped at 0 after separation */
+#define SL_HED_SKIMAGE_017 2 /* -log10(rgb+2) @ hed_from_rgb ; 10^(-x) - 2 */
+
+/* Extractor constants.  The reference never forwards these from fit/transform, so the
+ * defaults are effectively constants (macenko_stain_extractor.py:7,
+ * vahadane_stain_extractor.py:19, stain_utils.py:69). */
+typedef struct SlParams {
+    double luminosity_threshold; /* 0.8  (binary64 like the Python float the reference compares with) */
+    double angular_percentile;   /* 99   */
+    double lasso_lambda;        /* 0.01 */
+    double dl_lambda;           /* 0.1  (Vahadane) */
+    int32_t dl_max_sweeps;      /* 200  (Vahadane; the reference is wall-clock budgeted) */
+    int32_t reserved;
+    double dl_tol;              /* 1e-7 max-abs change of the dictionary between sweeps */
+} SlParams;
+
+int sl_version(void);
+const char* sl_error_string(int code);
+void sl_default_params(SlParams* p);
+
+/* Bytes of device workspace an op needs for n tiles of h x w.  0 for ops that need none. */
+size_t sl_workspace_bytes(int op, int n_tiles, int h, int w);
+
+/* MacenkoStainExtractor.get_stain_matrix (extraction/macenko_stain_extractor.py:7-44)
+ * + get_concentrations (utils/stain_utils.py:69-78) + np.percentile(C, 99, axis=0)
+ * (normalization/normalizer.py:34-36), for each of n tiles.
+ *   M_out    n x 2 x 3 double   unit-norm rows, H first
+ *   maxC_out n x 2 double
+ *   status   n int32 */
+int sl_macenko_fit(const uint8_t* rgb, int n, int h, int w, const SlParams* params,
+                   double* M_out, double* maxC_out, int32_t* status,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* VahadaneStainExtractor.get_stain_matrix (extraction/vahadane_stain_extractor.py:19-43) with
+ * spams.trainDL replaced by the converged optimum of the same objective, then as above.
+ *   sweeps_out  n int32 (may be NULL): dictionary sweeps used per tile */
+int sl_vahadane_fit(const uint8_t* rgb, int n, int h, int w, const SlParams* params,
+                    double* M_out, double* maxC_out, int32_t* status, int32_t* sweeps_out,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* The OD + reconstruction pass: get_concentrations on every pixel with the tile's own
+ * stain matrix, rescale by maxC_tgt / maxC_src, 255*exp(-C @ M_tgt), truncating uint8 cast
+ * (utils/stain_utils.py:69-78,101-112 ; normalization/normalizer.py:46-50).
+ *   M_src n x 2 x 3, maxC_src n x 2 (per tile); M_tgt 2 x 3, maxC_tgt 2 (shared)
+ *   prequant  optional n x P x 3 float: the values before the uint8 cast (parity tests) */
+int sl_normalize_apply(const uint8_t* rgb, uint8_t* out, int n, int h, int w,
+                       const double* M_src, const double* maxC_src,
+                       const double* M_tgt, const double* maxC_tgt,
+                       double lasso_lambda, float* prequant, void* stream);
+
+/* ExtractiveStainNormalizer('macenko').transform (normalization/normalizer.py:39-50) for a
+ * batch: per-tile fit stages + the apply pass in one cache-friendly schedule.
+ *   M_src_out n x 2 x 3 / maxC_src_out n x 2 may be NULL. */
+int sl_macenko_transform(const uint8_t* rgb, uint8_t* out, int n, int h, int w,
+                         const SlParams* params, const double* M_tgt, const double* maxC_tgt,
+                         double* M_src_out, double* maxC_src_out, int32_t* status,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* ExtractiveStainNormalizer('vahadane').transform, same shape. */
+int sl_vahadane_transform(const uint8_t* rgb, uint8_t* out, int n, int h, int w,
+                          const SlParams* params, const double* M_tgt, const double* maxC_tgt,
+                          double* M_src_out, double* maxC_src_out, int32_t* status,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* HedColorAugmenter.transform (augmentation/augmenter.py:276-331) for uint8 tiles:
+ * cutoff test on the tile mean, rgb2hed, per-channel x*(1+sigma)+bias, hed2rgb, clip, *255,
+ * truncate.  sigma, bias: n x 3 float.  applied[i] = 0 when tile i failed the cutoff test
+ * (its pixels are copied through unchanged). */
+int sl_hed_augment(const uint8_t* rgb, uint8_t* out, int n, int h, int w,
+                   const float* sigma, const float* bias, float cutoff_lo, float cutoff_hi,
+                   int skimage_mode, int32_t* applied,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* StainAugmentor.pop (augmentation/augmenter.py:428-449): concentrations with the tile's
+ * stain matrix M (n x 2 x 3), C[:,i] = C[:,i]*alpha_i + beta_i on tissue pixels (all pixels
+ * when augment_background), 255*exp(-C @ M), clip to [0,255], truncate.
+ *   alpha_beta n x 4 float: alpha0, beta0, alpha1, beta1 (the reference's draw order) */
+int sl_stain_augment(const uint8_t* rgb, uint8_t* out, int n, int h, int w,
+                     const double* M, const float* alpha_beta, int augment_background,
+                     const SlParams* params, void* stream);
+
+/* LuminosityThresholdTissueLocator.get_tissue_mask (utils/stain_utils.py:32-48):
+ * mask_out n x P uint8 (0/1, may be NULL), counts n int64 (may be NULL). */
+int sl_tissue_mask(const uint8_t* rgb, int n, int h, int w, double luminosity_threshold,
+                   uint8_t* mask_out, int64_t* counts, void* stream);
+
+/* get_concentrations (utils/stain_utils.py:69-78) materialised: C_out n x P x 2 float. */
+int sl_concentrations(const uint8_t* rgb, int n, int h, int w, const double* M,
+                      double lasso_lambda, float* C_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STAINLIB_HIP_H */

@@ -1,0 +1,84 @@
+"""ctypes binding of the C ABI in include/stainlib_hip.h.
+
+The HIP library is the product: if ``libstainlib_hip.so`` is missing or a call fails this
+module raises -- there is no CPU fallback anywhere in ``stainlib_amd``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libstainlib_hip.so")
+
+
+class SlParams(C.Structure):
+    _fields_ = [
+        ("luminosity_threshold", C.c_double),
+        ("angular_percentile", C.c_double),
+        ("lasso_lambda", C.c_double),
+        ("dl_lambda", C.c_double),
+        ("dl_max_sweeps", C.c_int32),
+        ("reserved", C.c_int32),
+        ("dl_tol", C.c_double),
+    ]
+
+
+class StainlibHipError(RuntimeError):
+    pass
+
+
+# ops (sl_workspace_bytes)
+OP_MACENKO_FIT, OP_MACENKO_TRANSFORM, OP_VAHADANE_FIT, OP_VAHADANE_TRANSFORM, OP_HED_AUGMENT, OP_STAIN_AUGMENT = range(1, 7)
+# per-tile status
+TILE_OK, TILE_EMPTY_MASK, TILE_DEGENERATE_COV, TILE_ZERO_MAXC = range(4)
+
+_P = C.c_void_p
+_SIGNATURES = {
+    "sl_version": (C.c_int, []),
+    "sl_error_string": (C.c_char_p, [C.c_int]),
+    "sl_default_params": (None, [C.POINTER(SlParams)]),
+    "sl_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "sl_macenko_fit": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(SlParams), _P, _P, _P, _P, C.c_size_t, _P]),
+    "sl_vahadane_fit": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(SlParams), _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "sl_normalize_apply": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_double, _P, _P]),
+    "sl_macenko_transform": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(SlParams), _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "sl_vahadane_transform": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(SlParams), _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "sl_hed_augment": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_float, C.c_float, C.c_int, _P, _P, C.c_size_t, _P]),
+    "sl_stain_augment": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.POINTER(SlParams), _P]),
+    "sl_tissue_mask": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_double, _P, _P, _P]),
+    "sl_concentrations": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_double, _P, _P]),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libstainlib_hip.so (once).  torch is imported first so that the library binds to
+    the same HIP runtime (libamdhip64.so.7) torch already has in the process."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise StainlibHipError(
+                f"{LIB_PATH} not found: build it with `make -C stainlib_amd/csrc` "
+                "(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+        import torch  # noqa: F401  (loads the HIP runtime)
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(h, name)   # AttributeError here == a symbol the header declares is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        raise StainlibHipError(f"{what} failed: {lib().sl_error_string(code).decode()} (code {code})")
+
+
+def default_params() -> SlParams:
+    p = SlParams()
+    lib().sl_default_params(C.byref(p))
+    return p

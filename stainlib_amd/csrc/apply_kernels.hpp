@@ -1,0 +1,244 @@
+// apply.hip -- the per-pixel "OD + reconstruction" family of sweeps (gfx950).
+//
+//   k_apply          normalizer.py:46-50   u8 -> OD -> 2-atom lasso -> rescale -> 255*exp(-C@Mt) -> u8
+//   k_stain_augment  augmenter.py:428-449  same skeleton, C*alpha+beta on tissue, clip
+//   k_concentrations stain_utils.py:69-78  materialise C (only for the Python attribute)
+//   k_tissue_mask    stain_utils.py:32-48  materialise the mask / count it
+//
+// Roofline: HBM.  Algorithmic traffic of k_apply is 3 B read + 3 B written per pixel.
+#pragma once
+#include "sl_device.hpp"
+
+namespace sl {
+
+template <bool ALIGNED>
+__device__ __forceinline__ Chunk load_chunk(const uint8_t* tile, size_t nbytes, int c) {
+    if (ALIGNED) {
+        return reinterpret_cast<const Chunk*>(tile)[c];
+    } else {
+        uint32_t w[3] = {0, 0, 0};
+        const size_t base = (size_t)c * 12;
+        for (int i = 0; i < 12; ++i)
+            if (base + i < nbytes) w[i >> 2] |= (uint32_t)tile[base + i] << (8 * (i & 3));
+        return Chunk{w[0], w[1], w[2]};
+    }
+}
+
+template <bool ALIGNED>
+__device__ __forceinline__ void store_chunk(uint8_t* tile, size_t nbytes, int c, const Chunk& v) {
+    if (ALIGNED) {
+        reinterpret_cast<Chunk*>(tile)[c] = v;
+    } else {
+        const size_t base = (size_t)c * 12;
+        for (int i = 0; i < 12; ++i)
+            if (base + i < nbytes) tile[base + i] = (uint8_t)chunk_byte(v, i);
+    }
+}
+
+struct ReconK {
+    float q[2][3];  // -log2(e) * scale_i * M_out[i][c]
+};
+
+// One pixel: OD -> concentrations -> (optional affine) -> Beer-Lambert in base 2.
+template <bool CLIP>
+__device__ __forceinline__ void recon_px(const ReconK& R, float c1, float c2, float (&v)[3]) {
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const float e = fmaf(c1, R.q[0][ch], c2 * R.q[1][ch]);
+        float t = 255.0f * __builtin_amdgcn_exp2f(e);
+        if (CLIP) t = fminf(t, 255.0f);   // t >= 0 always; NaN -> 255 is irrelevant (cast gives 0 first)
+        v[ch] = t;
+    }
+}
+
+// Truncating cast of normalizer.py:50 (`astype(np.uint8)`): toward zero, then modulo 256.
+__device__ __forceinline__ uint32_t trunc_u8(float t) { return ((uint32_t)t) & 0xffu; }
+
+constexpr int kU = 4;  // chunks in flight per lane per trip (4 x 12 B loads issued back to back)
+
+template <bool ALIGNED, bool PREQ>
+static __global__ __launch_bounds__(kWG) void k_apply(const uint8_t* __restrict__ rgb, uint8_t* __restrict__ out,
+                                               int P, int parts, const double* __restrict__ M_src,
+                                               const double* __restrict__ maxC_src,
+                                               const double* __restrict__ M_tgt,
+                                               const double* __restrict__ maxC_tgt, double lam,
+                                               float* __restrict__ prequant) {
+    __shared__ float s_od[256 * kRepl];
+    fill_od_lut(s_od);
+    const int tile = blockIdx.x / parts, part = blockIdx.x % parts;
+    const int tid = threadIdx.x;
+    const uint32_t lane32 = tid & (kRepl - 1);   // which LDS copy of the table this lane reads
+
+    // per-tile constants, computed redundantly in binary64 by every lane, then made scalar
+    LassoK L;
+    lasso_consts(M_src + 6 * (size_t)tile, lam, L);
+    uni(L);
+    ReconK R;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const double ratio = maxC_tgt[i] / maxC_src[2 * (size_t)tile + i];   // normalizer.py:48
+#pragma unroll
+        for (int c = 0; c < 3; ++c) R.q[i][c] = uni((float)(-1.4426950408889634 * ratio * M_tgt[3 * i + c]));
+    }
+    __syncthreads();
+
+    const size_t nbytes = (size_t)P * 3;
+    const uint8_t* src = rgb + (size_t)tile * nbytes;
+    uint8_t* dst = out + (size_t)tile * nbytes;
+    const int nch = (P + 3) >> 2;
+    const int span = (nch + parts - 1) / parts;
+    const int c0 = part * span;
+    const int c1 = min(nch, c0 + span);
+
+    // A tile whose fit failed (empty tissue mask / degenerate covariance: M is NaN) is passed
+    // through unchanged; the caller sees why in status[].  (Block-uniform branch.)
+    if (!(M_src[6 * (size_t)tile] == M_src[6 * (size_t)tile])) {
+        for (int c = c0 + tid; c < c1; c += kWG) store_chunk<ALIGNED>(dst, nbytes, c, load_chunk<ALIGNED>(src, nbytes, c));
+        return;
+    }
+
+    for (int c = c0 + tid; c < c1; c += kWG * kU) {
+        Chunk in[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int cc = c + u * kWG;
+            in[u] = cc < c1 ? load_chunk<ALIGNED>(src, nbytes, cc) : Chunk{0, 0, 0};
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int cc = c + u * kWG;
+            uint32_t ob[12];
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                const float x = lut(s_od, chunk_byte(in[u], 3 * px + 0), lane32);
+                const float y = lut(s_od, chunk_byte(in[u], 3 * px + 1), lane32);
+                const float z = lut(s_od, chunk_byte(in[u], 3 * px + 2), lane32);
+                float a, b, v[3];
+                lasso2(L, x, y, z, a, b);
+                recon_px<false>(R, a, b, v);
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) ob[3 * px + ch] = trunc_u8(v[ch]);
+                if (PREQ) {
+                    const size_t pix = (size_t)cc * 4 + px;
+                    if (cc < c1 && pix < (size_t)P) {
+                        float* pq = prequant + ((size_t)tile * P + pix) * 3;
+                        pq[0] = v[0]; pq[1] = v[1]; pq[2] = v[2];
+                    }
+                }
+            }
+            Chunk o;
+            o.w0 = ob[0] | (ob[1] << 8) | (ob[2] << 16) | (ob[3] << 24);
+            o.w1 = ob[4] | (ob[5] << 8) | (ob[6] << 16) | (ob[7] << 24);
+            o.w2 = ob[8] | (ob[9] << 8) | (ob[10] << 16) | (ob[11] << 24);
+            if (cc < c1) store_chunk<ALIGNED>(dst, nbytes, cc, o);
+        }
+    }
+}
+
+// StainAugmentor.pop: own stain matrix both ways, affine on the concentrations of tissue pixels
+// (augmenter.py:435-443), clip (augmenter.py:447).
+template <bool ALIGNED>
+static __global__ __launch_bounds__(kWG) void k_stain_augment(const uint8_t* __restrict__ rgb, uint8_t* __restrict__ out,
+                                                       int P, int parts, const double* __restrict__ M,
+                                                       const float* __restrict__ alpha_beta, int augment_background,
+                                                       uint32_t y_lim, double lam) {
+    __shared__ float s_od[256 * kRepl];
+    __shared__ uint32_t s_g[256 * kRepl];
+    fill_od_lut(s_od);
+    fill_gamma_lut(s_g);
+    const int tile = blockIdx.x / parts, part = blockIdx.x % parts;
+    const int tid = threadIdx.x;
+    const uint32_t lane32 = tid & (kRepl - 1);   // which LDS copy of the table this lane reads
+    LassoK L;
+    lasso_consts(M + 6 * (size_t)tile, lam, L);
+    uni(L);
+    ReconK R;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) R.q[i][c] = uni((float)(-1.4426950408889634 * M[6 * (size_t)tile + 3 * i + c]));
+    const float al0 = uni(alpha_beta[4 * (size_t)tile + 0]), be0 = uni(alpha_beta[4 * (size_t)tile + 1]);
+    const float al1 = uni(alpha_beta[4 * (size_t)tile + 2]), be1 = uni(alpha_beta[4 * (size_t)tile + 3]);
+    __syncthreads();
+
+    const size_t nbytes = (size_t)P * 3;
+    const uint8_t* src = rgb + (size_t)tile * nbytes;
+    uint8_t* dst = out + (size_t)tile * nbytes;
+    const int nch = (P + 3) >> 2;
+    const int span = (nch + parts - 1) / parts;
+    const int c0 = part * span;
+    const int c1 = min(nch, c0 + span);
+    for (int c = c0 + tid; c < c1; c += kWG) {
+        const Chunk in = load_chunk<ALIGNED>(src, nbytes, c);
+        uint32_t ob[12];
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            const uint32_t r = chunk_byte(in, 3 * px), g = chunk_byte(in, 3 * px + 1), b = chunk_byte(in, 3 * px + 2);
+            const bool tissue = augment_background ||
+                                is_tissue(lut(s_g, r, lane32), lut(s_g, g, lane32), lut(s_g, b, lane32), y_lim);
+            float a1, a2, v[3];
+            lasso2(L, lut(s_od, r, lane32), lut(s_od, g, lane32), lut(s_od, b, lane32), a1, a2);
+            a1 = tissue ? fmaf(a1, al0, be0) : a1;
+            a2 = tissue ? fmaf(a2, al1, be1) : a2;
+            recon_px<true>(R, a1, a2, v);
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) ob[3 * px + ch] = trunc_u8(v[ch]);
+        }
+        Chunk o;
+        o.w0 = ob[0] | (ob[1] << 8) | (ob[2] << 16) | (ob[3] << 24);
+        o.w1 = ob[4] | (ob[5] << 8) | (ob[6] << 16) | (ob[7] << 24);
+        o.w2 = ob[8] | (ob[9] << 8) | (ob[10] << 16) | (ob[11] << 24);
+        store_chunk<ALIGNED>(dst, nbytes, c, o);
+    }
+}
+
+static __global__ __launch_bounds__(kWG) void k_concentrations(const uint8_t* __restrict__ rgb, int P, int parts,
+                                                        const double* __restrict__ M, double lam,
+                                                        float* __restrict__ C_out) {
+    __shared__ float s_od[256 * kRepl];
+    fill_od_lut(s_od);
+    const int tile = blockIdx.x / parts, part = blockIdx.x % parts;
+    const uint32_t lane32 = threadIdx.x & (kRepl - 1);
+    LassoK L;
+    lasso_consts(M + 6 * (size_t)tile, lam, L);
+    uni(L);
+    __syncthreads();
+    const int span = (P + parts - 1) / parts;
+    const int p0 = part * span, p1 = min(P, p0 + span);
+    const uint8_t* src = rgb + (size_t)tile * P * 3;
+    for (int p = p0 + threadIdx.x; p < p1; p += kWG) {
+        float a, b;
+        lasso2(L, lut(s_od, src[3 * (size_t)p], lane32), lut(s_od, src[3 * (size_t)p + 1], lane32),
+               lut(s_od, src[3 * (size_t)p + 2], lane32), a, b);
+        reinterpret_cast<float2*>(C_out)[(size_t)tile * P + p] = make_float2(a, b);
+    }
+}
+
+static __global__ __launch_bounds__(kWG) void k_tissue_mask(const uint8_t* __restrict__ rgb, int P, int parts,
+                                                     uint32_t y_lim, uint8_t* __restrict__ mask_out,
+                                                     unsigned long long* __restrict__ counts) {
+    __shared__ uint32_t s_g[256 * kRepl];
+    __shared__ unsigned long long s_cnt;
+    fill_gamma_lut(s_g);
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const int tile = blockIdx.x / parts, part = blockIdx.x % parts;
+    const uint32_t lane32 = threadIdx.x & (kRepl - 1);
+    const int span = (P + parts - 1) / parts;
+    const int p0 = part * span, p1 = min(P, p0 + span);
+    const uint8_t* src = rgb + (size_t)tile * P * 3;
+    unsigned long long n = 0;
+    for (int p = p0 + threadIdx.x; p < p1; p += kWG) {
+        const bool t = is_tissue(lut(s_g, src[3 * (size_t)p], lane32), lut(s_g, src[3 * (size_t)p + 1], lane32),
+                                 lut(s_g, src[3 * (size_t)p + 2], lane32), y_lim);
+        if (mask_out) mask_out[(size_t)tile * P + p] = t ? 1 : 0;
+        n += t ? 1 : 0;
+    }
+    n = wave_sum(n);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&s_cnt, n);
+    __syncthreads();
+    if (threadIdx.x == 0 && counts) atomicAdd(&counts[tile], s_cnt);
+}
+
+}  // namespace sl
+

@@ -1,0 +1,59 @@
+// common.hip -- host-only pieces of the C ABI: version, errors, defaults, the luminosity
+// threshold -> integer limit translation.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "sl_host.hpp"
+
+namespace sl {
+
+// OpenCV RGB2Lab_b (modules/imgproc/src/color_lab.cpp): L8 = sat8((296*fY - 1336934 + 2^14) >> 15)
+// with fY = LabCbrtTab_b[idx] = round(2^15 * f(idx/2040)), f the CIE Lab cube-root curve.
+// The reference keeps pixels with L8/255.0 < threshold (stain_utils.py:42-43).
+uint32_t y_limit_for_threshold(double luminosity_threshold) {
+    const double thr = luminosity_threshold;
+    const float scale = 1.0f / (255.0f * 8.0f);
+    int best = -1;
+    for (int i = 0; i < 3072; ++i) {
+        const double x = (double)(scale * (float)i);
+        const double f = x < 216.0 / 24389.0 ? x * (841.0 / 108.0) + 16.0 / 116.0 : std::cbrt(x);
+        const long fY = std::lrint(f * 32768.0);
+        long L = (296 * fY - 1336934 + 16384) >> 15;
+        L = L < 0 ? 0 : (L > 255 ? 255 : L);
+        if ((double)L / 255.0 < thr) best = i;   // tables are monotone: keep the last that passes
+    }
+    return (uint32_t)(best + 1) << 12;
+}
+
+}  // namespace sl
+
+extern "C" int sl_version(void) { return SL_VERSION; }
+
+extern "C" void sl_default_params(SlParams* p) {
+    if (!p) return;
+    std::memset(p, 0, sizeof(*p));
+    p->luminosity_threshold = 0.8;
+    p->angular_percentile = 99.0;
+    p->lasso_lambda = 0.01;
+    p->dl_lambda = 0.1;
+    p->dl_max_sweeps = 200;
+    p->dl_tol = 1e-7;
+}
+
+extern "C" const char* sl_error_string(int code) {
+    static thread_local char buf[96];
+    switch (code) {
+        case SL_OK: return "ok";
+        case SL_ERR_BADARG: return "bad argument";
+        case SL_ERR_WORKSPACE: return "workspace missing or too small";
+        case SL_ERR_NODEVICE: return "no usable HIP device";
+        default: break;
+    }
+    if (code <= SL_ERR_HIP_BASE) {
+        std::snprintf(buf, sizeof(buf), "HIP error %d: %s", SL_ERR_HIP_BASE - code,
+                      hipGetErrorString((hipError_t)(SL_ERR_HIP_BASE - code)));
+        return buf;
+    }
+    return "unknown error";
+}

@@ -1,0 +1,156 @@
+// macenko.hip -- host schedule + C ABI of the Macenko fit / transform (kernels: stats_kernels.hpp).
+//
+// Tiles are processed in GROUPS sized to stay resident in the 256 MiB Infinity Cache, so that the
+// second, third and fourth sweep of a group re-read the uint8 tiles on-die instead of from HBM
+// (tile-major schedule, SURVEY 7 hard part 4).  Per group: 3 sweeps + 3 one-workgroup-per-tile
+// finish kernels (+ the apply sweep for transform), all on the caller's stream, no host sync.
+#include "stats_kernels.hpp"
+#include "sl_host.hpp"
+
+using namespace sl;
+
+namespace {
+
+constexpr size_t kGroupBytes = 96u << 20;   // uint8 bytes of one tile group (fits the 256 MiB MALL with output + slack)
+
+struct Layout {
+    int parts, stride_log2, n_sample, G;
+    size_t off_M, off_maxC, off_status, off_partials, off_sample, off_cand, off_state, total;
+};
+
+size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+Layout make_layout(int n, long P) {
+    Layout L;
+    L.parts = parts_for(P);
+    L.stride_log2 = 6;
+    while (((P + (1L << L.stride_log2) - 1) >> L.stride_log2) > kMaxSample) ++L.stride_log2;
+    L.n_sample = (int)((P + (1L << L.stride_log2) - 1) >> L.stride_log2);
+    long g = (long)(kGroupBytes / (size_t)(3 * P));
+    const long min_g = (1024 + L.parts - 1) / L.parts;      // keep >= ~1024 workgroups per sweep launch
+    if (g < min_g) g = min_g;
+    if (g > n) g = n;
+    if (g < 1) g = 1;
+    L.G = (int)g;
+    size_t o = 0;
+    L.off_M = o;        o = align_up(o + sizeof(double) * 6 * (size_t)n);
+    L.off_maxC = o;     o = align_up(o + sizeof(double) * 2 * (size_t)n);
+    L.off_status = o;   o = align_up(o + sizeof(int32_t) * (size_t)n);
+    L.off_partials = o; o = align_up(o + sizeof(double) * 10 * (size_t)L.parts * L.G);
+    L.off_sample = o;   o = align_up(o + sizeof(uint32_t) * (size_t)L.n_sample * L.G);
+    L.off_cand = o;     o = align_up(o + sizeof(float) * 2 * (size_t)kCapList * L.G);
+    L.off_state = o;    o = align_up(o + sizeof(TileState) * (size_t)L.G);
+    L.total = o;
+    return L;
+}
+
+// Runs the statistics stages for tiles [g0, g0+m) of the batch; results land in M_all/maxC_all/status_all.
+int run_stats_group(const uint8_t* rgb, int g0, int m, long P, const SlParams& p, const Layout& L, char* ws,
+                    double* M_all, double* maxC_all, int32_t* status_all, hipStream_t s) {
+    StatsArgs a;
+    a.rgb = rgb + (size_t)g0 * 3 * P;
+    a.P = (int)P;
+    a.parts = L.parts;
+    a.stride_log2 = L.stride_log2;
+    a.n_sample = L.n_sample;
+    a.y_lim = y_limit_for_threshold(p.luminosity_threshold);
+    a.lam = p.lasso_lambda;
+    a.pct = p.angular_percentile;
+    a.partials = (double*)(ws + L.off_partials);
+    a.sample = (uint32_t*)(ws + L.off_sample);
+    a.cand = (float*)(ws + L.off_cand);
+    a.state = (TileState*)(ws + L.off_state);
+    const bool al = aligned4(a.rgb, P);
+    const dim3 gs((unsigned)((long)m * L.parts)), bs(kWG), gf((unsigned)m), bf(kFinishThreads);
+    if (al) hipLaunchKernelGGL((k_moments<true>), gs, bs, 0, s, a);
+    else    hipLaunchKernelGGL((k_moments<false>), gs, bs, 0, s, a);
+    hipLaunchKernelGGL(k_finish_moments, gf, bf, 0, s, a);
+    if (al) hipLaunchKernelGGL((k_select<kStageAngle, true>), gs, bs, 0, s, a);
+    else    hipLaunchKernelGGL((k_select<kStageAngle, false>), gs, bs, 0, s, a);
+    hipLaunchKernelGGL(k_finish_angle, gf, bf, 0, s, a);
+    if (al) hipLaunchKernelGGL((k_select<kStageConc, true>), gs, bs, 0, s, a);
+    else    hipLaunchKernelGGL((k_select<kStageConc, false>), gs, bs, 0, s, a);
+    hipLaunchKernelGGL(k_finish_conc, gf, bf, 0, s, a, M_all, maxC_all, status_all, g0);
+    return launch_status();
+}
+
+int check_common(const void* rgb, int n, int h, int w, const void* ws, size_t ws_bytes, size_t need) {
+    if (!rgb || n <= 0 || h <= 0 || w <= 0) return SL_ERR_BADARG;
+    if ((long)h * w > (1L << 30)) return SL_ERR_BADARG;
+    if (!ws || ws_bytes < need) return SL_ERR_WORKSPACE;
+    if (((uintptr_t)ws & 255u) != 0) return SL_ERR_WORKSPACE;
+    return SL_OK;
+}
+
+}  // namespace
+
+extern "C" size_t sl_workspace_bytes(int op, int n_tiles, int h, int w) {
+    if (n_tiles <= 0 || h <= 0 || w <= 0) return 0;
+    switch (op) {
+        case SL_OP_MACENKO_FIT:
+        case SL_OP_MACENKO_TRANSFORM:
+        case SL_OP_VAHADANE_FIT:
+        case SL_OP_VAHADANE_TRANSFORM:
+            return make_layout(n_tiles, (long)h * w).total;
+        default:
+            return 0;
+    }
+}
+
+extern "C" int sl_macenko_fit(const uint8_t* rgb, int n, int h, int w, const SlParams* params, double* M_out,
+                              double* maxC_out, int32_t* status, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+    const long P = (long)h * w;
+    const Layout L = (n > 0 && h > 0 && w > 0) ? make_layout(n, P) : Layout{};
+    int rc = check_common(rgb, n, h, w, workspace, workspace_bytes, L.total);
+    if (rc) return rc;
+    SlParams p;
+    sl_default_params(&p);
+    if (params) p = *params;
+    char* ws = (char*)workspace;
+    double* M_all = M_out ? M_out : (double*)(ws + L.off_M);
+    double* maxC_all = maxC_out ? maxC_out : (double*)(ws + L.off_maxC);
+    int32_t* st_all = status ? status : (int32_t*)(ws + L.off_status);
+    for (int g0 = 0; g0 < n; g0 += L.G) {
+        const int m = (n - g0) < L.G ? (n - g0) : L.G;
+        rc = run_stats_group(rgb, g0, m, P, p, L, ws, M_all, maxC_all, st_all, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return SL_OK;
+}
+
+extern "C" int sl_macenko_transform(const uint8_t* rgb, uint8_t* out, int n, int h, int w, const SlParams* params,
+                                    const double* M_tgt, const double* maxC_tgt, double* M_src_out,
+                                    double* maxC_src_out, int32_t* status, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+    const long P = (long)h * w;
+    const Layout L = (n > 0 && h > 0 && w > 0) ? make_layout(n, P) : Layout{};
+    int rc = check_common(rgb, n, h, w, workspace, workspace_bytes, L.total);
+    if (rc) return rc;
+    if (!out || !M_tgt || !maxC_tgt) return SL_ERR_BADARG;
+    SlParams p;
+    sl_default_params(&p);
+    if (params) p = *params;
+    char* ws = (char*)workspace;
+    double* M_all = M_src_out ? M_src_out : (double*)(ws + L.off_M);
+    double* maxC_all = maxC_src_out ? maxC_src_out : (double*)(ws + L.off_maxC);
+    int32_t* st_all = status ? status : (int32_t*)(ws + L.off_status);
+    for (int g0 = 0; g0 < n; g0 += L.G) {
+        const int m = (n - g0) < L.G ? (n - g0) : L.G;
+        rc = run_stats_group(rgb, g0, m, P, p, L, ws, M_all, maxC_all, st_all, (hipStream_t)stream);
+        if (rc) return rc;
+        rc = sl_normalize_apply(rgb + (size_t)g0 * 3 * P, out + (size_t)g0 * 3 * P, m, h, w, M_all + 6 * (size_t)g0,
+                                maxC_all + 2 * (size_t)g0, M_tgt, maxC_tgt, p.lasso_lambda, nullptr, stream);
+        if (rc) return rc;
+    }
+    return SL_OK;
+}
+
+// Development aid (not part of the public header): where the per-tile state lives in the workspace.
+extern "C" int sl_debug_layout(int n, int h, int w, size_t* off_state, size_t* sizeof_state, int* group) {
+    const Layout L = make_layout(n, (long)h * w);
+    if (off_state) *off_state = L.off_state;
+    if (sizeof_state) *sizeof_state = sizeof(TileState);
+    if (group) *group = L.G;
+    return SL_OK;
+}

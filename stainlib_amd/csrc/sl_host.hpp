@@ -1,0 +1,36 @@
+// sl_host.hpp -- host-side helpers shared by the C-ABI translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/stainlib_hip.h"
+
+namespace sl {
+
+inline int hip_err(hipError_t e) { return e == hipSuccess ? SL_OK : SL_ERR_HIP_BASE - (int)e; }
+
+#define SL_HIP_TRY(expr)                                   \
+    do {                                                   \
+        hipError_t e__ = (expr);                           \
+        if (e__ != hipSuccess) return ::sl::hip_err(e__);  \
+    } while (0)
+
+inline int launch_status() { return hip_err(hipGetLastError()); }
+
+// Largest index into OpenCV's LabCbrtTab_b whose 8-bit L satisfies L/255.0 < threshold, +1,
+// shifted to the fixed-point scale the kernels compare against (see is_tissue()).
+// 0 means "no pixel is tissue".
+uint32_t y_limit_for_threshold(double luminosity_threshold);
+
+inline bool aligned4(const void* p, long pixels_per_tile) {
+    return ((uintptr_t)p & 3u) == 0 && (pixels_per_tile & 3) == 0;
+}
+
+// Workgroups a tile of P pixels is split into for the streaming sweeps: ~32 Ki pixels each,
+// at least 1, so that a batch of >=32 tiles launches >>256 workgroups.
+inline int parts_for(long P) {
+    long p = (P + 32767) / 32768;
+    return (int)(p < 1 ? 1 : p);
+}
+
+}  // namespace sl

@@ -1,0 +1,209 @@
+"""Batched device-level operators: torch uint8 NHWC tensors in HBM -> the C ABI.
+
+PyTorch is plumbing here (device memory, streams); every computation is a call into
+``libstainlib_hip.so``.  All functions enqueue on torch's current stream and return
+device tensors without synchronising.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _ffi
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _check_tiles(rgb: torch.Tensor):
+    if not (isinstance(rgb, torch.Tensor) and rgb.is_cuda and rgb.dtype == torch.uint8 and rgb.dim() == 4
+            and rgb.shape[-1] == 3 and rgb.is_contiguous()):
+        raise ValueError("expected a contiguous CUDA uint8 tensor of shape (N, H, W, 3)")
+    n, h, w, _ = rgb.shape
+    return n, h, w
+
+
+def _f64(x, shape, device):
+    t = torch.as_tensor(x, dtype=torch.float64, device=device).reshape(shape)
+    return t.contiguous()
+
+
+def make_params(**kw) -> _ffi.SlParams:
+    p = _ffi.default_params()
+    for k, v in kw.items():
+        if v is not None:
+            setattr(p, k, v)
+    return p
+
+
+class Workspace:
+    """Caller-owned scratch the library asks for via sl_workspace_bytes (grown on demand)."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, op: int, n: int, h: int, w: int, device) -> torch.Tensor:
+        need = int(_ffi.lib().sl_workspace_bytes(op, n, h, w))
+        if self.buf is None or self.buf.numel() < need or self.buf.device != device:
+            self.buf = torch.empty(max(need, 256), dtype=torch.uint8, device=device)
+        return self.buf
+
+
+_default_ws = Workspace()
+
+
+def normalize_apply(rgb, M_src, maxC_src, M_tgt, maxC_tgt, lasso_lambda=0.01, out=None, want_prequant=False):
+    """OD + reconstruction pass (sl_normalize_apply).  Returns out, or (out, prequant)."""
+    n, h, w = _check_tiles(rgb)
+    dev = rgb.device
+    M_src = _f64(M_src, (n, 2, 3), dev)
+    maxC_src = _f64(maxC_src, (n, 2), dev)
+    M_tgt = _f64(M_tgt, (2, 3), dev)
+    maxC_tgt = _f64(maxC_tgt, (2,), dev)
+    if out is None:
+        out = torch.empty_like(rgb)
+    pre = torch.empty((n, h, w, 3), dtype=torch.float32, device=dev) if want_prequant else None
+    _ffi.check(_ffi.lib().sl_normalize_apply(_ptr(rgb), _ptr(out), n, h, w, _ptr(M_src), _ptr(maxC_src),
+                                             _ptr(M_tgt), _ptr(maxC_tgt), float(lasso_lambda), _ptr(pre),
+                                             _stream()), "sl_normalize_apply")
+    return (out, pre) if want_prequant else out
+
+
+def _fit(fn_name, op, rgb, params, ws, with_sweeps=False):
+    n, h, w = _check_tiles(rgb)
+    dev = rgb.device
+    p = params if params is not None else _ffi.default_params()
+    M = torch.empty((n, 2, 3), dtype=torch.float64, device=dev)
+    maxC = torch.empty((n, 2), dtype=torch.float64, device=dev)
+    status = torch.empty((n,), dtype=torch.int32, device=dev)
+    wsb = (ws or _default_ws).get(op, n, h, w, dev)
+    fn = getattr(_ffi.lib(), fn_name)
+    if with_sweeps:
+        sweeps = torch.empty((n,), dtype=torch.int32, device=dev)
+        code = fn(_ptr(rgb), n, h, w, C.byref(p), _ptr(M), _ptr(maxC), _ptr(status), _ptr(sweeps), _ptr(wsb),
+                  wsb.numel(), _stream())
+        _ffi.check(code, fn_name)
+        return M, maxC, status, sweeps
+    code = fn(_ptr(rgb), n, h, w, C.byref(p), _ptr(M), _ptr(maxC), _ptr(status), _ptr(wsb), wsb.numel(), _stream())
+    _ffi.check(code, fn_name)
+    return M, maxC, status
+
+
+def macenko_fit(rgb, params=None, ws=None):
+    """Per-tile Macenko stain matrix (N,2,3) f64, 99th-percentile concentrations (N,2) f64, status (N,) i32."""
+    return _fit("sl_macenko_fit", _ffi.OP_MACENKO_FIT, rgb, params, ws)
+
+
+def vahadane_fit(rgb, params=None, ws=None):
+    """As macenko_fit with the sparse-NMF dictionary; also returns sweeps used per tile."""
+    return _fit("sl_vahadane_fit", _ffi.OP_VAHADANE_FIT, rgb, params, ws, with_sweeps=True)
+
+
+def _transform(fn_name, op, rgb, M_tgt, maxC_tgt, params, out, ws):
+    n, h, w = _check_tiles(rgb)
+    dev = rgb.device
+    p = params if params is not None else _ffi.default_params()
+    M_tgt = _f64(M_tgt, (2, 3), dev)
+    maxC_tgt = _f64(maxC_tgt, (2,), dev)
+    if out is None:
+        out = torch.empty_like(rgb)
+    M = torch.empty((n, 2, 3), dtype=torch.float64, device=dev)
+    maxC = torch.empty((n, 2), dtype=torch.float64, device=dev)
+    status = torch.empty((n,), dtype=torch.int32, device=dev)
+    wsb = (ws or _default_ws).get(op, n, h, w, dev)
+    code = getattr(_ffi.lib(), fn_name)(_ptr(rgb), _ptr(out), n, h, w, C.byref(p), _ptr(M_tgt), _ptr(maxC_tgt),
+                                        _ptr(M), _ptr(maxC), _ptr(status), _ptr(wsb), wsb.numel(), _stream())
+    _ffi.check(code, fn_name)
+    return out, M, maxC, status
+
+
+def macenko_transform(rgb, M_tgt, maxC_tgt, params=None, out=None, ws=None):
+    """Batched ExtractiveStainNormalizer('macenko').transform -> (out, M_src, maxC_src, status)."""
+    return _transform("sl_macenko_transform", _ffi.OP_MACENKO_TRANSFORM, rgb, M_tgt, maxC_tgt, params, out, ws)
+
+
+def vahadane_transform(rgb, M_tgt, maxC_tgt, params=None, out=None, ws=None):
+    return _transform("sl_vahadane_transform", _ffi.OP_VAHADANE_TRANSFORM, rgb, M_tgt, maxC_tgt, params, out, ws)
+
+
+def hed_augment(rgb, sigma, bias, cutoff=(0.05, 0.95), skimage_mode=0, out=None, ws=None):
+    """Batched HedColorAugmenter.transform for uint8 tiles -> (out, applied (N,) i32)."""
+    n, h, w = _check_tiles(rgb)
+    dev = rgb.device
+    sigma = torch.as_tensor(sigma, dtype=torch.float32, device=dev).reshape(n, 3).contiguous()
+    bias = torch.as_tensor(bias, dtype=torch.float32, device=dev).reshape(n, 3).contiguous()
+    if out is None:
+        out = torch.empty_like(rgb)
+    applied = torch.empty((n,), dtype=torch.int32, device=dev)
+    wsb = (ws or _default_ws).get(_ffi.OP_HED_AUGMENT, n, h, w, dev)
+    _ffi.check(_ffi.lib().sl_hed_augment(_ptr(rgb), _ptr(out), n, h, w, _ptr(sigma), _ptr(bias), float(cutoff[0]),
+                                         float(cutoff[1]), int(skimage_mode), _ptr(applied), _ptr(wsb), wsb.numel(),
+                                         _stream()), "sl_hed_augment")
+    return out, applied
+
+
+def stain_augment(rgb, M, alpha_beta, augment_background=False, params=None, out=None):
+    """Batched StainAugmentor.pop given per-tile M (N,2,3) and (alpha0,beta0,alpha1,beta1) (N,4)."""
+    n, h, w = _check_tiles(rgb)
+    dev = rgb.device
+    M = _f64(M, (n, 2, 3), dev)
+    ab = torch.as_tensor(alpha_beta, dtype=torch.float32, device=dev).reshape(n, 4).contiguous()
+    p = params if params is not None else _ffi.default_params()
+    if out is None:
+        out = torch.empty_like(rgb)
+    _ffi.check(_ffi.lib().sl_stain_augment(_ptr(rgb), _ptr(out), n, h, w, _ptr(M), _ptr(ab),
+                                           1 if augment_background else 0, C.byref(p), _stream()), "sl_stain_augment")
+    return out
+
+
+def tissue_mask(rgb, luminosity_threshold=0.8, want_mask=True):
+    """(mask (N,H,W) uint8 or None, counts (N,) int64)."""
+    n, h, w = _check_tiles(rgb)
+    dev = rgb.device
+    mask = torch.empty((n, h, w), dtype=torch.uint8, device=dev) if want_mask else None
+    counts = torch.empty((n,), dtype=torch.int64, device=dev)
+    _ffi.check(_ffi.lib().sl_tissue_mask(_ptr(rgb), n, h, w, float(luminosity_threshold), _ptr(mask), _ptr(counts),
+                                         _stream()), "sl_tissue_mask")
+    return mask, counts
+
+
+def concentrations(rgb, M, lasso_lambda=0.01):
+    """get_concentrations materialised: (N, H*W, 2) float32."""
+    n, h, w = _check_tiles(rgb)
+    dev = rgb.device
+    M = _f64(M, (n, 2, 3), dev)
+    Cout = torch.empty((n, h * w, 2), dtype=torch.float32, device=dev)
+    _ffi.check(_ffi.lib().sl_concentrations(_ptr(rgb), n, h, w, _ptr(M), float(lasso_lambda), _ptr(Cout), _stream()),
+               "sl_concentrations")
+    return Cout
+
+
+def synth_tiles(n, h, w, seed=0, device="cuda", M_true=None, chunk=32):
+    """Synthetic H&E tiles generated on the device (SURVEY 8d recipe; torch RNG, not numpy's)."""
+    import math
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    M = torch.tensor(M_true if M_true is not None else [[0.65, 0.70, 0.29], [0.07, 0.99, 0.11]],
+                     dtype=torch.float32, device=device)
+    M = M / M.norm(dim=1, keepdim=True)
+    out = torch.empty((n, h, w, 3), dtype=torch.uint8, device=device)
+    P = h * w
+    for i in range(0, n, chunk):
+        m = min(chunk, n - i)
+        # Gamma(k=2, theta=0.35) = -0.35 * (ln U1 + ln U2)
+        u = torch.rand((m, P, 2, 2), generator=g, device=device).clamp_min_(1e-12)
+        Cc = -0.35 * (u[..., 0].log() + u[..., 1].log())
+        bg = torch.rand((m, P, 1), generator=g, device=device) < 0.2
+        Cc = torch.where(bg, Cc * 0.02, Cc)
+        od = Cc @ M + 0.01 * torch.randn((m, P, 3), generator=g, device=device)
+        rgb = (255.0 * torch.exp(-od)).clamp_(0, 255)
+        out[i:i + m] = rgb.to(torch.uint8).reshape(m, h, w, 3)
+        del u, Cc, bg, od, rgb
+    _ = math
+    return out

@@ -1,0 +1,144 @@
+"""-m gpu: batched Macenko fit / transform (sl_macenko_fit, sl_macenko_transform) vs the oracle
+and vs the golden vectors produced by the reference."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import stain_oracle as so
+from tests.gpu_util import oracle_fit_tile, to_dev, u8_parity
+
+pytestmark = pytest.mark.gpu
+
+M_ATOL = 2e-6       # stain-matrix tolerance (unit-norm rows): binary32 keys, binary64 everything else
+MAXC_RTOL = 2e-6
+
+
+def _fit_oracle(I):
+    M, mc = oracle_fit_tile(I)
+    return M, mc
+
+
+@pytest.mark.parametrize("h,w", [(64, 64), (256, 256), (96, 130), (33, 47), (128, 512)])
+def test_fit_vs_oracle(h, w):
+    from stainlib_amd import engine
+    tiles = [so.synth_tile(h, w, s) for s in (2, 3, 4, 5)]
+    M, mc, st = engine.macenko_fit(to_dev(tiles))
+    M, mc, st = M.cpu().numpy(), mc.cpu().numpy(), st.cpu().numpy()
+    assert (st == 0).all()
+    for i, I in enumerate(tiles):
+        Mo, mco = _fit_oracle(I)
+        np.testing.assert_allclose(M[i], Mo, rtol=0, atol=M_ATOL)
+        np.testing.assert_allclose(mc[i], mco, rtol=MAXC_RTOL)
+        np.testing.assert_allclose(np.linalg.norm(M[i], axis=1), 1.0, rtol=0, atol=1e-12)
+        assert M[i][0, 0] > M[i][1, 0]            # H row first (macenko_stain_extractor.py:40)
+
+
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "macenko_*.npz")))
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
+def test_fit_transform_golden(path):
+    """fit(target) + transform(I) against what the reference itself produced."""
+    from stainlib_amd import engine
+    g = np.load(path)
+    size, seed = int(g["size"]), int(g["seed"])
+    I = so.synth_tile(size, size, seed)
+    tgt = so.synth_tile(size, size, 1000 + seed, so.M_TRUE_TGT)
+    Mt, mct, st = engine.macenko_fit(to_dev([tgt]))
+    np.testing.assert_allclose(Mt.cpu().numpy()[0], g["M_target"], rtol=0, atol=M_ATOL)
+    np.testing.assert_allclose(mct.cpu().numpy()[0], g["maxC_target"].reshape(2), rtol=MAXC_RTOL)
+    out, M, mc, st = engine.macenko_transform(to_dev([I]), Mt[0], mct[0])
+    assert int(st[0]) == 0
+    np.testing.assert_allclose(M.cpu().numpy()[0], g["M"], rtol=0, atol=M_ATOL)
+    np.testing.assert_allclose(mc.cpu().numpy()[0], g["maxC"].reshape(2), rtol=MAXC_RTOL)
+    # end-to-end bytes: M/maxC carry ~1e-6 error, so allow a 4e-4 flip rate, never more than 1 level
+    u8_parity(out.cpu().numpy()[0], g["out"], max_rate=4e-4)
+    # with the reference's own (M, maxC) the apply pass alone meets the 1e-4 bar (test_gpu_apply)
+
+
+def test_transform_batch_matches_single_and_oracle():
+    from stainlib_amd import engine
+    tiles = [so.synth_tile(256, 256, s) for s in range(10, 18)]
+    tgt = so.synth_tile(256, 256, 1001, so.M_TRUE_TGT)
+    Mt, mct = _fit_oracle(tgt)
+    dev = to_dev(tiles)
+    out, M, mc, st = engine.macenko_transform(dev, Mt, mct)
+    out = out.cpu().numpy()
+    n = so.ExtractiveStainNormalizer("macenko")
+    n.stain_matrix_target, n.maxC_target = Mt, mct.reshape(1, 2)
+    for i, I in enumerate(tiles):
+        want = n.transform(I)
+        u8_parity(out[i], want, max_rate=4e-4)
+        single = engine.macenko_transform(dev[i:i + 1].contiguous(), Mt, mct)[0].cpu().numpy()[0]
+        assert np.array_equal(single, out[i])     # a tile's result never depends on its batch
+
+
+def test_failed_tiles_do_not_poison_batch():
+    from stainlib_amd import engine
+    good = so.synth_tile(128, 128, 3)
+    white = np.full((128, 128, 3), 255, np.uint8)
+    one = white.copy()
+    one[0, 0] = (90, 40, 120)                      # exactly one tissue pixel -> np.cov is NaN in the reference
+    tiles = [good, white, one, good]
+    Mt, mct = _fit_oracle(so.synth_tile(128, 128, 1001, so.M_TRUE_TGT))
+    out, M, mc, st = engine.macenko_transform(to_dev(tiles), Mt, mct)
+    st = st.cpu().numpy()
+    assert list(st) == [0, 1, 2, 0]
+    out = out.cpu().numpy()
+    assert np.array_equal(out[1], white) and np.array_equal(out[2], one)      # passed through
+    assert np.array_equal(out[0], out[3])
+    assert np.isnan(M.cpu().numpy()[1]).all()
+    n = so.ExtractiveStainNormalizer("macenko")
+    n.stain_matrix_target, n.maxC_target = Mt, mct.reshape(1, 2)
+    u8_parity(out[0], n.transform(good), max_rate=4e-4)
+
+
+def test_heavy_ties_take_the_exact_path():
+    """Few distinct colours: every bracket is swamped by ties, so the finish kernels must fall back to
+    the exact radix select; the answer still has to match numpy's percentiles."""
+    from stainlib_amd import engine
+    rng = np.random.RandomState(7)
+    base = so.synth_tile(32, 32, 9).reshape(-1, 3)
+    palette = base[rng.choice(len(base), 12, replace=False)]
+    I = palette[rng.randint(0, 12, size=(192, 192))].astype(np.uint8)
+    M, mc, st = engine.macenko_fit(to_dev([I]))
+    assert int(st[0]) == 0
+    Mo, mco = _fit_oracle(I)
+    np.testing.assert_allclose(M.cpu().numpy()[0], Mo, rtol=0, atol=M_ATOL)
+    np.testing.assert_allclose(mc.cpu().numpy()[0], mco, rtol=MAXC_RTOL)
+
+
+def test_constant_tile_does_not_hang():
+    from stainlib_amd import engine
+    I = np.full((64, 64, 3), (120, 60, 150), np.uint8)
+    M, mc, st = engine.macenko_fit(to_dev([I]))
+    torch.cuda.synchronize()
+    assert int(st[0]) in (0, 3)
+
+
+def test_fit_1024_vs_oracle_and_permutation_invariance():
+    from stainlib_amd import engine
+    I = so.synth_tile(1024, 1024, 21)
+    perm = np.random.RandomState(1).permutation(1024 * 1024)
+    J = I.reshape(-1, 3)[perm].reshape(I.shape)
+    M, mc, st = engine.macenko_fit(to_dev([I, J]))
+    M, mc = M.cpu().numpy(), mc.cpu().numpy()
+    Mo, mco = _fit_oracle(I)
+    np.testing.assert_allclose(M[0], Mo, rtol=0, atol=M_ATOL)
+    np.testing.assert_allclose(mc[0], mco, rtol=MAXC_RTOL)
+    # get_stain_matrix depends on the multiset of pixels only; order statistics are exact => bit-equal keys,
+    # moment sums differ only by binary64 summation order
+    np.testing.assert_allclose(M[1], M[0], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(mc[1], mc[0], rtol=1e-12)
+
+
+def test_params_are_honoured():
+    from stainlib_amd import engine
+    I = so.synth_tile(128, 128, 4)
+    p = engine.make_params(luminosity_threshold=0.7, angular_percentile=95.0)
+    M, mc, st = engine.macenko_fit(to_dev([I]), params=p)
+    Mo = so.macenko_stain_matrix(I, luminosity_threshold=0.7, angular_percentile=95)
+    np.testing.assert_allclose(M.cpu().numpy()[0], Mo, rtol=0, atol=M_ATOL)

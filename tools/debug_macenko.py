@@ -1,0 +1,48 @@
+import ctypes as C
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from oracle import stain_oracle as so  # noqa: E402
+from stainlib_amd import _ffi, engine  # noqa: E402
+
+size = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+I = so.synth_tile(size, size, 2)
+d = {}
+Mo = so.macenko_stain_matrix(I, details=d)
+ws = engine.Workspace()
+M, mc, st = engine.macenko_fit(torch.from_numpy(I[None]).cuda(), ws=ws)
+torch.cuda.synchronize()
+off, sz, grp = C.c_size_t(), C.c_size_t(), C.c_int()
+_ffi.lib().sl_debug_layout(1, size, size, C.byref(off), C.byref(sz), C.byref(grp))
+raw = ws.buf[off.value:off.value + sz.value].cpu().numpy().tobytes()
+n_t = np.frombuffer(raw, np.float64, 1, 0)[0]
+Vd = np.frombuffer(raw, np.float64, 6, 8).reshape(3, 2)
+lo = np.frombuffer(raw, np.float32, 2, 80); hi = np.frombuffer(raw, np.float32, 2, 88)
+lt = np.frombuffer(raw, np.uint32, 2, 96); le = np.frombuffer(raw, np.uint32, 2, 104); nc = np.frombuffer(raw, np.uint32, 2, 112)
+Ms = np.frombuffer(raw, np.float64, 6, 120).reshape(2, 3)
+maxC = np.frombuffer(raw, np.float64, 2, 168)
+status, fb = np.frombuffer(raw, np.int32, 2, 184)
+print("n_tissue gpu", n_t, "oracle", d["n_tissue"])
+print("V gpu\n", Vd, "\nV oracle\n", d["V"], "\nmax diff", np.abs(Vd - d["V"]).max())
+print("M gpu\n", Ms, "\nM oracle\n", Mo, "\nmaxdiff", np.abs(Ms - Mo).max())
+print("stage3: lo", lo, "hi", hi, "lt", lt, "le", le, "ncand", nc, "status", status, "fallbacks", fb)
+# emulate stage 2 in numpy float32 to see which ranks the GPU should have picked
+OD = so.rgb_to_od(I).reshape(-1, 3)[d["mask"]].astype(np.float32)
+V32 = d["V"].astype(np.float32)
+t0 = OD @ V32[:, 0]; t1 = OD @ V32[:, 1]
+p = t1 / (np.abs(t0) + np.abs(t1)); assert (t0 >= 0).all()
+ps = np.sort(p)
+T = len(p)
+for pct in (1.0, 99.0):
+    vi = (T - 1) * pct / 100
+    k = int(np.floor(vi)); g = vi - k
+    ph = np.arctan2(ps[k:k + 2].astype(np.float64), 1 - np.abs(ps[k:k + 2].astype(np.float64)))
+    print("pct", pct, "k", k, "frac", g, "phi interp", ph[0] + g * (ph[1] - ph[0]), "oracle", d["minPhi"] if pct < 50 else d["maxPhi"])
+# what phi does the gpu M imply?  M rows = V [cos, sin]
+for r in range(2):
+    c = Ms[r] @ d["V"]
+    print("gpu row", r, "phi =", np.arctan2(c[1], c[0]))
+print("maxC gpu", maxC, "oracle", np.percentile(so.get_concentrations(I, Mo), 99, axis=0))
