@@ -58,6 +58,29 @@ extern "C" {
 #define SL_HED_SKIMAGE_019 1 /* as 0.18 + stains clamped at 0 after separation */
 #define SL_HED_SKIMAGE_017 2 /* -log10(rgb+2) @ hed_from_rgb ; 10^(-x) - 2 */
 
+/* Optional kernel timing.  When SlParams.profile is non-NULL, sl_*_fit / sl_*_transform bracket every
+ * launch of the selected kernel classes with two caller-created hipEvent_t from events[] (start, stop),
+ * on the same stream as the kernels, and record which class each pair belongs to.  The library only
+ * records; the caller synchronises and reads hipEventElapsedTime.  Launches beyond `capacity` are
+ * simply not bracketed. */
+#define SL_PROF_MOMENTS 1
+#define SL_PROF_SELECT_ANGLE 2
+#define SL_PROF_SELECT_CONC 4
+#define SL_PROF_FINISH 8
+#define SL_PROF_APPLY 16
+#define SL_PROF_DICT 32
+#define SL_PROF_FUSED_FIT 64       /* the persistent one-workgroup-per-tile kernel, fit only */
+#define SL_PROF_FUSED_TRANSFORM 128 /* the same including the apply sweep */
+typedef struct SlProfile {
+    void** events;      /* capacity caller-owned hipEvent_t */
+    int32_t* tags;      /* capacity/2 ints, out: SL_PROF_* class of pair i */
+    int32_t* tiles;     /* capacity/2 ints, out: tiles covered by the launch of pair i */
+    int32_t capacity;   /* number of events available (even) */
+    int32_t used;       /* in/out: events consumed so far (start at 0) */
+    int32_t mask;       /* OR of SL_PROF_* classes to bracket */
+    int32_t reserved;
+} SlProfile;
+
 /* Extractor constants.  The reference never forwards these from fit/transform, so the
  * defaults are effectively constants (macenko_stain_extractor.py:7,
  * vahadane_stain_extractor.py:19, stain_utils.py:69). */
@@ -69,6 +92,7 @@ typedef struct SlParams {
     int32_t dl_max_sweeps;      /* 200  (Vahadane; the reference is wall-clock budgeted) */
     int32_t reserved;
     double dl_tol;              /* 1e-7 max-abs change of the dictionary between sweeps */
+    SlProfile* profile;         /* NULL (default): no timing events */
 } SlParams;
 
 int sl_version(void);

@@ -12,6 +12,24 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libstainlib_hip.so")
 
 
+class SlProfile(C.Structure):
+    _fields_ = [
+        ("events", C.POINTER(C.c_void_p)),
+        ("tags", C.POINTER(C.c_int32)),
+        ("tiles", C.POINTER(C.c_int32)),
+        ("capacity", C.c_int32),
+        ("used", C.c_int32),
+        ("mask", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+PROF_MOMENTS, PROF_SELECT_ANGLE, PROF_SELECT_CONC, PROF_FINISH, PROF_APPLY, PROF_DICT = 1, 2, 4, 8, 16, 32
+PROF_FUSED_FIT, PROF_FUSED_TRANSFORM = 64, 128
+PROF_NAMES = {1: "k_moments", 2: "k_select<angle>", 4: "k_select<conc>", 8: "k_finish_*", 16: "k_apply", 32: "k_dict",
+              64: "k_macenko_fused<fit>", 128: "k_macenko_fused<transform>"}
+
+
 class SlParams(C.Structure):
     _fields_ = [
         ("luminosity_threshold", C.c_double),
@@ -21,6 +39,7 @@ class SlParams(C.Structure):
         ("dl_max_sweeps", C.c_int32),
         ("reserved", C.c_int32),
         ("dl_tol", C.c_double),
+        ("profile", C.POINTER(SlProfile)),
     ]
 
 

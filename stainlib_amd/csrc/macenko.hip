@@ -13,9 +13,14 @@ namespace {
 
 constexpr size_t kGroupBytes = 96u << 20;   // uint8 bytes of one tile group (fits the 256 MiB MALL with output + slack)
 
+constexpr int kFusedMinTiles = 64;          // from this batch size on, one workgroup per tile fills the chip better
+constexpr int kFusedMaxGrid = 512;          // 2 resident 1024-thread workgroups per CU x 256 CUs
+
 struct Layout {
     int parts, stride_log2, n_sample, G;
-    size_t off_M, off_maxC, off_status, off_partials, off_sample, off_cand, off_state, total;
+    bool fused;
+    int grid;                               // fused: workgroups launched
+    size_t off_M, off_maxC, off_status, off_partials, off_sample, off_cand, off_state, off_diag, total;
 };
 
 size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -32,13 +37,17 @@ Layout make_layout(int n, long P) {
     if (g > n) g = n;
     if (g < 1) g = 1;
     L.G = (int)g;
+    L.fused = n >= kFusedMinTiles;
+    L.grid = n < kFusedMaxGrid ? n : kFusedMaxGrid;
+    const size_t slots = L.fused ? (size_t)L.grid : (size_t)L.G;     // candidate buffers: per workgroup / per tile of a group
     size_t o = 0;
     L.off_M = o;        o = align_up(o + sizeof(double) * 6 * (size_t)n);
     L.off_maxC = o;     o = align_up(o + sizeof(double) * 2 * (size_t)n);
     L.off_status = o;   o = align_up(o + sizeof(int32_t) * (size_t)n);
+    L.off_diag = o;     o = align_up(o + sizeof(int32_t) * (size_t)n);
     L.off_partials = o; o = align_up(o + sizeof(double) * 10 * (size_t)L.parts * L.G);
     L.off_sample = o;   o = align_up(o + sizeof(uint32_t) * (size_t)L.n_sample * L.G);
-    L.off_cand = o;     o = align_up(o + sizeof(float) * 2 * (size_t)kCapList * L.G);
+    L.off_cand = o;     o = align_up(o + sizeof(float) * 2 * (size_t)kCapList * slots);
     L.off_state = o;    o = align_up(o + sizeof(TileState) * (size_t)L.G);
     L.total = o;
     return L;
@@ -62,15 +71,62 @@ int run_stats_group(const uint8_t* rgb, int g0, int m, long P, const SlParams& p
     a.state = (TileState*)(ws + L.off_state);
     const bool al = aligned4(a.rgb, P);
     const dim3 gs((unsigned)((long)m * L.parts)), bs(kWG), gf((unsigned)m), bf(kFinishThreads);
-    if (al) hipLaunchKernelGGL((k_moments<true>), gs, bs, 0, s, a);
-    else    hipLaunchKernelGGL((k_moments<false>), gs, bs, 0, s, a);
-    hipLaunchKernelGGL(k_finish_moments, gf, bf, 0, s, a);
-    if (al) hipLaunchKernelGGL((k_select<kStageAngle, true>), gs, bs, 0, s, a);
-    else    hipLaunchKernelGGL((k_select<kStageAngle, false>), gs, bs, 0, s, a);
-    hipLaunchKernelGGL(k_finish_angle, gf, bf, 0, s, a);
-    if (al) hipLaunchKernelGGL((k_select<kStageConc, true>), gs, bs, 0, s, a);
-    else    hipLaunchKernelGGL((k_select<kStageConc, false>), gs, bs, 0, s, a);
-    hipLaunchKernelGGL(k_finish_conc, gf, bf, 0, s, a, M_all, maxC_all, status_all, g0);
+    SlProfile* prof = p.profile;
+    {
+        ProfScope ps(prof, SL_PROF_MOMENTS, m, s);
+        if (al) hipLaunchKernelGGL((k_moments<true>), gs, bs, 0, s, a);
+        else    hipLaunchKernelGGL((k_moments<false>), gs, bs, 0, s, a);
+    }
+    { ProfScope ps(prof, SL_PROF_FINISH, m, s); hipLaunchKernelGGL(k_finish_moments, gf, bf, 0, s, a); }
+    {
+        ProfScope ps(prof, SL_PROF_SELECT_ANGLE, m, s);
+        if (al) hipLaunchKernelGGL((k_select<kStageAngle, true>), gs, bs, 0, s, a);
+        else    hipLaunchKernelGGL((k_select<kStageAngle, false>), gs, bs, 0, s, a);
+    }
+    { ProfScope ps(prof, SL_PROF_FINISH, m, s); hipLaunchKernelGGL(k_finish_angle, gf, bf, 0, s, a); }
+    {
+        ProfScope ps(prof, SL_PROF_SELECT_CONC, m, s);
+        if (al) hipLaunchKernelGGL((k_select<kStageConc, true>), gs, bs, 0, s, a);
+        else    hipLaunchKernelGGL((k_select<kStageConc, false>), gs, bs, 0, s, a);
+    }
+    {
+        ProfScope ps(prof, SL_PROF_FINISH, m, s);
+        hipLaunchKernelGGL(k_finish_conc, gf, bf, 0, s, a, M_all, maxC_all, status_all, g0);
+    }
+    return launch_status();
+}
+
+// The persistent schedule: one launch for the whole batch (fit only when out == nullptr).
+int run_fused(const uint8_t* rgb, uint8_t* out, int n, long P, const SlParams& p, const Layout& L, char* ws,
+              const double* M_tgt, const double* maxC_tgt, double* M_all, double* maxC_all, int32_t* status_all,
+              hipStream_t s) {
+    FusedArgs a;
+    a.rgb = rgb;
+    a.out = out;
+    a.n_tiles = n;
+    a.P = (int)P;
+    a.stride_log2 = L.stride_log2;
+    a.n_sample = L.n_sample;
+    a.y_lim = y_limit_for_threshold(p.luminosity_threshold);
+    a.lam = p.lasso_lambda;
+    a.pct = p.angular_percentile;
+    a.M_tgt = M_tgt;
+    a.maxC_tgt = maxC_tgt;
+    a.cand = (float*)(ws + L.off_cand);
+    a.M_out = M_all;
+    a.maxC_out = maxC_all;
+    a.status_out = status_all;
+    a.diag_out = (int32_t*)(ws + L.off_diag);
+    const bool al = aligned4(rgb, P) && (!out || aligned4(out, P));
+    const dim3 g((unsigned)L.grid), b(kFusedThreads);
+    ProfScope ps(p.profile, out ? SL_PROF_FUSED_TRANSFORM : SL_PROF_FUSED_FIT, n, s);
+    if (out) {
+        if (al) hipLaunchKernelGGL((k_macenko_fused<true, true>), g, b, 0, s, a);
+        else    hipLaunchKernelGGL((k_macenko_fused<true, false>), g, b, 0, s, a);
+    } else {
+        if (al) hipLaunchKernelGGL((k_macenko_fused<false, true>), g, b, 0, s, a);
+        else    hipLaunchKernelGGL((k_macenko_fused<false, false>), g, b, 0, s, a);
+    }
     return launch_status();
 }
 
@@ -111,6 +167,8 @@ extern "C" int sl_macenko_fit(const uint8_t* rgb, int n, int h, int w, const SlP
     double* M_all = M_out ? M_out : (double*)(ws + L.off_M);
     double* maxC_all = maxC_out ? maxC_out : (double*)(ws + L.off_maxC);
     int32_t* st_all = status ? status : (int32_t*)(ws + L.off_status);
+    if (L.fused)
+        return run_fused(rgb, nullptr, n, P, p, L, ws, nullptr, nullptr, M_all, maxC_all, st_all, (hipStream_t)stream);
     for (int g0 = 0; g0 < n; g0 += L.G) {
         const int m = (n - g0) < L.G ? (n - g0) : L.G;
         rc = run_stats_group(rgb, g0, m, P, p, L, ws, M_all, maxC_all, st_all, (hipStream_t)stream);
@@ -135,22 +193,31 @@ extern "C" int sl_macenko_transform(const uint8_t* rgb, uint8_t* out, int n, int
     double* M_all = M_src_out ? M_src_out : (double*)(ws + L.off_M);
     double* maxC_all = maxC_src_out ? maxC_src_out : (double*)(ws + L.off_maxC);
     int32_t* st_all = status ? status : (int32_t*)(ws + L.off_status);
+    if (L.fused)
+        return run_fused(rgb, out, n, P, p, L, ws, M_tgt, maxC_tgt, M_all, maxC_all, st_all, (hipStream_t)stream);
     for (int g0 = 0; g0 < n; g0 += L.G) {
         const int m = (n - g0) < L.G ? (n - g0) : L.G;
         rc = run_stats_group(rgb, g0, m, P, p, L, ws, M_all, maxC_all, st_all, (hipStream_t)stream);
         if (rc) return rc;
-        rc = sl_normalize_apply(rgb + (size_t)g0 * 3 * P, out + (size_t)g0 * 3 * P, m, h, w, M_all + 6 * (size_t)g0,
-                                maxC_all + 2 * (size_t)g0, M_tgt, maxC_tgt, p.lasso_lambda, nullptr, stream);
+        {
+            ProfScope ps(p.profile, SL_PROF_APPLY, m, (hipStream_t)stream);
+            rc = sl_normalize_apply(rgb + (size_t)g0 * 3 * P, out + (size_t)g0 * 3 * P, m, h, w,
+                                    M_all + 6 * (size_t)g0, maxC_all + 2 * (size_t)g0, M_tgt, maxC_tgt,
+                                    p.lasso_lambda, nullptr, stream);
+        }
         if (rc) return rc;
     }
     return SL_OK;
 }
 
 // Development aid (not part of the public header): where the per-tile state lives in the workspace.
-extern "C" int sl_debug_layout(int n, int h, int w, size_t* off_state, size_t* sizeof_state, int* group) {
+extern "C" int sl_debug_layout(int n, int h, int w, size_t* off_state, size_t* sizeof_state, int* group,
+                               size_t* off_diag, int* fused) {
     const Layout L = make_layout(n, (long)h * w);
     if (off_state) *off_state = L.off_state;
     if (sizeof_state) *sizeof_state = sizeof(TileState);
     if (group) *group = L.G;
+    if (off_diag) *off_diag = L.off_diag;
+    if (fused) *fused = L.fused ? 1 : 0;
     return SL_OK;
 }

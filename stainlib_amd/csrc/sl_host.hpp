@@ -33,4 +33,25 @@ inline int parts_for(long P) {
     return (int)(p < 1 ? 1 : p);
 }
 
+// Brackets one launch with two caller-provided events when the class is selected (see SlProfile).
+struct ProfScope {
+    SlProfile* p;
+    hipStream_t s;
+    bool on;
+    ProfScope(SlProfile* prof, int cls, int tiles, hipStream_t stream) : p(prof), s(stream), on(false) {
+        if (p && (p->mask & cls) && p->events && p->used + 2 <= p->capacity) {
+            on = true;
+            if (p->tags) p->tags[p->used / 2] = cls;
+            if (p->tiles) p->tiles[p->used / 2] = tiles;
+            (void)hipEventRecord((hipEvent_t)p->events[p->used], s);
+        }
+    }
+    ~ProfScope() {
+        if (on) {
+            (void)hipEventRecord((hipEvent_t)p->events[p->used + 1], s);
+            p->used += 2;
+        }
+    }
+};
+
 }  // namespace sl

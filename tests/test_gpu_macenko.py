@@ -142,3 +142,48 @@ def test_params_are_honoured():
     M, mc, st = engine.macenko_fit(to_dev([I]), params=p)
     Mo = so.macenko_stain_matrix(I, luminosity_threshold=0.7, angular_percentile=95)
     np.testing.assert_allclose(M.cpu().numpy()[0], Mo, rtol=0, atol=M_ATOL)
+
+
+# ---- the persistent one-workgroup-per-tile schedule kicks in from 64 tiles ---------------------
+def _fused_batch(h, w, n=66):
+    tiles = [so.synth_tile(h, w, 100 + s) for s in range(n)]
+    tiles[5] = np.full((h, w, 3), 255, np.uint8)                       # empty mask
+    rng = np.random.RandomState(3)
+    pal = tiles[0].reshape(-1, 3)[rng.choice(h * w, 9, replace=False)]
+    tiles[7] = pal[rng.randint(0, 9, size=(h, w))].astype(np.uint8)    # heavy ties -> exact fallback
+    return tiles
+
+
+@pytest.mark.parametrize("h,w", [(64, 64), (96, 130), (33, 47)])
+def test_fused_schedule_vs_oracle(h, w):
+    from stainlib_amd import engine
+    tiles = _fused_batch(h, w)
+    tgt = so.synth_tile(128, 128, 1001, so.M_TRUE_TGT)
+    Mt, mct = _fit_oracle(tgt)
+    dev = to_dev(tiles)
+    M, mc, st = engine.macenko_fit(dev)
+    out, M2, mc2, st2 = engine.macenko_transform(dev, Mt, mct)
+    assert torch.equal(st, st2) and torch.equal(M[st == 0], M2[st2 == 0]) and torch.equal(mc[st == 0], mc2[st2 == 0])
+    M, mc, st, out = M.cpu().numpy(), mc.cpu().numpy(), st.cpu().numpy(), out.cpu().numpy()
+    assert st[5] == 1 and np.array_equal(out[5], tiles[5])
+    n = so.ExtractiveStainNormalizer("macenko")
+    n.stain_matrix_target, n.maxC_target = Mt, mct.reshape(1, 2)
+    for i in list(range(0, 12)) + [len(tiles) - 1]:
+        if i == 5:
+            continue
+        Mo, mco = _fit_oracle(tiles[i])
+        assert st[i] == 0
+        np.testing.assert_allclose(M[i], Mo, rtol=0, atol=M_ATOL)
+        np.testing.assert_allclose(mc[i], mco, rtol=MAXC_RTOL)
+        u8_parity(out[i], n.transform(tiles[i]), max_rate=1e-3 if i == 7 else 4e-4)
+
+
+def test_fused_equals_multikernel_schedule():
+    """Both schedules select the same exact order statistics; only the binary64 summation order differs."""
+    from stainlib_amd import engine
+    tiles = [so.synth_tile(128, 128, 300 + s) for s in range(64)]
+    dev = to_dev(tiles)
+    Mf, mcf, stf = engine.macenko_fit(dev)                    # 64 tiles -> fused
+    Mm, mcm, stm = engine.macenko_fit(dev[:8].contiguous())   # 8 tiles -> one launch per phase
+    np.testing.assert_allclose(Mf[:8].cpu().numpy(), Mm.cpu().numpy(), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(mcf[:8].cpu().numpy(), mcm.cpu().numpy(), rtol=1e-12)

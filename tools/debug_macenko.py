@@ -15,8 +15,8 @@ Mo = so.macenko_stain_matrix(I, details=d)
 ws = engine.Workspace()
 M, mc, st = engine.macenko_fit(torch.from_numpy(I[None]).cuda(), ws=ws)
 torch.cuda.synchronize()
-off, sz, grp = C.c_size_t(), C.c_size_t(), C.c_int()
-_ffi.lib().sl_debug_layout(1, size, size, C.byref(off), C.byref(sz), C.byref(grp))
+off, sz, grp, od, fu = C.c_size_t(), C.c_size_t(), C.c_int(), C.c_size_t(), C.c_int()
+_ffi.lib().sl_debug_layout(1, size, size, C.byref(off), C.byref(sz), C.byref(grp), C.byref(od), C.byref(fu))
 raw = ws.buf[off.value:off.value + sz.value].cpu().numpy().tobytes()
 n_t = np.frombuffer(raw, np.float64, 1, 0)[0]
 Vd = np.frombuffer(raw, np.float64, 6, 8).reshape(3, 2)
