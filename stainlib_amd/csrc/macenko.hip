@@ -46,7 +46,7 @@ Layout make_layout(int n, long P) {
     L.off_status = o;   o = align_up(o + sizeof(int32_t) * (size_t)n);
     L.off_diag = o;     o = align_up(o + sizeof(int32_t) * (size_t)n);
     L.off_partials = o; o = align_up(o + sizeof(double) * 10 * (size_t)L.parts * L.G);
-    L.off_sample = o;   o = align_up(o + sizeof(uint32_t) * (size_t)L.n_sample * L.G);
+    L.off_sample = o;   o = align_up(o + sizeof(uint32_t) * (size_t)L.n_sample * slots);
     L.off_cand = o;     o = align_up(o + sizeof(float) * 2 * (size_t)kCapList * slots);
     L.off_state = o;    o = align_up(o + sizeof(TileState) * (size_t)L.G);
     L.total = o;
@@ -96,6 +96,8 @@ int run_stats_group(const uint8_t* rgb, int g0, int m, long P, const SlParams& p
     return launch_status();
 }
 
+long long* g_phase_clock = nullptr;   // development aid, see sl_debug_set_phase_clock
+
 // The persistent schedule: one launch for the whole batch (fit only when out == nullptr).
 int run_fused(const uint8_t* rgb, uint8_t* out, int n, long P, const SlParams& p, const Layout& L, char* ws,
               const double* M_tgt, const double* maxC_tgt, double* M_all, double* maxC_all, int32_t* status_all,
@@ -113,10 +115,12 @@ int run_fused(const uint8_t* rgb, uint8_t* out, int n, long P, const SlParams& p
     a.M_tgt = M_tgt;
     a.maxC_tgt = maxC_tgt;
     a.cand = (float*)(ws + L.off_cand);
+    a.sample = (uint32_t*)(ws + L.off_sample);
     a.M_out = M_all;
     a.maxC_out = maxC_all;
     a.status_out = status_all;
     a.diag_out = (int32_t*)(ws + L.off_diag);
+    a.phase_clock = g_phase_clock;
     const bool al = aligned4(rgb, P) && (!out || aligned4(out, P));
     const dim3 g((unsigned)L.grid), b(kFusedThreads);
     ProfScope ps(p.profile, out ? SL_PROF_FUSED_TRANSFORM : SL_PROF_FUSED_FIT, n, s);
@@ -221,3 +225,5 @@ extern "C" int sl_debug_layout(int n, int h, int w, size_t* off_state, size_t* s
     if (fused) *fused = L.fused ? 1 : 0;
     return SL_OK;
 }
+
+extern "C" void sl_debug_set_phase_clock(long long* device_buf) { g_phase_clock = device_buf; }

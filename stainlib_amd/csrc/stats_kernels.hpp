@@ -39,8 +39,8 @@ namespace sl {
 constexpr int kMaxSample = 16384;   // samples per tile (<= P/64)
 constexpr int kCapList = 16384;     // candidate capacity per bracket list
 constexpr int kFinishThreads = 1024;
-constexpr int kFusedThreads = 1024;
-constexpr int kWaveStage = 512;     // per-wave LDS staging entries per list (multi-kernel select)
+constexpr int kFusedThreads = 512;     // 2 resident workgroups per CU (<=128 VGPRs, 75 KB LDS each)
+constexpr int kWaveStage_unused = 0;    // per-wave LDS staging entries per list (multi-kernel select); a trip adds <= 512
 constexpr float kBracketZ = 6.0f;   // bracket half-width in standard deviations of the sample rank
 
 struct TileState {
@@ -75,15 +75,31 @@ struct StatsArgs {
     TileState* state;        // [tile]                    (multi-kernel)
 };
 
-// One 16-byte LDS entry per byte value: everything a sweep needs from one ds_read_b128.
-struct __attribute__((aligned(16))) TabEntry { double od; uint32_t gamma; float odf; };
-
-__device__ __forceinline__ void fill_tab(TabEntry* s_tab) {
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
-        TabEntry e; e.od = d_od_f64[i]; e.gamma = d_gamma[i]; e.odf = d_od_f32[i];
-        s_tab[i] = e;
+// LDS lookup tables of the 256 byte values, bank-replicated: copy (lane & (R-1)) of entry v sits at
+// [v*R + copy], so the lanes a DS instruction services together hit distinct banks whatever bytes
+// they look up (R = 32: conflict-free ds_read_b32; smaller R trades LDS for a few conflicts).
+// The sweeps are LDS-gather bound with a single 1 KB table (measured), hence the replication.
+struct TabView {                    // copy 0 of the tables, for the finish steps and key functors
+    const float* f; const uint32_t* g; int rf, rg;
+    __device__ __forceinline__ float odf(uint32_t v) const { return f[v * rf]; }
+    __device__ __forceinline__ uint32_t gam(uint32_t v) const { return g[v * rg]; }
+};
+template <int RF, int RG, int RD>
+struct Tabs {
+    float f[256 * RF];                       // max(-ln(v/255), 1e-6) in binary32
+    uint32_t g[256 * RG];                    // OpenCV inverse-sRGB-gamma table
+    double d[256 * (RD > 0 ? RD : 1)];       // OD in binary64 (moment sums only)
+    __device__ __forceinline__ void fill() {
+        for (int i = threadIdx.x; i < 256 * RF; i += blockDim.x) f[i] = d_od_f32[i / RF];
+        for (int i = threadIdx.x; i < 256 * RG; i += blockDim.x) g[i] = d_gamma[i / RG];
+        if (RD > 0)
+            for (int i = threadIdx.x; i < 256 * RD; i += blockDim.x) d[i] = d_od_f64[i / RD];
     }
-}
+    __device__ __forceinline__ float odf(uint32_t v, uint32_t lane) const { return f[v * RF + (lane & (RF - 1))]; }
+    __device__ __forceinline__ uint32_t gam(uint32_t v, uint32_t lane) const { return g[v * RG + (lane & (RG - 1))]; }
+    __device__ __forceinline__ double od64(uint32_t v, uint32_t lane) const { return d[v * RD + (lane & (RD - 1))]; }
+    __device__ __forceinline__ TabView view() const { return TabView{f, g, RF, RG}; }
+};
 
 // Which pixel of sampling block b is kept (same function in the sweep and in the finish steps).
 __device__ __forceinline__ uint32_t sample_offset(uint32_t b, int stride_log2) {
@@ -180,20 +196,35 @@ __device__ inline void wg_locate(const uint32_t* hist, int nb, uint32_t k, uint3
     __syncthreads();
 }
 
+// Visit key_at(i) for i in [0, n) with 4 independent loads in flight per thread (the key functors
+// read global/LDS memory; a plain loop would expose one full latency per element).
+template <class KeyAt, class Fn>
+__device__ __forceinline__ void wg_for_each_key(int n, const KeyAt& key_at, Fn fn) {
+    const int bd = blockDim.x;
+    for (int i0 = threadIdx.x; i0 < n; i0 += 4 * bd) {
+        float f[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * bd;
+            f[u] = i < n ? key_at(i) : nan_f();
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (f[u] == f[u]) fn(f2ord(f[u]));
+    }
+}
+
 // Exact 0-based k-th smallest of the n keys key_at(i) (NaN = absent).  count_le = #keys <= result,
 // n_valid = #non-NaN keys.  Narrowing windows in the ordered-integer domain: each pass histograms
 // the live window into <= 1024 bins, so a pass contends on LDS atomics only under real ties.
 template <class KeyAt>
-__device__ float wg_select(int n, KeyAt key_at, uint32_t k, uint32_t& count_le, uint32_t& n_valid, SelScratch& S) {
+__device__ __noinline__ float wg_select(int n, KeyAt key_at, uint32_t k, uint32_t& count_le, uint32_t& n_valid, SelScratch& S) {
     // pass 0: window = [min, max]
     if (threadIdx.x == 0) { S.misc[4] = 0xffffffffu; S.misc[5] = 0; S.misc[6] = 0; }
     __syncthreads();
     {
         uint32_t mn = 0xffffffffu, mx = 0, cnt = 0;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            const float f = key_at(i);
-            if (f == f) { const uint32_t o = f2ord(f); mn = min(mn, o); mx = max(mx, o); ++cnt; }
-        }
+        wg_for_each_key(n, key_at, [&](uint32_t o) { mn = min(mn, o); mx = max(mx, o); ++cnt; });
         for (int o = 32; o > 0; o >>= 1) {
             mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
             mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
@@ -215,13 +246,9 @@ __device__ float wg_select(int n, KeyAt key_at, uint32_t k, uint32_t& count_le, 
         const int nb = (int)(R >> s) + 1;
         for (int i = threadIdx.x; i < nb; i += blockDim.x) S.hist[i] = 0;
         __syncthreads();
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            const float f = key_at(i);
-            if (f == f) {
-                const uint32_t o = f2ord(f);
-                if (o >= wlo && o <= whi) atomicAdd(&S.hist[(o - wlo) >> s], 1u);
-            }
-        }
+        wg_for_each_key(n, key_at, [&](uint32_t o) {
+            if (o >= wlo && o <= whi) atomicAdd(&S.hist[(o - wlo) >> s], 1u);
+        });
         __syncthreads();
         wg_locate(S.hist, nb, k - below, S.misc);
         const uint32_t b = S.misc[0];
@@ -240,18 +267,12 @@ __device__ float wg_select(int n, KeyAt key_at, uint32_t k, uint32_t& count_le, 
 
 // smallest key strictly greater than v (v itself if none)
 template <class KeyAt>
-__device__ float wg_next_above(int n, KeyAt key_at, float v, SelScratch& S) {
+__device__ __noinline__ float wg_next_above(int n, KeyAt key_at, float v, SelScratch& S) {
     if (threadIdx.x == 0) S.misc[7] = 0xffffffffu;
     __syncthreads();
     uint32_t best = 0xffffffffu;
     const uint32_t ov = f2ord(v);
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const float f = key_at(i);
-        if (f == f) {
-            const uint32_t o = f2ord(f);
-            if (o > ov) best = min(best, o);
-        }
-    }
+    wg_for_each_key(n, key_at, [&](uint32_t o) { if (o > ov) best = min(best, o); });
     for (int o = 32; o > 0; o >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, o, 64));
     if ((threadIdx.x & 63) == 0) atomicMin(&S.misc[7], best);
     __syncthreads();
@@ -268,122 +289,231 @@ __device__ void wg_select_pair(int n, KeyAt key_at, uint32_t k, float& xa, float
     xb = (k + 1 < cle || k + 1 >= nv) ? xa : wg_next_above(n, key_at, xa, S);
 }
 
-// number of non-NaN keys
+// min / max / count of the valid keys (ordered-integer domain)
 template <class KeyAt>
-__device__ uint32_t wg_count_valid(int n, KeyAt key_at, SelScratch& S) {
-    if (threadIdx.x == 0) S.misc[8] = 0;
+__device__ __forceinline__ void wg_minmax(int n, const KeyAt& key_at, uint32_t& omin, uint32_t& omax, uint32_t& nv, SelScratch& S) {
+    if (threadIdx.x == 0) { S.misc[4] = 0xffffffffu; S.misc[5] = 0; S.misc[6] = 0; }
     __syncthreads();
-    uint32_t cnt = 0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const float f = key_at(i);
-        cnt += (f == f) ? 1u : 0u;
+    uint32_t mn = 0xffffffffu, mx = 0, cnt = 0;
+    wg_for_each_key(n, key_at, [&](uint32_t o) { mn = min(mn, o); mx = max(mx, o); ++cnt; });
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
+        mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+        cnt += __shfl_xor((int)cnt, o, 64);
     }
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor((int)cnt, o, 64);
-    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&S.misc[8], cnt);
+    if ((threadIdx.x & 63) == 0) { atomicMin(&S.misc[4], mn); atomicMax(&S.misc[5], mx); atomicAdd(&S.misc[6], cnt); }
     __syncthreads();
-    const uint32_t r = S.misc[8];
+    omin = S.misc[4]; omax = S.misc[5]; nv = S.misc[6];
     __syncthreads();
-    return r;
 }
 
-// Bracket [lo, hi] around rank pct/100*(nv-1) of the nv valid sample keys: exact sample order
-// statistics at rank -/+ z sigma; an end opens to -inf/+inf when its rank leaves the sample.
+// Two brackets (for percentiles pctA and pctB of the FULL population) from the sample keys, in
+// three passes over the sample: min/max, one shared 1024-bin histogram, one 4x256-bin refinement.
+// Each end is a bin edge on the safe side of the exact sample order statistic at rank -/+ z sigma
+// (so the bracket is a hair wider than with exact sample quantiles, never narrower); an end opens
+// to -inf/+inf when its rank leaves the sample.
 template <class KeyAt>
-__device__ void wg_sample_bracket(int n, KeyAt key_at, uint32_t nv, double pct, float& lo, float& hi, SelScratch& S) {
-    if (nv == 0) { lo = -INFINITY; hi = INFINITY; return; }
-    uint32_t cle, nv2;
-    const double q = pct / 100.0;
-    const double r = q * ((double)nv - 1.0);
-    const double sd = sqrt(fmax(q * (1.0 - q) * (double)nv, 0.0));
-    const long long rlo = (long long)floor(r - kBracketZ * sd) - 1;
-    const long long rhi = (long long)ceil(r + kBracketZ * sd) + 1;
-    lo = rlo < 0 ? -INFINITY : wg_select(n, key_at, (uint32_t)rlo, cle, nv2, S);
-    hi = rhi > (long long)nv - 1 ? INFINITY : wg_select(n, key_at, (uint32_t)rhi, cle, nv2, S);
+__device__ __forceinline__ void wg_sample_brackets(int n, const KeyAt& key_at, int nbr, const double* pct, float* lo,
+                                                   float* hi, SelScratch& S) {
+    uint32_t omin, omax, nv;
+    wg_minmax(n, key_at, omin, omax, nv, S);
+    uint32_t rank[4];
+    bool open[4];
+    for (int i = 0; i < 2 * nbr; ++i) { rank[i] = 0; open[i] = true; }
+    if (nv > 0) {
+        for (int b = 0; b < nbr; ++b) {
+            const double q = pct[b] / 100.0;
+            const double r = q * ((double)nv - 1.0);
+            const double sd = sqrt(fmax(q * (1.0 - q) * (double)nv, 0.0));
+            const long long rlo = (long long)floor(r - kBracketZ * sd) - 1;
+            const long long rhi = (long long)ceil(r + kBracketZ * sd) + 1;
+            open[2 * b] = rlo < 0;
+            open[2 * b + 1] = rhi > (long long)nv - 1;
+            rank[2 * b] = open[2 * b] ? 0u : (uint32_t)rlo;
+            rank[2 * b + 1] = open[2 * b + 1] ? nv - 1 : (uint32_t)rhi;
+        }
+    }
+    uint32_t wlo[4], whi[4], below[4];
+    const uint32_t R = omax - omin;
+    const int s1 = (nv == 0 || R < 1024u) ? 0 : (32 - __clz(R) - 10);
+    if (nv > 0) {
+        const int nb1 = (int)(R >> s1) + 1;
+        for (int i = threadIdx.x; i < nb1; i += blockDim.x) S.hist[i] = 0;
+        __syncthreads();
+        wg_for_each_key(n, key_at, [&](uint32_t o) { atomicAdd(&S.hist[(o - omin) >> s1], 1u); });
+        __syncthreads();
+        for (int i = 0; i < 2 * nbr; ++i) {
+            wg_locate(S.hist, nb1, rank[i], S.misc);
+            wlo[i] = omin + (S.misc[0] << s1);
+            const uint32_t span = s1 ? ((1u << s1) - 1u) : 0u;
+            whi[i] = (omax - wlo[i]) < span ? omax : wlo[i] + span;
+            below[i] = S.misc[1];
+            __syncthreads();
+        }
+        if (s1 > 0) {            // refine every window into 256 bins (segments of the same LDS histogram)
+            const int s2 = s1 > 8 ? s1 - 8 : 0;
+            for (int i = threadIdx.x; i < 1024; i += blockDim.x) S.hist[i] = 0;
+            __syncthreads();
+            wg_for_each_key(n, key_at, [&](uint32_t o) {
+                for (int i = 0; i < 2 * nbr; ++i)
+                    if (o >= wlo[i] && o <= whi[i]) atomicAdd(&S.hist[i * 256 + ((o - wlo[i]) >> s2)], 1u);
+            });
+            __syncthreads();
+            for (int i = 0; i < 2 * nbr; ++i) {
+                wg_locate(S.hist + i * 256, 256, rank[i] - below[i], S.misc);
+                const uint32_t nlo = wlo[i] + (S.misc[0] << s2);
+                const uint32_t span = s2 ? ((1u << s2) - 1u) : 0u;
+                whi[i] = (whi[i] - nlo) < span ? whi[i] : nlo + span;
+                wlo[i] = nlo;
+                __syncthreads();
+            }
+        }
+    }
+    for (int b = 0; b < nbr; ++b) {
+        lo[b] = (nv == 0 || open[2 * b]) ? -INFINITY : ord2f(wlo[2 * b]);
+        hi[b] = (nv == 0 || open[2 * b + 1]) ? INFINITY : ord2f(whi[2 * b + 1]);
+    }
+}
+
+// Exact order statistics k and k2 = min(k+1, nv-1) of a SMALL key set (the bracket members): min/max,
+// one 1024-bin histogram, then the keys of the bin holding rank k are gathered into LDS and ranked by
+// brute force.  Falls back to the generic windowed selection when that bin holds more than 256 keys.
+template <class KeyAt>
+__device__ __forceinline__ void wg_select_pair_small(int n, const KeyAt& key_at, uint32_t k, float& xa, float& xb, SelScratch& S) {
+    uint32_t omin, omax, nv;
+    wg_minmax(n, key_at, omin, omax, nv, S);
+    if (nv == 0) { xa = xb = nan_f(); return; }
+    if (k >= nv) k = nv - 1;
+    const uint32_t k2 = k + 1 < nv ? k + 1 : k;
+    const uint32_t R = omax - omin;
+    const int s1 = R < 1024u ? 0 : (32 - __clz(R) - 10);
+    const int nb1 = (int)(R >> s1) + 1;
+    for (int i = threadIdx.x; i < nb1; i += blockDim.x) S.hist[i] = 0;
+    __syncthreads();
+    wg_for_each_key(n, key_at, [&](uint32_t o) { atomicAdd(&S.hist[(o - omin) >> s1], 1u); });
+    __syncthreads();
+    wg_locate(S.hist, nb1, k, S.misc);
+    const uint32_t bin = S.misc[0], below = S.misc[1], cnt = S.misc[2];
+    __syncthreads();
+    if (cnt > 256u) {                                     // heavy ties / degenerate spread: generic path
+        wg_select_pair(n, key_at, k, xa, xb, S);
+        return;
+    }
+    const uint32_t wlo = omin + (bin << s1);
+    const uint32_t span = s1 ? ((1u << s1) - 1u) : 0u;
+    const uint32_t whi = (omax - wlo) < span ? omax : wlo + span;
+    if (threadIdx.x == 0) S.misc[9] = 0;
+    __syncthreads();
+    float* list = reinterpret_cast<float*>(S.hist);       // the histogram is no longer needed
+    wg_for_each_key(n, key_at, [&](uint32_t o) {
+        if (o >= wlo && o <= whi) list[atomicAdd(&S.misc[9], 1u)] = ord2f(o);
+    });
+    __syncthreads();
+    if (threadIdx.x == 0) { S.misc[10] = 0; S.misc[11] = 0; }
+    __syncthreads();
+    if (threadIdx.x < cnt) {
+        const float me = list[threadIdx.x];
+        uint32_t r = 0;
+        for (uint32_t j = 0; j < cnt; ++j) {
+            const float o = list[j];
+            r += (o < me || (o == me && j < threadIdx.x)) ? 1u : 0u;
+        }
+        if (r == k - below) S.misc[10] = __float_as_uint(me);
+        if (r == k2 - below) S.misc[11] = __float_as_uint(me);
+    }
+    __syncthreads();
+    xa = __uint_as_float(S.misc[10]);
+    const bool same_bin = (k2 - below) < cnt;
+    xb = __uint_as_float(S.misc[11]);
+    __syncthreads();
+    if (!same_bin) xb = wg_next_above(n, key_at, xa, S);
 }
 
 // ------------------------------------------------------------------------------------------
 // finish-step arithmetic (thread 0)
 // ------------------------------------------------------------------------------------------
-__device__ inline void jacobi_eigh3(double A[3][3], double w[3], double V[3][3]) {
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) V[i][j] = i == j ? 1.0 : 0.0;
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
-        const double dia = fabs(A[0][0]) + fabs(A[1][1]) + fabs(A[2][2]);
-        if (off <= 1e-300 || off <= 1e-22 * dia) break;
-        for (int p = 0; p < 2; ++p)
-            for (int q = p + 1; q < 3; ++q) {
-                if (A[p][q] == 0.0) continue;
-                const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-                for (int r = 0; r < 3; ++r) {       // A <- A J
-                    const double arp = A[r][p], arq = A[r][q];
-                    A[r][p] = c * arp - s * arq;
-                    A[r][q] = s * arp + c * arq;
-                }
-                for (int r = 0; r < 3; ++r) {       // A <- J^T A
-                    const double apr = A[p][r], aqr = A[q][r];
-                    A[p][r] = c * apr - s * aqr;
-                    A[q][r] = s * apr + c * aqr;
-                }
-                for (int r = 0; r < 3; ++r) {       // V <- V J
-                    const double vrp = V[r][p], vrq = V[r][q];
-                    V[r][p] = c * vrp - s * vrq;
-                    V[r][q] = s * vrp + c * vrq;
-                }
-            }
+// One Jacobi rotation annihilating a_pq of a symmetric 3x3 (r = the third index); every operand
+// is a named scalar so that nothing is indexed dynamically (dynamic indexing would put the
+// matrices in scratch memory and cost ~100 us of latency per tile on the single working lane).
+__device__ __forceinline__ void jacobi_rot(double& app, double& aqq, double& apq, double& apr, double& aqr,
+                                           double (&vp)[3], double (&vq)[3]) {
+    if (apq == 0.0) return;
+    const double theta = (aqq - app) / (2.0 * apq);
+    const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+    const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+    app -= t * apq;
+    aqq += t * apq;
+    apq = 0.0;
+    const double npr = c * apr - sn * aqr, nqr = sn * apr + c * aqr;
+    apr = npr;
+    aqr = nqr;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double a = vp[i], b = vq[i];
+        vp[i] = c * a - sn * b;
+        vq[i] = sn * a + c * b;
     }
-    for (int i = 0; i < 3; ++i) w[i] = A[i][i];
 }
 
 // sums = {n, Sx, Sy, Sz, Sxx, Sxy, Sxz, Syy, Syz, Szz} -> status, V (binary64 + binary32)
-__device__ inline int eigvecs_from_moments(const double* sum, double* Vd, float* Vf) {
+__device__ __forceinline__ int eigvecs_from_moments(const double* sum, double* Vd, float* Vf) {
     const double n = sum[0];
     int status = SL_TILE_OK;
-    double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, w[3] = {0, 0, 0};
+    double v0[3] = {1, 0, 0}, v1[3] = {0, 1, 0}, v2[3] = {0, 0, 1};
+    double a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0;
     if (n < 1) status = SL_TILE_EMPTY_MASK;
     else if (n < 2) status = SL_TILE_DEGENERATE_COV;
     else {
         // np.cov(OD, rowvar=False): (sum xx^T - n mean mean^T) / (n - 1)   (macenko_stain_extractor.py:22)
-        const double m[3] = {sum[1] / n, sum[2] / n, sum[3] / n};
-        double C[3][3];
-        C[0][0] = sum[4] - n * m[0] * m[0]; C[0][1] = sum[5] - n * m[0] * m[1]; C[0][2] = sum[6] - n * m[0] * m[2];
-        C[1][1] = sum[7] - n * m[1] * m[1]; C[1][2] = sum[8] - n * m[1] * m[2]; C[2][2] = sum[9] - n * m[2] * m[2];
-        C[1][0] = C[0][1]; C[2][0] = C[0][2]; C[2][1] = C[1][2];
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) C[i][j] /= (n - 1.0);
-        jacobi_eigh3(C, w, V);
+        const double mx = sum[1] / n, my = sum[2] / n, mz = sum[3] / n, inv = 1.0 / (n - 1.0);
+        a00 = (sum[4] - n * mx * mx) * inv; a01 = (sum[5] - n * mx * my) * inv; a02 = (sum[6] - n * mx * mz) * inv;
+        a11 = (sum[7] - n * my * my) * inv; a12 = (sum[8] - n * my * mz) * inv; a22 = (sum[9] - n * mz * mz) * inv;
+        for (int sweep = 0; sweep < 30; ++sweep) {
+            const double off = fabs(a01) + fabs(a02) + fabs(a12);
+            const double dia = fabs(a00) + fabs(a11) + fabs(a22);
+            if (off <= 1e-300 || off <= 1e-22 * dia) break;
+            jacobi_rot(a00, a11, a01, a02, a12, v0, v1);
+            jacobi_rot(a00, a22, a02, a01, a12, v0, v2);
+            jacobi_rot(a11, a22, a12, a01, a02, v1, v2);
+        }
     }
     // eigh is ascending; the reference takes columns [2, 1] = largest, second largest (:24)
-    int o[3] = {0, 1, 2};
-    for (int i = 0; i < 2; ++i)
-        for (int j = 0; j < 2 - i; ++j)
-            if (w[o[j]] > w[o[j + 1]]) { const int t = o[j]; o[j] = o[j + 1]; o[j + 1] = t; }
-    const int sel[2] = {o[2], o[1]};
-    for (int k = 0; k < 2; ++k) {
-        const double sgn = V[0][sel[k]] < 0 ? -1.0 : 1.0;          // :26-27
-        for (int c = 0; c < 3; ++c) {
-            Vd[c * 2 + k] = sgn * V[c][sel[k]];
-            Vf[c * 2 + k] = (float)(sgn * V[c][sel[k]]);
-        }
+    double w0 = a00, w1 = a11, w2 = a22;
+#define SL_SWAP_COL(wa, wb, va, vb) do { const double tw = wa; wa = wb; wb = tw; \
+        for (int i_ = 0; i_ < 3; ++i_) { const double tv = va[i_]; va[i_] = vb[i_]; vb[i_] = tv; } } while (0)
+    if (w0 > w1) SL_SWAP_COL(w0, w1, v0, v1);
+    if (w1 > w2) SL_SWAP_COL(w1, w2, v1, v2);
+    if (w0 > w1) SL_SWAP_COL(w0, w1, v0, v1);
+#undef SL_SWAP_COL
+    const double s2 = v2[0] < 0 ? -1.0 : 1.0, s1 = v1[0] < 0 ? -1.0 : 1.0;      // :26-27
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        Vd[c * 2 + 0] = s2 * v2[c]; Vf[c * 2 + 0] = (float)(s2 * v2[c]);
+        Vd[c * 2 + 1] = s1 * v1[c]; Vf[c * 2 + 1] = (float)(s1 * v1[c]);
     }
     return status;
 }
 
 // pseudo-angle order statistics -> stain matrix (macenko_stain_extractor.py:33-44)
-__device__ inline void stain_matrix_from_angles(const double* Vd, const float* xs /*[4]*/, const double* gfrac, double* M) {
+__device__ __forceinline__ void stain_matrix_from_angles(const double* Vd, const float* xs /*[4]*/, const double* gfrac, double* M) {
     const double minPhi = np_lerp(angle_of_pseudo((double)xs[0]), angle_of_pseudo((double)xs[1]), gfrac[0]);
     const double maxPhi = np_lerp(angle_of_pseudo((double)xs[2]), angle_of_pseudo((double)xs[3]), gfrac[1]);
+    double s1, c1, s2, c2;
+    sincos(minPhi, &s1, &c1);
+    sincos(maxPhi, &s2, &c2);
     double v1[3], v2[3];
+#pragma unroll
     for (int c = 0; c < 3; ++c) {                         // :36-37
-        v1[c] = Vd[c * 2] * cos(minPhi) + Vd[c * 2 + 1] * sin(minPhi);
-        v2[c] = Vd[c * 2] * cos(maxPhi) + Vd[c * 2 + 1] * sin(maxPhi);
+        v1[c] = Vd[c * 2] * c1 + Vd[c * 2 + 1] * s1;
+        v2[c] = Vd[c * 2] * c2 + Vd[c * 2 + 1] * s2;
     }
-    const double* h = v1[0] > v2[0] ? v1 : v2;            // :40-43
-    const double* e = v1[0] > v2[0] ? v2 : v1;
+    const bool first = v1[0] > v2[0];                     // :40-43
+    double h[3], e[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { h[c] = first ? v1[c] : v2[c]; e[c] = first ? v2[c] : v1[c]; }
     const double nh = sqrt(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]);
     const double ne = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+#pragma unroll
     for (int c = 0; c < 3; ++c) { M[c] = h[c] / nh; M[3 + c] = e[c] / ne; }   // :44
 }
 
@@ -393,8 +523,9 @@ __device__ inline void stain_matrix_from_angles(const double* Vd, const float* x
 struct Moments {
     double sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
     uint32_t cnt = 0;
-    __device__ __forceinline__ void add(double x, double y, double z) {
-        cnt += 1;
+    __device__ __forceinline__ void add(bool on, double x, double y, double z) {
+        x = on ? x : 0.0; y = on ? y : 0.0; z = on ? z : 0.0;
+        cnt += on ? 1u : 0u;
         sx += x; sy += y; sz += z;
         sxx = fma(x, x, sxx); sxy = fma(x, y, sxy); sxz = fma(x, z, sxz);
         syy = fma(y, y, syy); syz = fma(y, z, syz); szz = fma(z, z, szz);
@@ -406,9 +537,9 @@ struct Moments {
 };
 
 // sweep 1 over chunks [c0, c1) with `nthreads` cooperating threads (thread index t)
-template <bool ALIGNED, class SampleStore>
+template <bool ALIGNED, class TABS, class SampleStore>
 __device__ __forceinline__ void moments_sweep(const uint8_t* src, int P, int c0, int c1, int t, int nthreads,
-                                              const TabEntry* s_tab, uint32_t y_lim, int stride_log2,
+                                              const TABS& T, uint32_t y_lim, int stride_log2,
                                               SampleStore store_sample, Moments& mo) {
     const size_t nbytes = (size_t)P * 3;
     const int cps_log2 = stride_log2 - 2;          // chunks per sampling block
@@ -425,16 +556,19 @@ __device__ __forceinline__ void moments_sweep(const uint8_t* src, int P, int c0,
             const bool live = cc < c1;
             const uint32_t b = (uint32_t)cc >> cps_log2;        // stratified sample: block b keeps pixel b*stride+off
             const uint32_t off = sample_offset(b, stride_log2);
-            const bool has_sample = live && ((off >> 2) == ((uint32_t)cc & ((1u << cps_log2) - 1)));
+            const bool has_sample = live & ((off >> 2) == ((uint32_t)cc & ((1u << cps_log2) - 1)));
 #pragma unroll
             for (int px = 0; px < 4; ++px) {
                 const uint32_t r = chunk_byte(in[u], 3 * px), g = chunk_byte(in[u], 3 * px + 1),
                                bb = chunk_byte(in[u], 3 * px + 2);
-                const TabEntry er = s_tab[r], eg = s_tab[g], eb = s_tab[bb];
-                const bool inb = live && (ALIGNED || (size_t)cc * 4 + px < (size_t)P);
-                const bool tissue = inb && is_tissue(er.gamma, eg.gamma, eb.gamma, y_lim);
-                if (tissue) mo.add(er.od, eg.od, eb.od);
-                if (has_sample && (off & 3) == (uint32_t)px && inb)
+                // branch-free on purpose: every table read is unconditional so that the compiler can issue
+                // all LDS gathers of a trip back to back (a short-circuit && here costs 2.5x in time)
+                const uint32_t gr = T.gam(r, t), gg = T.gam(g, t), gb = T.gam(bb, t);
+                const double ox = T.od64(r, t), oy = T.od64(g, t), oz = T.od64(bb, t);
+                const bool inb = live & (ALIGNED | ((size_t)cc * 4 + px < (size_t)P));
+                const bool tissue = inb & is_tissue(gr, gg, gb, y_lim);
+                mo.add(tissue, ox, oy, oz);
+                if (has_sample & ((off & 3) == (uint32_t)px) & inb)
                     store_sample(b, r | (g << 8) | (bb << 16) | ((tissue ? 1u : 0u) << 24));
             }
         }
@@ -450,10 +584,11 @@ struct SelConsts {
 };
 
 // sweeps 2/3 over chunks [c0, c1): wave-uniform trip count so that ballots see every lane.
-// Sink: push(list, flag, key, lane) collects bracket members.
-template <int STAGE, bool ALIGNED, class Sink>
+// Per trip a lane classifies 8 pixels against both brackets; the bracket members are handed to the
+// sink in ONE commit per list (one reservation per trip instead of one per pixel).
+template <int STAGE, bool ALIGNED, class TABS, class Sink>
 __device__ __forceinline__ void select_sweep(const uint8_t* src, int P, int c0, int c1, int t, int nthreads,
-                                             const TabEntry* s_tab, uint32_t y_lim, const SelConsts& K, Sink& sink,
+                                             const TABS& T, uint32_t y_lim, const SelConsts& K, Sink& sink,
                                              uint32_t (&cnt)[4]) {
     const size_t nbytes = (size_t)P * 3;
     const int lane = t & 63;
@@ -464,43 +599,95 @@ __device__ __forceinline__ void select_sweep(const uint8_t* src, int P, int c0, 
             const int cc = cb + lane + u * nthreads;
             in[u] = cc < c1 ? load_chunk<ALIGNED>(src, nbytes, cc) : Chunk{0xffffffffu, 0xffffffffu, 0xffffffffu};
         }
+        float k0[8], k1[8];
+        bool f0[8], f1[8];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int cc = cb + lane + u * nthreads;
             const bool live = cc < c1;
 #pragma unroll
             for (int px = 0; px < 4; ++px) {
+                const int j = u * 4 + px;
                 const uint32_t r = chunk_byte(in[u], 3 * px), g = chunk_byte(in[u], 3 * px + 1),
                                bb = chunk_byte(in[u], 3 * px + 2);
-                const TabEntry er = s_tab[r], eg = s_tab[g], eb = s_tab[bb];
-                const bool inb = live && (ALIGNED || (size_t)cc * 4 + px < (size_t)P);
-                float k0, k1;
+                const float ox = T.odf(r, t), oy = T.odf(g, t), oz = T.odf(bb, t);
+                const bool inb = live & (ALIGNED | ((size_t)cc * 4 + px < (size_t)P));
                 bool valid;
                 if (STAGE == kStageAngle) {
-                    valid = inb && is_tissue(er.gamma, eg.gamma, eb.gamma, y_lim);
-                    k0 = k1 = angle_key(K.V, er.odf, eg.odf, eb.odf);
+                    const uint32_t gr = T.gam(r, t), gg = T.gam(g, t), gb = T.gam(bb, t);
+                    valid = inb & is_tissue(gr, gg, gb, y_lim);
+                    k0[j] = k1[j] = angle_key(K.V, ox, oy, oz);
                 } else {
                     valid = inb;
-                    lasso2(K.L, er.odf, eg.odf, eb.odf, k0, k1);
+                    lasso2(K.L, ox, oy, oz, k0[j], k1[j]);
                 }
-                const bool b_lt0 = valid & (k0 < K.lo0), b_le0 = valid & (k0 <= K.hi0);
-                const bool b_lt1 = valid & (k1 < K.lo1), b_le1 = valid & (k1 <= K.hi1);
-                cnt[0] += __popcll(__ballot(b_lt0));
-                cnt[1] += __popcll(__ballot(b_le0));
-                cnt[2] += __popcll(__ballot(b_lt1));
-                cnt[3] += __popcll(__ballot(b_le1));
-                sink.push(0, b_le0 & !b_lt0, k0, lane);
-                sink.push(1, b_le1 & !b_lt1, k1, lane);
+                const bool b_lt0 = valid & (k0[j] < K.lo0), b_le0 = valid & (k0[j] <= K.hi0);
+                const bool b_lt1 = valid & (k1[j] < K.lo1), b_le1 = valid & (k1[j] <= K.hi1);
+                // per-LANE counters (v_cmp + v_addc): a ballot/popcount per pixel serialises the wave on the
+                // scalar unit (measured: 25 SALU instructions per pixel slot, 2x the sweep time)
+                cnt[0] += b_lt0 ? 1u : 0u;
+                cnt[1] += b_le0 ? 1u : 0u;
+                cnt[2] += b_lt1 ? 1u : 0u;
+                cnt[3] += b_le1 ? 1u : 0u;
+                f0[j] = b_le0 & !b_lt0;
+                f1[j] = b_le1 & !b_lt1;
             }
-            sink.after_chunk(lane);
         }
+        sink.commit(0, f0, k0, lane);
+        sink.commit(1, f1, k1, lane);
     }
 }
+
+// ---- key functors handed BY VALUE to the (non-inlined) selection primitives ----
+struct CandKey {
+    const float* cand;
+    __device__ __forceinline__ float operator()(int i) const { return cand[i]; }
+};
+// pseudo-angle of sample entry b (NaN: not tissue / beyond the tile)
+struct SampleAngleKey {
+    const uint32_t* sample; TabView tab; float V[6]; int stride_log2; int P;
+    __device__ __forceinline__ float operator()(int b) const {
+        const long long pix = ((long long)b << stride_log2) + sample_offset(b, stride_log2);
+        if (pix >= P) return nan_f();
+        const uint32_t s = sample[b];
+        if (!(s >> 24)) return nan_f();
+        return angle_key(V, tab.odf(s & 255u), tab.odf((s >> 8) & 255u), tab.odf((s >> 16) & 255u));
+    }
+};
+// concentration `col` of sample entry b (all pixels, tissue or not)
+struct SampleConcKey {
+    const uint32_t* sample; TabView tab; LassoK L; int stride_log2; int P; int col;
+    __device__ __forceinline__ float operator()(int b) const {
+        const long long pix = ((long long)b << stride_log2) + sample_offset(b, stride_log2);
+        if (pix >= P) return nan_f();
+        const uint32_t s = sample[b];
+        float c1, c2;
+        lasso2(L, tab.odf(s & 255u), tab.odf((s >> 8) & 255u), tab.odf((s >> 16) & 255u), c1, c2);
+        return col == 0 ? c1 : c2;
+    }
+};
+// keys of pixel p of a whole tile (exact fallback)
+struct AngleTileKey {
+    const uint8_t* src; TabView tab; float V[6]; uint32_t y_lim;
+    __device__ __forceinline__ float operator()(int p) const {
+        const uint32_t r = src[3 * (size_t)p], g = src[3 * (size_t)p + 1], b = src[3 * (size_t)p + 2];
+        if (!is_tissue(tab.gam(r), tab.gam(g), tab.gam(b), y_lim)) return nan_f();
+        return angle_key(V, tab.odf(r), tab.odf(g), tab.odf(b));
+    }
+};
+struct ConcTileKey {
+    const uint8_t* src; TabView tab; LassoK L; int col;
+    __device__ __forceinline__ float operator()(int p) const {
+        float c1, c2;
+        lasso2(L, tab.odf(src[3 * (size_t)p]), tab.odf(src[3 * (size_t)p + 1]), tab.odf(src[3 * (size_t)p + 2]), c1, c2);
+        return col == 0 ? c1 : c2;
+    }
+};
 
 // Exact order statistics (k, k+1) of one list of a selection stage: from the collected candidates
 // when the bracket verified, else by exact selection over the whole tile (rare).
 template <class TileKeyAt>
-__device__ void stage_order_stats(const float* cand, float lo, float hi, uint32_t lt, uint32_t le, uint32_t nc,
+__device__ __forceinline__ void stage_order_stats(const float* cand, float lo, float hi, uint32_t lt, uint32_t le, uint32_t nc,
                                   int P, TileKeyAt tile_key_at, uint32_t n, long long k, float& xa, float& xb,
                                   int& fallbacks, SelScratch& S) {
     const long long k2 = (k + 1 < (long long)n) ? k + 1 : k;
@@ -509,8 +696,7 @@ __device__ void stage_order_stats(const float* cand, float lo, float hi, uint32_
     if (covered && lo == hi) {               // every member of the bracket equals lo
         xa = xb = lo;
     } else if (covered && (long long)nc == in && nc <= (uint32_t)kCapList) {
-        auto at = [&](int i) -> float { return cand[i]; };
-        wg_select_pair((int)nc, at, (uint32_t)(k - lt), xa, xb, S);
+        wg_select_pair_small((int)nc, CandKey{cand}, (uint32_t)(k - lt), xa, xb, S);
         if (k2 == k) xb = xa;
     } else {                                 // exact, slow, rare
         wg_select_pair(P, tile_key_at, (uint32_t)k, xa, xb, S);
@@ -524,9 +710,9 @@ __device__ void stage_order_stats(const float* cand, float lo, float hi, uint32_
 // ------------------------------------------------------------------------------------------
 template <bool ALIGNED>
 static __global__ __launch_bounds__(kWG) void k_moments(StatsArgs a) {
-    __shared__ TabEntry s_tab[256];
+    __shared__ Tabs<1, 8, 4> s_tab;
     __shared__ double s_red[kWG / 64][10];
-    fill_tab(s_tab);
+    s_tab.fill();
     __syncthreads();
     const int tile = blockIdx.x / a.parts, part = blockIdx.x % a.parts;
     const int tid = threadIdx.x;
@@ -552,12 +738,29 @@ static __global__ __launch_bounds__(kWG) void k_moments(StatsArgs a) {
     }
 }
 
+// brackets of both angular quantiles from the sample
+__device__ __forceinline__ void angle_brackets(const SampleAngleKey& key, int n_sample, double pct, float* lo, float* hi,
+                                               SelScratch& S) {
+    const double p2[2] = {100.0 - pct, pct};          // minPhi, maxPhi (macenko_stain_extractor.py:33-34)
+    wg_sample_brackets(n_sample, key, 2, p2, lo, hi, S);
+}
+// brackets of the 99th percentile of both concentration columns from the sample (normalizer.py:36,47)
+__device__ __forceinline__ void conc_brackets(SampleConcKey key, int n_sample, float* lo, float* hi, SelScratch& S) {
+    const double p1[1] = {99.0};
+    for (int col = 0; col < 2; ++col) {
+        key.col = col;
+        wg_sample_brackets(n_sample, key, 1, p1, lo + col, hi + col, S);
+    }
+}
+
 static __global__ __launch_bounds__(kFinishThreads) void k_finish_moments(StatsArgs a) {
+    __shared__ Tabs<1, 1, 0> s_tab;
     __shared__ SelScratch S;
     __shared__ double s_sum[10];
     __shared__ float s_V[6];
     const int tile = blockIdx.x, tid = threadIdx.x;
     TileState& st = a.state[tile];
+    s_tab.fill();
     if (tid < 10) {                                   // fixed order => run-to-run identical sums
         double t = 0;
         for (int p = 0; p < a.parts; ++p) t += a.partials[((size_t)tile * a.parts + p) * 10 + tid];
@@ -574,36 +777,27 @@ static __global__ __launch_bounds__(kFinishThreads) void k_finish_moments(StatsA
         for (int i = 0; i < 2; ++i) { st.lt[i] = 0; st.le[i] = 0; st.ncand[i] = 0; }
     }
     __syncthreads();
-    const uint32_t* samp = a.sample + (size_t)tile * a.n_sample;
-    float Vr[6];
-    for (int i = 0; i < 6; ++i) Vr[i] = s_V[i];
-    auto key_at = [&](int b) -> float {
-        const long long pix = ((long long)b << a.stride_log2) + sample_offset(b, a.stride_log2);
-        if (pix >= a.P) return nan_f();
-        const uint32_t s = samp[b];
-        if (!(s >> 24)) return nan_f();
-        return angle_key(Vr, d_od_f32[s & 255u], d_od_f32[(s >> 8) & 255u], d_od_f32[(s >> 16) & 255u]);
-    };
-    float lo0, hi0, lo1, hi1;
-    const uint32_t nv = wg_count_valid(a.n_sample, key_at, S);
-    wg_sample_bracket(a.n_sample, key_at, nv, 100.0 - a.pct, lo0, hi0, S);   // minPhi (:33)
-    wg_sample_bracket(a.n_sample, key_at, nv, a.pct, lo1, hi1, S);           // maxPhi (:34)
-    if (tid == 0) { st.lo[0] = lo0; st.hi[0] = hi0; st.lo[1] = lo1; st.hi[1] = hi1; }
+    SampleAngleKey key;
+    key.sample = a.sample + (size_t)tile * a.n_sample;
+    key.tab = s_tab.view();
+    for (int i = 0; i < 6; ++i) key.V[i] = s_V[i];
+    key.stride_log2 = a.stride_log2;
+    key.P = a.P;
+    float lo[2], hi[2];
+    angle_brackets(key, a.n_sample, a.pct, lo, hi, S);
+    if (tid == 0) { st.lo[0] = lo[0]; st.hi[0] = hi[0]; st.lo[1] = lo[1]; st.hi[1] = hi[1]; }
 }
 
-struct WaveStageSink {              // per-wave candidate staging in LDS, flushed with ONE global atomic
-    float* buf[2];
-    uint32_t n[2];
-    float* dst[2];
-    unsigned int* counter[2];
-    __device__ __forceinline__ void push(int li, bool flag, float v, int lane) {
-        const unsigned long long m = __ballot(flag);
-        if (m) {
-            const uint32_t pos = n[li] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-            if (flag) buf[li][pos] = v;
-            n[li] += __popcll(m);
-        }
-    }
+// Bracket members are staged per wave in LDS and written out in bursts: the list head (a global
+// or LDS counter) is touched once per burst and the global stores are dense.  Scattered masked
+// stores straight from the sweep made it VMEM-issue bound (16 mostly-empty store instructions per
+// 8 pixels).
+template <int CAP>
+struct StagedSink {
+    float* buf[2];              // LDS, this wave's CAP entries per list
+    uint32_t n[2];              // wave-uniform fill
+    float* dst[2];              // global candidate lists
+    unsigned int* counter[2];   // list heads
     __device__ __forceinline__ void flush(int li, int lane) {
         if (n[li] == 0) return;
         uint32_t base = 0;
@@ -613,18 +807,28 @@ struct WaveStageSink {              // per-wave candidate staging in LDS, flushe
             if (base + i < (uint32_t)kCapList) dst[li][base + i] = buf[li][i];
         n[li] = 0;
     }
-    // a chunk adds at most 4*64 entries per list: keep that much room (wave-uniform test)
-    __device__ __forceinline__ void after_chunk(int lane) {
-        if (n[0] > kWaveStage - 256) flush(0, lane);
-        if (n[1] > kWaveStage - 256) flush(1, lane);
+    __device__ __forceinline__ void commit(int li, const bool (&f)[8], const float (&k)[8], int lane) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned long long m = __ballot(f[j]);
+            if (m) {                                                   // wave-uniform
+                const uint32_t c = __popcll(m);
+                if (n[li] + c > (uint32_t)CAP) flush(li, lane);
+                const uint32_t pos = n[li] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+                if (f[j]) buf[li][pos] = k[j];
+                n[li] += c;
+            }
+        }
     }
 };
+constexpr int kStageMulti = 256;    // per-wave staging entries per list, multi-kernel select (4 waves)
+constexpr int kStageFused = 128;    // fused kernel (8 waves)
 
 template <int STAGE, bool ALIGNED>
 static __global__ __launch_bounds__(kWG) void k_select(StatsArgs a) {
-    __shared__ TabEntry s_tab[256];
-    __shared__ float s_stage[2][kWG / 64][kWaveStage];
-    fill_tab(s_tab);
+    __shared__ Tabs<8, 8, 0> s_tab;
+    __shared__ float s_stage[2][kWG / 64][kStageMulti];
+    s_tab.fill();
     const int tile = blockIdx.x / a.parts, part = blockIdx.x % a.parts;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     TileState& st = a.state[tile];
@@ -642,7 +846,7 @@ static __global__ __launch_bounds__(kWG) void k_select(StatsArgs a) {
     const int nch = (a.P + 3) >> 2;
     const int span = (nch + a.parts - 1) / a.parts;
     const int c0 = part * span, c1 = min(nch, c0 + span);
-    WaveStageSink sink;
+    StagedSink<kStageMulti> sink;
     for (int li = 0; li < 2; ++li) {
         sink.buf[li] = s_stage[li][wave];
         sink.n[li] = 0;
@@ -653,6 +857,8 @@ static __global__ __launch_bounds__(kWG) void k_select(StatsArgs a) {
     select_sweep<STAGE, ALIGNED>(src, a.P, c0, c1, tid, kWG, s_tab, a.y_lim, K, sink, cnt);
     sink.flush(0, lane);
     sink.flush(1, lane);
+    for (int i = 0; i < 4; ++i)
+        for (int o = 32; o > 0; o >>= 1) cnt[i] += __shfl_xor((int)cnt[i], o, 64);
     if (lane == 0) {
         if (cnt[0]) atomicAdd(&st.lt[0], cnt[0]);
         if (cnt[1]) atomicAdd(&st.le[0], cnt[1]);
@@ -661,25 +867,8 @@ static __global__ __launch_bounds__(kWG) void k_select(StatsArgs a) {
     }
 }
 
-// key of pixel p of a tile for the exact fallback
-struct AngleTileKey {
-    const uint8_t* src; const float* V; uint32_t y_lim;
-    __device__ __forceinline__ float operator()(int p) const {
-        const uint32_t r = src[3 * (size_t)p], g = src[3 * (size_t)p + 1], b = src[3 * (size_t)p + 2];
-        if (!is_tissue(d_gamma[r], d_gamma[g], d_gamma[b], y_lim)) return nan_f();
-        return angle_key(V, d_od_f32[r], d_od_f32[g], d_od_f32[b]);
-    }
-};
-struct ConcTileKey {
-    const uint8_t* src; const LassoK* L; int col;
-    __device__ __forceinline__ float operator()(int p) const {
-        float c1, c2;
-        lasso2(*L, d_od_f32[src[3 * (size_t)p]], d_od_f32[src[3 * (size_t)p + 1]], d_od_f32[src[3 * (size_t)p + 2]], c1, c2);
-        return col == 0 ? c1 : c2;
-    }
-};
-
 static __global__ __launch_bounds__(kFinishThreads) void k_finish_angle(StatsArgs a) {
+    __shared__ Tabs<1, 1, 0> s_tab;
     __shared__ SelScratch S;
     __shared__ float s_res[4];
     __shared__ LassoK s_L;
@@ -689,10 +878,12 @@ static __global__ __launch_bounds__(kFinishThreads) void k_finish_angle(StatsArg
         if (tid < 6) st.M[tid] = nan_d();
         return;
     }
-    float Vr[6];
-    for (int i = 0; i < 6; ++i) Vr[i] = st.Vf[i];
+    s_tab.fill();
+    __syncthreads();
     const uint8_t* src = a.rgb + (size_t)tile * a.P * 3;
-    const AngleTileKey tkey{src, Vr, a.y_lim};
+    AngleTileKey tkey;
+    tkey.src = src; tkey.tab = s_tab.view(); tkey.y_lim = a.y_lim;
+    for (int i = 0; i < 6; ++i) tkey.V[i] = st.Vf[i];
     const uint32_t T = (uint32_t)st.n_tissue;
     long long k[2];
     double gfrac[2];
@@ -717,27 +908,21 @@ static __global__ __launch_bounds__(kFinishThreads) void k_finish_angle(StatsArg
         for (int i = 0; i < 2; ++i) { st.lt[i] = 0; st.le[i] = 0; st.ncand[i] = 0; }
     }
     __syncthreads();
-    // brackets for np.percentile(C, 99, axis=0) from the sample (all pixels, tissue or not)
-    const LassoK L = s_L;
-    const uint32_t* samp = a.sample + (size_t)tile * a.n_sample;
-    for (int col = 0; col < 2; ++col) {
-        auto key_at = [&](int b) -> float {
-            const long long pix = ((long long)b << a.stride_log2) + sample_offset(b, a.stride_log2);
-            if (pix >= a.P) return nan_f();
-            const uint32_t s = samp[b];
-            float c1, c2;
-            lasso2(L, d_od_f32[s & 255u], d_od_f32[(s >> 8) & 255u], d_od_f32[(s >> 16) & 255u], c1, c2);
-            return col == 0 ? c1 : c2;
-        };
-        float lo, hi;
-        const uint32_t nv = wg_count_valid(a.n_sample, key_at, S);
-        wg_sample_bracket(a.n_sample, key_at, nv, 99.0, lo, hi, S);
-        if (tid == 0) { st.lo[col] = lo; st.hi[col] = hi; }
-    }
+    SampleConcKey ckey;
+    ckey.sample = a.sample + (size_t)tile * a.n_sample;
+    ckey.tab = s_tab.view();
+    ckey.L = s_L;
+    ckey.stride_log2 = a.stride_log2;
+    ckey.P = a.P;
+    ckey.col = 0;
+    float lo[2], hi[2];
+    conc_brackets(ckey, a.n_sample, lo, hi, S);
+    if (tid == 0) { st.lo[0] = lo[0]; st.hi[0] = hi[0]; st.lo[1] = lo[1]; st.hi[1] = hi[1]; }
 }
 
 static __global__ __launch_bounds__(kFinishThreads) void k_finish_conc(StatsArgs a, double* M_out, double* maxC_out,
                                                                        int32_t* status_out, int tile0) {
+    __shared__ Tabs<1, 1, 0> s_tab;
     __shared__ SelScratch S;
     __shared__ float s_res[4];
     __shared__ LassoK s_L;
@@ -745,15 +930,19 @@ static __global__ __launch_bounds__(kFinishThreads) void k_finish_conc(StatsArgs
     TileState& st = a.state[tile];
     const bool bad = st.status == SL_TILE_EMPTY_MASK || st.status == SL_TILE_DEGENERATE_COV;
     if (!bad) {
+        s_tab.fill();
         if (tid == 0) { LassoK L; lasso_consts(st.M, a.lam, L); s_L = L; }
         __syncthreads();
         long long k;
         double gfrac;
         percentile_pos((double)a.P, 99.0, k, gfrac);
         int fallbacks = 0;
-        const uint8_t* src = a.rgb + (size_t)tile * a.P * 3;
+        ConcTileKey tkey;
+        tkey.src = a.rgb + (size_t)tile * a.P * 3;
+        tkey.tab = s_tab.view();
+        tkey.L = s_L;
         for (int col = 0; col < 2; ++col) {
-            const ConcTileKey tkey{src, &s_L, col};
+            tkey.col = col;
             float xa, xb;
             stage_order_stats(a.cand + ((size_t)tile * 2 + col) * kCapList, st.lo[col], st.hi[col], st.lt[col],
                               st.le[col], st.ncand[col], a.P, tkey, (uint32_t)a.P, k, xa, xb, fallbacks, S);
@@ -791,31 +980,17 @@ struct FusedArgs {
     const double* M_tgt;     // transform only
     const double* maxC_tgt;  // transform only
     float* cand;             // [gridDim.x][2][kCapList]
+    uint32_t* sample;        // [gridDim.x][n_sample]
     double* M_out;           // [n_tiles][6]
     double* maxC_out;        // [n_tiles][2]
     int32_t* status_out;     // [n_tiles]
     int32_t* diag_out;       // [n_tiles] fallbacks (may be NULL)
-};
-
-struct LdsSink {                    // the tile belongs to this workgroup: the list heads live in LDS
-    unsigned int* ncand;            // LDS [2]
-    float* dst[2];                  // global
-    __device__ __forceinline__ void push(int li, bool flag, float v, int lane) {
-        const unsigned long long m = __ballot(flag);
-        if (m) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&ncand[li], (unsigned int)__popcll(m));
-            base = __builtin_amdgcn_readfirstlane(base);
-            const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-            if (flag && pos < (uint32_t)kCapList) dst[li][pos] = v;
-        }
-    }
-    __device__ __forceinline__ void after_chunk(int) {}
+    long long* phase_clock;  // [n_tiles][8] wall_clock64() at phase boundaries (development aid, may be NULL)
 };
 
 struct FusedShared {
-    TabEntry tab[256];
-    uint32_t sample[kMaxSample];
+    Tabs<32, 16, 4> tab;     // 32 + 16 + 8 KB
+    float stage[2][kFusedThreads / 64][kStageFused];   // 8 KB
     SelScratch S;
     double red[kFusedThreads / 64][10];
     double sum[10];
@@ -831,12 +1006,13 @@ struct FusedShared {
 };
 
 template <bool TRANSFORM, bool ALIGNED>
-static __global__ __launch_bounds__(kFusedThreads) void k_macenko_fused(FusedArgs a) {
+static __global__ __launch_bounds__(kFusedThreads, 4) void k_macenko_fused(FusedArgs a) {
     __shared__ FusedShared sh;
     const int tid = threadIdx.x, lane = tid & 63;
-    fill_tab(sh.tab);
+    sh.tab.fill();
     __syncthreads();
     const int nch = (a.P + 3) >> 2;
+    uint32_t* samp = a.sample + (size_t)blockIdx.x * a.n_sample;
     float* cand0 = a.cand + ((size_t)blockIdx.x * 2 + 0) * kCapList;
     float* cand1 = a.cand + ((size_t)blockIdx.x * 2 + 1) * kCapList;
 
@@ -844,11 +1020,12 @@ static __global__ __launch_bounds__(kFusedThreads) void k_macenko_fused(FusedArg
         const size_t nbytes = (size_t)a.P * 3;
         const uint8_t* src = a.rgb + (size_t)tile * nbytes;
         int fallbacks = 0;
-
+#define SL_PHASE(i) do { if (a.phase_clock && tid == 0) a.phase_clock[(size_t)tile * 8 + (i)] = wall_clock64(); } while (0)
+        SL_PHASE(0);
         // ---------------- sweep 1: moments + sample (into LDS)
         {
             Moments mo;
-            auto store = [&](uint32_t b, uint32_t v) { sh.sample[b] = v; };
+            auto store = [&](uint32_t b, uint32_t v) { samp[b] = v; };
             moments_sweep<ALIGNED>(src, a.P, 0, nch, tid, kFusedThreads, sh.tab, a.y_lim, a.stride_log2, store, mo);
             double v[10];
             mo.to_array(v);
@@ -864,7 +1041,8 @@ static __global__ __launch_bounds__(kFusedThreads) void k_macenko_fused(FusedArg
             sh.sum[tid] = t;
         }
         __syncthreads();
-        // ---------------- finish 1
+        SL_PHASE(1);
+        // ---------------- finish 1: eigenvectors, angle brackets
         if (tid == 0) {
             double Vd[6];
             float Vf[6];
@@ -875,25 +1053,32 @@ static __global__ __launch_bounds__(kFusedThreads) void k_macenko_fused(FusedArg
         __syncthreads();
         const bool bad = sh.status == SL_TILE_EMPTY_MASK || sh.status == SL_TILE_DEGENERATE_COV;   // block-uniform
         if (!bad) {
-            SelConsts K;
-            for (int i = 0; i < 6; ++i) K.V[i] = uni(sh.Vf[i]);
             {
-                auto key_at = [&](int b) -> float {
-                    const long long pix = ((long long)b << a.stride_log2) + sample_offset(b, a.stride_log2);
-                    if (pix >= a.P) return nan_f();
-                    const uint32_t s = sh.sample[b];
-                    if (!(s >> 24)) return nan_f();
-                    return angle_key(K.V, d_od_f32[s & 255u], d_od_f32[(s >> 8) & 255u], d_od_f32[(s >> 16) & 255u]);
-                };
-                const uint32_t nv = wg_count_valid(a.n_sample, key_at, sh.S);
-                wg_sample_bracket(a.n_sample, key_at, nv, 100.0 - a.pct, K.lo0, K.hi0, sh.S);
-                wg_sample_bracket(a.n_sample, key_at, nv, a.pct, K.lo1, K.hi1, sh.S);
+                SampleAngleKey key;
+                key.sample = samp; key.tab = sh.tab.view(); key.stride_log2 = a.stride_log2; key.P = a.P;
+                for (int i = 0; i < 6; ++i) key.V[i] = sh.Vf[i];
+                float lo[2], hi[2];
+                angle_brackets(key, a.n_sample, a.pct, lo, hi, sh.S);
+                if (tid == 0) { sh.lo[0] = lo[0]; sh.hi[0] = hi[0]; sh.lo[1] = lo[1]; sh.hi[1] = hi[1]; }
+                __syncthreads();
             }
+            SL_PHASE(2);
             // ---------------- sweep 2: angle select
             {
-                LdsSink sink{sh.ncand, {cand0, cand1}};
+                SelConsts K;
+                for (int i = 0; i < 6; ++i) K.V[i] = uni(sh.Vf[i]);
+                K.lo0 = uni(sh.lo[0]); K.hi0 = uni(sh.hi[0]); K.lo1 = uni(sh.lo[1]); K.hi1 = uni(sh.hi[1]);
+                StagedSink<kStageFused> sink;
+                sink.buf[0] = sh.stage[0][tid >> 6]; sink.buf[1] = sh.stage[1][tid >> 6];
+                sink.n[0] = sink.n[1] = 0;
+                sink.dst[0] = cand0; sink.dst[1] = cand1;
+                sink.counter[0] = &sh.ncand[0]; sink.counter[1] = &sh.ncand[1];
                 uint32_t cnt[4] = {0, 0, 0, 0};
                 select_sweep<kStageAngle, ALIGNED>(src, a.P, 0, nch, tid, kFusedThreads, sh.tab, a.y_lim, K, sink, cnt);
+                sink.flush(0, lane);
+                sink.flush(1, lane);
+                for (int i = 0; i < 4; ++i)
+                    for (int o = 32; o > 0; o >>= 1) cnt[i] += __shfl_xor((int)cnt[i], o, 64);
                 if (lane == 0) {
                     if (cnt[0]) atomicAdd(&sh.lt[0], cnt[0]);
                     if (cnt[1]) atomicAdd(&sh.le[0], cnt[1]);
@@ -903,18 +1088,20 @@ static __global__ __launch_bounds__(kFusedThreads) void k_macenko_fused(FusedArg
             }
             __threadfence_block();
             __syncthreads();
-            // ---------------- finish 2: exact angular percentiles -> M
+            SL_PHASE(3);
+            // ---------------- finish 2: exact angular percentiles -> M ; concentration brackets
             {
                 const uint32_t T = (uint32_t)sh.sum[0];
                 long long k[2];
                 double gfrac[2];
                 percentile_pos((double)T, 100.0 - a.pct, k[0], gfrac[0]);
                 percentile_pos((double)T, a.pct, k[1], gfrac[1]);
-                const AngleTileKey tkey{src, K.V, a.y_lim};
-                const float los[2] = {K.lo0, K.lo1}, his[2] = {K.hi0, K.hi1};
+                AngleTileKey tkey;
+                tkey.src = src; tkey.tab = sh.tab.view(); tkey.y_lim = a.y_lim;
+                for (int i = 0; i < 6; ++i) tkey.V[i] = sh.Vf[i];
                 for (int li = 0; li < 2; ++li) {
                     float xa, xb;
-                    stage_order_stats(li ? cand1 : cand0, los[li], his[li], sh.lt[li], sh.le[li], sh.ncand[li], a.P,
+                    stage_order_stats(li ? cand1 : cand0, sh.lo[li], sh.hi[li], sh.lt[li], sh.le[li], sh.ncand[li], a.P,
                                       tkey, T, k[li], xa, xb, fallbacks, sh.S);
                     if (tid == 0) { sh.res[2 * li] = xa; sh.res[2 * li + 1] = xb; }
                     __syncthreads();
@@ -929,30 +1116,32 @@ static __global__ __launch_bounds__(kFusedThreads) void k_macenko_fused(FusedArg
                     for (int i = 0; i < 2; ++i) { sh.lt[i] = 0; sh.le[i] = 0; sh.ncand[i] = 0; }
                 }
                 __syncthreads();
-            }
-            K.L = sh.L;
-            uni(K.L);
-            {
+                SampleConcKey ckey;
+                ckey.sample = samp; ckey.tab = sh.tab.view(); ckey.L = sh.L; ckey.stride_log2 = a.stride_log2;
+                ckey.P = a.P; ckey.col = 0;
                 float lo[2], hi[2];
-                for (int col = 0; col < 2; ++col) {
-                    auto key_at = [&](int b) -> float {
-                        const long long pix = ((long long)b << a.stride_log2) + sample_offset(b, a.stride_log2);
-                        if (pix >= a.P) return nan_f();
-                        const uint32_t s = sh.sample[b];
-                        float c1, c2;
-                        lasso2(K.L, d_od_f32[s & 255u], d_od_f32[(s >> 8) & 255u], d_od_f32[(s >> 16) & 255u], c1, c2);
-                        return col == 0 ? c1 : c2;
-                    };
-                    const uint32_t nv = wg_count_valid(a.n_sample, key_at, sh.S);
-                    wg_sample_bracket(a.n_sample, key_at, nv, 99.0, lo[col], hi[col], sh.S);
-                }
-                K.lo0 = lo[0]; K.hi0 = hi[0]; K.lo1 = lo[1]; K.hi1 = hi[1];
+                conc_brackets(ckey, a.n_sample, lo, hi, sh.S);
+                if (tid == 0) { sh.lo[0] = lo[0]; sh.hi[0] = hi[0]; sh.lo[1] = lo[1]; sh.hi[1] = hi[1]; }
+                __syncthreads();
             }
+            SL_PHASE(4);
             // ---------------- sweep 3: concentration select
             {
-                LdsSink sink{sh.ncand, {cand0, cand1}};
+                SelConsts K;
+                K.L = sh.L;
+                uni(K.L);
+                K.lo0 = uni(sh.lo[0]); K.hi0 = uni(sh.hi[0]); K.lo1 = uni(sh.lo[1]); K.hi1 = uni(sh.hi[1]);
+                StagedSink<kStageFused> sink;
+                sink.buf[0] = sh.stage[0][tid >> 6]; sink.buf[1] = sh.stage[1][tid >> 6];
+                sink.n[0] = sink.n[1] = 0;
+                sink.dst[0] = cand0; sink.dst[1] = cand1;
+                sink.counter[0] = &sh.ncand[0]; sink.counter[1] = &sh.ncand[1];
                 uint32_t cnt[4] = {0, 0, 0, 0};
                 select_sweep<kStageConc, ALIGNED>(src, a.P, 0, nch, tid, kFusedThreads, sh.tab, a.y_lim, K, sink, cnt);
+                sink.flush(0, lane);
+                sink.flush(1, lane);
+                for (int i = 0; i < 4; ++i)
+                    for (int o = 32; o > 0; o >>= 1) cnt[i] += __shfl_xor((int)cnt[i], o, 64);
                 if (lane == 0) {
                     if (cnt[0]) atomicAdd(&sh.lt[0], cnt[0]);
                     if (cnt[1]) atomicAdd(&sh.le[0], cnt[1]);
@@ -962,16 +1151,18 @@ static __global__ __launch_bounds__(kFusedThreads) void k_macenko_fused(FusedArg
             }
             __threadfence_block();
             __syncthreads();
+            SL_PHASE(5);
             // ---------------- finish 3: exact 99th percentiles -> maxC
             {
                 long long k;
                 double gfrac;
                 percentile_pos((double)a.P, 99.0, k, gfrac);
-                const float los[2] = {K.lo0, K.lo1}, his[2] = {K.hi0, K.hi1};
+                ConcTileKey tkey;
+                tkey.src = src; tkey.tab = sh.tab.view(); tkey.L = sh.L;
                 for (int col = 0; col < 2; ++col) {
-                    const ConcTileKey tkey{src, &sh.L, col};
+                    tkey.col = col;
                     float xa, xb;
-                    stage_order_stats(col ? cand1 : cand0, los[col], his[col], sh.lt[col], sh.le[col], sh.ncand[col],
+                    stage_order_stats(col ? cand1 : cand0, sh.lo[col], sh.hi[col], sh.lt[col], sh.le[col], sh.ncand[col],
                                       a.P, tkey, (uint32_t)a.P, k, xa, xb, fallbacks, sh.S);
                     if (tid == 0) { sh.res[2 * col] = xa; sh.res[2 * col + 1] = xb; }
                     __syncthreads();
@@ -992,7 +1183,7 @@ static __global__ __launch_bounds__(kFusedThreads) void k_macenko_fused(FusedArg
         if (tid < 2 && a.maxC_out) a.maxC_out[(size_t)tile * 2 + tid] = sh.maxC[tid];
         if (tid == 0 && a.status_out) a.status_out[tile] = sh.status;
         if (tid == 0 && a.diag_out) a.diag_out[tile] = fallbacks;
-
+        SL_PHASE(6);
         // ---------------- sweep 4: apply
         if (TRANSFORM) {
             uint8_t* dst = a.out + (size_t)tile * nbytes;
@@ -1021,9 +1212,9 @@ static __global__ __launch_bounds__(kFusedThreads) void k_macenko_fused(FusedArg
                         uint32_t ob[12];
 #pragma unroll
                         for (int px = 0; px < 4; ++px) {
-                            const float x = sh.tab[chunk_byte(in[u], 3 * px + 0)].odf;
-                            const float y = sh.tab[chunk_byte(in[u], 3 * px + 1)].odf;
-                            const float z = sh.tab[chunk_byte(in[u], 3 * px + 2)].odf;
+                            const float x = sh.tab.odf(chunk_byte(in[u], 3 * px + 0), tid);
+                            const float y = sh.tab.odf(chunk_byte(in[u], 3 * px + 1), tid);
+                            const float z = sh.tab.odf(chunk_byte(in[u], 3 * px + 2), tid);
                             float c1, c2, v[3];
                             lasso2(L, x, y, z, c1, c2);
                             recon_px<false>(R, c1, c2, v);
@@ -1040,6 +1231,8 @@ static __global__ __launch_bounds__(kFusedThreads) void k_macenko_fused(FusedArg
             }
         }
         __syncthreads();     // sh.* is reused by the next tile
+        SL_PHASE(7);
+#undef SL_PHASE
     }
 }
 
