@@ -56,7 +56,8 @@ extern "C" {
 /* skimage semantics selector for sl_hed_augment */
 #define SL_HED_SKIMAGE_018 0 /* ln(max(rgb,1e-6))/ln(1e-6) @ hed_from_rgb  (golden-pinned) */
 #define SL_HED_SKIMAGE_019 1 /* as 0.18 + stains clamped at 0 after separation */
-#define SL_HED_SKIMAGE_017 2 /* -log10(rgb+2) @ hed_from_rgb ; 10^(-x) - 2 */
+/* scikit-image 0.17 (the version pinned in the reference's environment.yml:107) is NOT offered: its
+ * log10(rgb+2) formulation cannot be checked against any source or wheel available to this build. */
 
 /* Optional kernel timing.  When SlParams.profile is non-NULL, sl_*_fit / sl_*_transform bracket every
  * launch of the selected kernel classes with two caller-created hipEvent_t from events[] (start, stop),
@@ -145,10 +146,11 @@ int sl_vahadane_transform(const uint8_t* rgb, uint8_t* out, int n, int h, int w,
 
 /* HedColorAugmenter.transform (augmentation/augmenter.py:276-331) for uint8 tiles:
  * cutoff test on the tile mean, rgb2hed, per-channel x*(1+sigma)+bias, hed2rgb, clip, *255,
- * truncate.  sigma, bias: n x 3 float.  applied[i] = 0 when tile i failed the cutoff test
- * (its pixels are copied through unchanged). */
+ * truncate.  sigma, bias: n x 3 double (H, E, D).  applied[i] (may be NULL) = 0 when tile i failed
+ * cutoff_lo <= mean/255 <= cutoff_hi; such a tile is copied through unchanged.
+ * workspace: sl_workspace_bytes(SL_OP_HED_AUGMENT, n, h, w) = 8 n bytes. */
 int sl_hed_augment(const uint8_t* rgb, uint8_t* out, int n, int h, int w,
-                   const float* sigma, const float* bias, float cutoff_lo, float cutoff_hi,
+                   const double* sigma, const double* bias, double cutoff_lo, double cutoff_hi,
                    int skimage_mode, int32_t* applied,
                    void* workspace, size_t workspace_bytes, void* stream);
 

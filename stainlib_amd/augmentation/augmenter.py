@@ -1,0 +1,196 @@
+"""Colour augmenters of stainlib/augmentation/augmenter.py (lines 19-372, 403-449) on the HIP engine.
+
+Public behaviour kept from the reference: class names, ``keyword``/``shapes``, the private attributes
+users peek at (``_sigmas``, ``_biases``, ``_sigma_ranges``, ``_bias_ranges``, ``_cutoff_range``), the
+range validation and its ``InvalidRangeError`` titles, the order in which ``randomize()`` / ``pop()``
+consume the GLOBAL ``np.random`` stream, and the "un-randomized augmenter applies the lower bounds"
+quirk (augmenter.py:194-198, 246-250).  The arithmetic is ``sl_hed_augment`` / ``sl_stain_augment``.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from ..utils.excepts import InvalidRangeError
+from ..utils.stain_utils import (_UINT8_MSG, LuminosityThresholdTissueLocator, _to_device, get_concentrations,
+                                 is_uint8_image)
+
+_CHANNELS = ("Haematoxylin", "Eosin", "Dab")
+
+
+class AugmenterBase(object):
+    """augmenter.py:19-70."""
+
+    def __init__(self, keyword):
+        self._keyword = keyword
+
+    @property
+    def keyword(self):
+        return self._keyword
+
+    def shapes(self, target_shapes):
+        """Output shapes equal input shapes (augmenter.py:41-53)."""
+        return target_shapes
+
+    def transform(self, patch):
+        pass
+
+    def randomize(self):
+        pass
+
+
+class ColorAugmenterBase(AugmenterBase):
+    """augmenter.py:72-84."""
+
+
+def _checked(title, rng, lowest):
+    """One interval of the constructor: None passes; otherwise a pair lo <= hi inside [lowest, 1]."""
+    if rng is not None:
+        bad = len(rng) != 2 or rng[1] < rng[0] or rng[0] < lowest or 1.0 < rng[1]
+        if bad:
+            raise InvalidRangeError(title, rng)
+    return rng
+
+
+class HedColorAugmenter(ColorAugmenterBase):
+    """Colour perturbation in HED space: value * (1 + sigma) + bias per channel (augmenter.py:86-344).
+
+    ``skimage_mode`` selects the rgb2hed/hed2rgb semantics: "0.18" (default, golden-pinned) or "0.19"
+    (stains clamped at zero after separation)."""
+
+    def __init__(self, haematoxylin_sigma_range, haematoxylin_bias_range, eosin_sigma_range, eosin_bias_range,
+                 dab_sigma_range, dab_bias_range, cutoff_range, skimage_mode="0.18"):
+        super().__init__(keyword="hed_color")
+        sig = (haematoxylin_sigma_range, eosin_sigma_range, dab_sigma_range)
+        bia = (haematoxylin_bias_range, eosin_bias_range, dab_bias_range)
+        self._sigma_ranges = [_checked(ch + " Sigma", r, -1.0) for ch, r in zip(_CHANNELS, sig)]
+        self._bias_ranges = [_checked(ch + " Bias", r, -1.0) for ch, r in zip(_CHANNELS, bia)]
+        # until randomize() is called the lower bounds are applied (augmenter.py:194-198, 246-250)
+        self._sigmas = [r[0] if r is not None else 0.0 for r in self._sigma_ranges]
+        self._biases = [r[0] if r is not None else 0.0 for r in self._bias_ranges]
+        cut = _checked("Cutoff", cutoff_range, 0.0)
+        self._cutoff_range = cut if cut is not None else [0.0, 1.0]
+        if skimage_mode not in ("0.18", "0.19"):
+            raise ValueError("skimage_mode must be '0.18' or '0.19'")
+        self._skimage_mode = 0 if skimage_mode == "0.18" else 1
+
+    def randomize(self):
+        """Six draws from the global numpy stream: sigma H, E, D then bias H, E, D (augmenter.py:333-344)."""
+        self._sigmas = [np.random.uniform(low=r[0], high=r[1], size=None) if r is not None else 1.0
+                        for r in self._sigma_ranges]
+        self._biases = [np.random.uniform(low=r[0], high=r[1], size=None) if r is not None else 0.0
+                        for r in self._bias_ranges]
+
+    def transform(self, patch):
+        """augmenter.py:276-331 for uint8 patches.  A patch whose mean is outside the cutoff interval is
+        returned as the same object."""
+        if not is_uint8_image(patch):
+            raise NotImplementedError("stainlib_amd implements the uint8 branch of HedColorAugmenter.transform "
+                                      "(augmenter.py:290-291, 323-325); float patches are not supported")
+        from .. import engine
+        out, applied = engine.hed_augment(_to_device(patch), [self._sigmas], [self._biases],
+                                          cutoff=self._cutoff_range, skimage_mode=self._skimage_mode)
+        if int(applied[0]) == 0:
+            return patch                                              # augmenter.py:331
+        return out[0].cpu().numpy()
+
+    def transform_batch(self, tiles, sigmas=None, biases=None, out=None):
+        """Batched extension: (N,H,W,3) uint8 device tensor; per-tile (N,3) sigmas / biases (defaults: the
+        augmenter's current ones for every tile).  Returns (out, applied)."""
+        from .. import engine
+        n = tiles.shape[0]
+        sigmas = [self._sigmas] * n if sigmas is None else sigmas
+        biases = [self._biases] * n if biases is None else biases
+        return engine.hed_augment(tiles, sigmas, biases, cutoff=self._cutoff_range,
+                                  skimage_mode=self._skimage_mode, out=out)
+
+    def randomize_batch(self, n):
+        """n successive randomize() calls (same global stream order) -> (n,3) sigmas, (n,3) biases."""
+        s, b = [], []
+        for _ in range(n):
+            self.randomize()
+            s.append(list(self._sigmas))
+            b.append(list(self._biases))
+        return np.array(s, dtype=np.float64), np.array(b, dtype=np.float64)
+
+
+class HedColorAugmenter1(HedColorAugmenter):
+    """Symmetric ranges (-t, t) for every sigma and bias, cutoff (0.05, 0.95) (augmenter.py:346-360)."""
+
+    def __init__(self, thresh, skimage_mode="0.18"):
+        r = (-thresh, thresh)
+        super().__init__(r, r, r, r, r, r, (0.05, 0.95), skimage_mode=skimage_mode)
+
+
+class HedLighterColorAugmenter(HedColorAugmenter1):
+    def __init__(self, skimage_mode="0.18"):
+        super().__init__(0.03, skimage_mode=skimage_mode)              # augmenter.py:362-364
+
+
+class HedLightColorAugmenter(HedColorAugmenter1):
+    def __init__(self, skimage_mode="0.18"):
+        super().__init__(0.1, skimage_mode=skimage_mode)               # augmenter.py:366-368
+
+
+class HedStrongColorAugmenter(HedColorAugmenter1):
+    def __init__(self, skimage_mode="0.18"):
+        super().__init__(1.0, skimage_mode=skimage_mode)               # augmenter.py:370-372
+
+
+class StainAugmentor(object):
+    """Stain-space augmentation of a fitted image (augmenter.py:403-449)."""
+
+    def __init__(self, method, sigma1=0.2, sigma2=0.2, augment_background=False):
+        name = method.lower()
+        if name == 'macenko':
+            from ..extraction.macenko_stain_extractor import MacenkoStainExtractor
+            self.extractor = MacenkoStainExtractor
+        elif name == 'vahadane':
+            from ..extraction.vahadane_stain_extractor import VahadaneStainExtractor
+            self.extractor = VahadaneStainExtractor
+        else:
+            raise Exception('Method not recognized.')                  # augmenter.py:411
+        self.sigma1 = sigma1
+        self.sigma2 = sigma2
+        self.augment_background = augment_background
+        self._image = None
+        self._dev = None
+        self._conc = None
+        self._mask = None
+
+    def fit(self, I):
+        """augmenter.py:416-426: stain matrix of I; concentrations and tissue mask stay on the device
+        (recomputed inside the pop kernel) and are only materialised if the attributes are read."""
+        assert is_uint8_image(I), _UINT8_MSG
+        self.image_shape = I.shape
+        self.stain_matrix = self.extractor.get_stain_matrix(I)
+        self.n_stains = 2
+        self._image = I
+        self._dev = _to_device(I)
+        self._conc = None
+        self._mask = None
+
+    @property
+    def source_concentrations(self):
+        if self._conc is None and self._image is not None:
+            self._conc = get_concentrations(self._image, self.stain_matrix)
+        return self._conc
+
+    @property
+    def tissue_mask(self):
+        if self._mask is None and self._image is not None:
+            self._mask = LuminosityThresholdTissueLocator.get_tissue_mask(self._image).ravel()
+        return self._mask
+
+    def pop(self):
+        """One augmented version of the fitted image; draws alpha0, beta0, alpha1, beta1 from the global
+        numpy stream in the reference's order (augmenter.py:435-437)."""
+        ab = []
+        for _ in range(self.n_stains):
+            ab.append(np.random.uniform(1 - self.sigma1, 1 + self.sigma1))
+            ab.append(np.random.uniform(-self.sigma2, self.sigma2))
+        return self.pop_with(ab)
+
+    def pop_with(self, alpha_beta):
+        from .. import engine
+        out = engine.stain_augment(self._dev, self.stain_matrix[None], [alpha_beta], self.augment_background)
+        return out[0].cpu().numpy()

@@ -1,0 +1,186 @@
+// hed.hip -- HedColorAugmenter.transform (stainlib/augmentation/augmenter.py:276-331) for uint8 tiles.
+//
+// Reference chain: mean cutoff test -> skimage.color.rgb2hed -> per-channel x*(1+sigma)+bias ->
+// hed2rgb -> clip [0,1] -> *255 -> truncate.  With scikit-image 0.18 semantics
+// (colorconv.py:1448-1454, 1511-1518) the two 3x3 products and the affine fold into
+//     ln rgb' = ln(max(rgb,1e-6)) @ (H diag(1+sigma) R) + ln(1e-6) * (bias @ R)
+// so a pixel costs 3 LDS lookups, 9 FMA, 3 exp: the sweep is HBM-bound at 3 B read + 3 B written.
+// The cutoff test needs the tile mean BEFORE the transform; instead of a separate 3 B/px sweep the
+// transform runs speculatively while the same sweep sums the bytes, and a fix-up kernel copies the
+// (rare) tiles that fail the test.  >=0.19 semantics (stains clamped at 0) keep the two products apart.
+#include "apply_kernels.hpp"
+#include "sl_host.hpp"
+
+namespace sl {
+
+struct HedConst { double H[9]; double R[9]; };   // hed_from_rgb, rgb_from_hed (row-major)
+
+template <int MODE, bool ALIGNED>
+static __global__ __launch_bounds__(kWG) void k_hed(const uint8_t* __restrict__ rgb, uint8_t* __restrict__ out, int P,
+                                                    int parts, const double* __restrict__ sigma,
+                                                    const double* __restrict__ bias, HedConst hc,
+                                                    unsigned long long* __restrict__ sums) {
+    __shared__ float s_x[256];      // ln(max(v/255, 1e-6)) * log2(e)-free: plain natural log, binary32
+    __shared__ unsigned long long s_sum;
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x / parts, part = blockIdx.x % parts;
+    const double Ladj = log(1e-6);
+    {
+        const double v = tid == 0 ? 1e-6 : fmax((double)tid / 255.0, 1e-6);
+        s_x[tid] = (float)log(v);
+    }
+    if (tid == 0) s_sum = 0;
+    // per-tile constants in binary64, then binary32 scalars
+    float A[3][3], b[3], Hs[3][3], Rs[3][3], sc[3], bi[3];
+    const double* sg = sigma + 3 * (size_t)tile;
+    const double* bs = bias + 3 * (size_t)tile;
+    const double kL2E = 1.4426950408889634;
+    if (MODE == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                double acc = 0;
+                for (int j = 0; j < 3; ++j) acc += hc.H[3 * k + j] * (1.0 + sg[j]) * hc.R[3 * j + c];
+                A[k][c] = uni((float)(acc * kL2E));
+            }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double acc = 0;
+            for (int j = 0; j < 3; ++j) acc += bs[j] * hc.R[3 * j + c];
+            b[c] = uni((float)(Ladj * acc * kL2E));
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                Hs[k][c] = uni((float)(hc.H[3 * k + c] / Ladj));           // stains = ln(rgb)/ln(1e-6) @ H
+                Rs[k][c] = uni((float)(hc.R[3 * k + c] * Ladj * kL2E));    // log2 rgb = ln(1e-6) * stains @ R * log2(e)
+            }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { sc[c] = uni((float)(1.0 + sg[c])); bi[c] = uni((float)bs[c]); }
+    }
+    __syncthreads();
+
+    const size_t nbytes = (size_t)P * 3;
+    const uint8_t* src = rgb + (size_t)tile * nbytes;
+    uint8_t* dst = out + (size_t)tile * nbytes;
+    const int nch = (P + 3) >> 2;
+    const int span = (nch + parts - 1) / parts;
+    const int c0 = part * span, c1 = min(nch, c0 + span);
+    uint32_t bsum = 0;
+    for (int c = c0 + tid; c < c1; c += kWG * kU) {
+        Chunk in[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int cc = c + u * kWG;
+            in[u] = cc < c1 ? load_chunk<ALIGNED>(src, nbytes, cc) : Chunk{0, 0, 0};
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int cc = c + u * kWG;
+            bsum = __builtin_amdgcn_udot4(in[u].w0, 0x01010101u, bsum, false);
+            bsum = __builtin_amdgcn_udot4(in[u].w1, 0x01010101u, bsum, false);
+            bsum = __builtin_amdgcn_udot4(in[u].w2, 0x01010101u, bsum, false);
+            uint32_t ob[12];
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                const float x0 = s_x[chunk_byte(in[u], 3 * px)], x1 = s_x[chunk_byte(in[u], 3 * px + 1)],
+                            x2 = s_x[chunk_byte(in[u], 3 * px + 2)];
+                float l[3];
+                if (MODE == 0) {
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) l[ch] = fmaf(x2, A[2][ch], fmaf(x1, A[1][ch], fmaf(x0, A[0][ch], b[ch])));
+                } else {
+                    float st[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        st[k] = fmaf(x2, Hs[2][k], fmaf(x1, Hs[1][k], x0 * Hs[0][k]));
+                        st[k] = fmaxf(st[k], 0.0f);                        // scikit-image >= 0.19
+                        st[k] = fmaf(st[k], sc[k], bi[k]);                 // augmenter.py:298-316
+                    }
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) l[ch] = fmaf(st[2], Rs[2][ch], fmaf(st[1], Rs[1][ch], st[0] * Rs[0][ch]));
+                }
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    const float v = 255.0f * fminf(__builtin_amdgcn_exp2f(l[ch]), 1.0f);   // clip [0,1], *255 (:320-324)
+                    ob[3 * px + ch] = trunc_u8(v);                                        // astype(uint8) (:325)
+                }
+            }
+            Chunk o;
+            o.w0 = ob[0] | (ob[1] << 8) | (ob[2] << 16) | (ob[3] << 24);
+            o.w1 = ob[4] | (ob[5] << 8) | (ob[6] << 16) | (ob[7] << 24);
+            o.w2 = ob[8] | (ob[9] << 8) | (ob[10] << 16) | (ob[11] << 24);
+            if (cc < c1) store_chunk<ALIGNED>(dst, nbytes, cc, o);
+        }
+    }
+    unsigned long long ws = wave_sum((unsigned long long)bsum);
+    if ((tid & 63) == 0) atomicAdd(&s_sum, ws);
+    __syncthreads();
+    if (tid == 0) atomicAdd(&sums[tile], s_sum);
+}
+
+// Tiles whose mean/255 is outside [lo, hi] are returned unchanged (augmenter.py:293,331).
+template <bool ALIGNED>
+static __global__ __launch_bounds__(kWG) void k_hed_fixup(const uint8_t* __restrict__ rgb, uint8_t* __restrict__ out, int P,
+                                                          int parts, const unsigned long long* __restrict__ sums,
+                                                          double lo, double hi, int32_t* __restrict__ applied) {
+    const int tile = blockIdx.x / parts, part = blockIdx.x % parts;
+    // the reference averages float32 values then divides by 255 (augmenter.py:291); here the byte sum is exact
+    const double mean = (double)sums[tile] / (3.0 * (double)P) / 255.0;
+    const bool ok = (lo <= mean) && (mean <= hi);
+    if (part == 0 && threadIdx.x == 0 && applied) applied[tile] = ok ? 1 : 0;
+    if (ok) return;
+    const size_t nbytes = (size_t)P * 3;
+    const uint8_t* src = rgb + (size_t)tile * nbytes;
+    uint8_t* dst = out + (size_t)tile * nbytes;
+    const int nch = (P + 3) >> 2;
+    const int span = (nch + parts - 1) / parts;
+    const int c0 = part * span, c1 = min(nch, c0 + span);
+    for (int c = c0 + threadIdx.x; c < c1; c += kWG) store_chunk<ALIGNED>(dst, nbytes, c, load_chunk<ALIGNED>(src, nbytes, c));
+}
+
+}  // namespace sl
+
+using namespace sl;
+
+namespace {
+void inv3(const double* m, double* o) {
+    const double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
+    const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+    o[0] = (e * i - f * h) / det; o[1] = (c * h - b * i) / det; o[2] = (b * f - c * e) / det;
+    o[3] = (f * g - d * i) / det; o[4] = (a * i - c * g) / det; o[5] = (c * d - a * f) / det;
+    o[6] = (d * h - e * g) / det; o[7] = (b * g - a * h) / det; o[8] = (a * e - b * d) / det;
+}
+}  // namespace
+
+extern "C" int sl_hed_augment(const uint8_t* rgb, uint8_t* out, int n, int h, int w, const double* sigma,
+                              const double* bias, double cutoff_lo, double cutoff_hi, int skimage_mode,
+                              int32_t* applied, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!rgb || !out || !sigma || !bias || n <= 0 || h <= 0 || w <= 0) return SL_ERR_BADARG;
+    if (skimage_mode != SL_HED_SKIMAGE_018 && skimage_mode != SL_HED_SKIMAGE_019) return SL_ERR_BADARG;
+    const long P = (long)h * w;
+    if (P > (1L << 30)) return SL_ERR_BADARG;
+    if (!workspace || workspace_bytes < sizeof(unsigned long long) * (size_t)n || ((uintptr_t)workspace & 7u))
+        return SL_ERR_WORKSPACE;
+    HedConst hc;
+    // skimage.color.rgb_from_hed (colorconv.py:475-478), hed_from_rgb = inv(.)
+    const double R[9] = {0.65, 0.70, 0.29, 0.07, 0.99, 0.11, 0.27, 0.57, 0.78};
+    for (int i = 0; i < 9; ++i) hc.R[i] = R[i];
+    inv3(R, hc.H);
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long* sums = (unsigned long long*)workspace;
+    SL_HIP_TRY(hipMemsetAsync(sums, 0, sizeof(unsigned long long) * (size_t)n, s));
+    const int parts = parts_for(P);
+    const dim3 grid((unsigned)((long)n * parts)), block(kWG);
+    const bool al = aligned4(rgb, P) && aligned4(out, P);
+#define SL_GO(M, A) hipLaunchKernelGGL((k_hed<M, A>), grid, block, 0, s, rgb, out, (int)P, parts, sigma, bias, hc, sums)
+    if (skimage_mode == SL_HED_SKIMAGE_018) { if (al) SL_GO(0, true); else SL_GO(0, false); }
+    else                                    { if (al) SL_GO(1, true); else SL_GO(1, false); }
+#undef SL_GO
+    if (al) hipLaunchKernelGGL((k_hed_fixup<true>), grid, block, 0, s, rgb, out, (int)P, parts, sums, cutoff_lo, cutoff_hi, applied);
+    else    hipLaunchKernelGGL((k_hed_fixup<false>), grid, block, 0, s, rgb, out, (int)P, parts, sums, cutoff_lo, cutoff_hi, applied);
+    return launch_status();
+}

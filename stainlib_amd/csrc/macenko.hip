@@ -152,6 +152,8 @@ extern "C" size_t sl_workspace_bytes(int op, int n_tiles, int h, int w) {
         case SL_OP_VAHADANE_FIT:
         case SL_OP_VAHADANE_TRANSFORM:
             return make_layout(n_tiles, (long)h * w).total;
+        case SL_OP_HED_AUGMENT:
+            return (sizeof(unsigned long long) * (size_t)n_tiles + 255) & ~(size_t)255;
         default:
             return 0;
     }

@@ -2,4 +2,3 @@
 #include "sl_host.hpp"
 extern "C" int sl_vahadane_fit(const uint8_t*, int, int, int, const SlParams*, double*, double*, int32_t*, int32_t*, void*, size_t, void*) { return SL_ERR_BADARG; }
 extern "C" int sl_vahadane_transform(const uint8_t*, uint8_t*, int, int, int, const SlParams*, const double*, const double*, double*, double*, int32_t*, void*, size_t, void*) { return SL_ERR_BADARG; }
-extern "C" int sl_hed_augment(const uint8_t*, uint8_t*, int, int, int, const float*, const float*, float, float, int, int32_t*, void*, size_t, void*) { return SL_ERR_BADARG; }

@@ -136,8 +136,9 @@ def hed_augment(rgb, sigma, bias, cutoff=(0.05, 0.95), skimage_mode=0, out=None,
     """Batched HedColorAugmenter.transform for uint8 tiles -> (out, applied (N,) i32)."""
     n, h, w = _check_tiles(rgb)
     dev = rgb.device
-    sigma = torch.as_tensor(sigma, dtype=torch.float32, device=dev).reshape(n, 3).contiguous()
-    bias = torch.as_tensor(bias, dtype=torch.float32, device=dev).reshape(n, 3).contiguous()
+    import numpy as np
+    sigma = torch.as_tensor(np.asarray(sigma, dtype=np.float64), device=dev).reshape(n, 3).contiguous()
+    bias = torch.as_tensor(np.asarray(bias, dtype=np.float64), device=dev).reshape(n, 3).contiguous()
     if out is None:
         out = torch.empty_like(rgb)
     applied = torch.empty((n,), dtype=torch.int32, device=dev)

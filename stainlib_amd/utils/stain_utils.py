@@ -1,0 +1,88 @@
+"""Host-side mirror of the pieces of stainlib/utils/stain_utils.py that sit on the hot path.
+
+Everything numeric is a call into the HIP engine (stainlib_amd.engine); this module only adapts
+numpy uint8 HWC images (the reference's contract) to batched device tensors and maps per-tile
+status codes to the reference's exceptions.
+"""
+from __future__ import annotations
+
+from abc import ABC, abstractmethod
+
+import numpy as np
+
+from .excepts import TissueMaskException
+
+_UINT8_MSG = "Image should be RGB uint8."          # stain_utils.py:40, macenko_stain_extractor.py:16
+
+
+def is_image(I) -> bool:
+    """stain_utils.py:126-134 -- any 3-D ndarray (channel count is not checked by the reference)."""
+    return isinstance(I, np.ndarray) and I.ndim == 3
+
+
+def is_uint8_image(I) -> bool:
+    """stain_utils.py:136-144."""
+    return is_image(I) and I.dtype == np.uint8
+
+
+def _to_device(I: np.ndarray):
+    """(H,W,3) uint8 ndarray -> (1,H,W,3) device tensor."""
+    import torch
+    if I.shape[2] != 3:
+        raise ValueError(f"expected 3 channels, got shape {I.shape}")   # the reference fails later, inside cv2
+    return torch.from_numpy(np.ascontiguousarray(I)[None]).cuda()
+
+
+def raise_for_status(status: int) -> None:
+    """Per-tile status of the engine -> what the reference does for a single image."""
+    from .. import _ffi
+    if status == _ffi.TILE_EMPTY_MASK:
+        raise TissueMaskException("Empty tissue mask computed")          # stain_utils.py:47
+    if status == _ffi.TILE_DEGENERATE_COV:
+        # the reference computes np.cov of a single row (NaN) and fails inside eigh
+        raise np.linalg.LinAlgError("fewer than two tissue pixels: covariance undefined")
+
+
+class ABCStainExtractor(ABC):
+    """stain_utils.py:8-17."""
+
+    @staticmethod
+    @abstractmethod
+    def get_stain_matrix(I):
+        """Estimate the 2x3 stain matrix of an image."""
+
+
+class ABCTissueLocator(ABC):
+    """stain_utils.py:19-27."""
+
+    @staticmethod
+    @abstractmethod
+    def get_tissue_mask(I):
+        """Boolean tissue mask of an image."""
+
+
+class LuminosityThresholdTissueLocator(ABCTissueLocator):
+    """stain_utils.py:29-48; the OpenCV 8-bit Lab L test runs as an integer LUT kernel."""
+
+    @staticmethod
+    def get_tissue_mask(I, luminosity_threshold=0.8):
+        assert is_uint8_image(I), _UINT8_MSG
+        from .. import engine
+        mask, counts = engine.tissue_mask(_to_device(I), luminosity_threshold)
+        if int(counts[0]) == 0:
+            raise TissueMaskException("Empty tissue mask computed")
+        return mask[0].cpu().numpy().astype(bool)
+
+
+def get_concentrations(I, stain_matrix, regularizer=0.01):
+    """stain_utils.py:69-78 -> (P, 2) float64 (binary32 values from the device)."""
+    assert is_uint8_image(I), _UINT8_MSG
+    from .. import engine
+    C = engine.concentrations(_to_device(I), np.asarray(stain_matrix, dtype=np.float64)[None], regularizer)
+    return C[0].cpu().numpy().astype(np.float64)
+
+
+def normalize_matrix_rows(A):
+    """stain_utils.py:93-99 (six numbers: host arithmetic)."""
+    A = np.asarray(A, dtype=np.float64)
+    return A / np.linalg.norm(A, axis=1)[:, None]
