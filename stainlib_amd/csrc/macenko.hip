@@ -25,7 +25,7 @@ struct Layout {
 
 size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
-Layout make_layout(int n, long P) {
+Layout make_layout(int n, long P, bool force_fused = false) {
     Layout L;
     L.parts = parts_for(P);
     L.stride_log2 = 6;
@@ -37,7 +37,7 @@ Layout make_layout(int n, long P) {
     if (g > n) g = n;
     if (g < 1) g = 1;
     L.G = (int)g;
-    L.fused = n >= kFusedMinTiles;
+    L.fused = force_fused || n >= kFusedMinTiles;
     L.grid = n < kFusedMaxGrid ? n : kFusedMaxGrid;
     const size_t slots = L.fused ? (size_t)L.grid : (size_t)L.G;     // candidate buffers: per workgroup / per tile of a group
     size_t o = 0;
@@ -99,9 +99,9 @@ int run_stats_group(const uint8_t* rgb, int g0, int m, long P, const SlParams& p
 long long* g_phase_clock = nullptr;   // development aid, see sl_debug_set_phase_clock
 
 // The persistent schedule: one launch for the whole batch (fit only when out == nullptr).
-int run_fused(const uint8_t* rgb, uint8_t* out, int n, long P, const SlParams& p, const Layout& L, char* ws,
+int run_fused(int method, const uint8_t* rgb, uint8_t* out, int n, long P, const SlParams& p, const Layout& L, char* ws,
               const double* M_tgt, const double* maxC_tgt, double* M_all, double* maxC_all, int32_t* status_all,
-              hipStream_t s) {
+              int32_t* sweeps_out, hipStream_t s) {
     FusedArgs a;
     a.rgb = rgb;
     a.out = out;
@@ -121,16 +121,22 @@ int run_fused(const uint8_t* rgb, uint8_t* out, int n, long P, const SlParams& p
     a.status_out = status_all;
     a.diag_out = (int32_t*)(ws + L.off_diag);
     a.phase_clock = g_phase_clock;
+    a.dl_lambda = p.dl_lambda;
+    a.dl_tol = p.dl_tol;
+    a.dl_max_sweeps = p.dl_max_sweeps > 0 ? p.dl_max_sweeps : 1;
+    a.sweeps_out = sweeps_out;
     const bool al = aligned4(rgb, P) && (!out || aligned4(out, P));
     const dim3 g((unsigned)L.grid), b(kFusedThreads);
     ProfScope ps(p.profile, out ? SL_PROF_FUSED_TRANSFORM : SL_PROF_FUSED_FIT, n, s);
-    if (out) {
-        if (al) hipLaunchKernelGGL((k_macenko_fused<true, true>), g, b, 0, s, a);
-        else    hipLaunchKernelGGL((k_macenko_fused<true, false>), g, b, 0, s, a);
+#define SL_GO(M, T, A) hipLaunchKernelGGL((k_fused<M, T, A>), g, b, 0, s, a)
+    if (method == kMethodMacenko) {
+        if (out) { if (al) SL_GO(kMethodMacenko, true, true); else SL_GO(kMethodMacenko, true, false); }
+        else     { if (al) SL_GO(kMethodMacenko, false, true); else SL_GO(kMethodMacenko, false, false); }
     } else {
-        if (al) hipLaunchKernelGGL((k_macenko_fused<false, true>), g, b, 0, s, a);
-        else    hipLaunchKernelGGL((k_macenko_fused<false, false>), g, b, 0, s, a);
+        if (out) { if (al) SL_GO(kMethodVahadane, true, true); else SL_GO(kMethodVahadane, true, false); }
+        else     { if (al) SL_GO(kMethodVahadane, false, true); else SL_GO(kMethodVahadane, false, false); }
     }
+#undef SL_GO
     return launch_status();
 }
 
@@ -149,9 +155,10 @@ extern "C" size_t sl_workspace_bytes(int op, int n_tiles, int h, int w) {
     switch (op) {
         case SL_OP_MACENKO_FIT:
         case SL_OP_MACENKO_TRANSFORM:
+            return make_layout(n_tiles, (long)h * w).total;
         case SL_OP_VAHADANE_FIT:
         case SL_OP_VAHADANE_TRANSFORM:
-            return make_layout(n_tiles, (long)h * w).total;
+            return make_layout(n_tiles, (long)h * w, true).total;
         case SL_OP_HED_AUGMENT:
             return (sizeof(unsigned long long) * (size_t)n_tiles + 255) & ~(size_t)255;
         default:
@@ -174,7 +181,8 @@ extern "C" int sl_macenko_fit(const uint8_t* rgb, int n, int h, int w, const SlP
     double* maxC_all = maxC_out ? maxC_out : (double*)(ws + L.off_maxC);
     int32_t* st_all = status ? status : (int32_t*)(ws + L.off_status);
     if (L.fused)
-        return run_fused(rgb, nullptr, n, P, p, L, ws, nullptr, nullptr, M_all, maxC_all, st_all, (hipStream_t)stream);
+        return run_fused(kMethodMacenko, rgb, nullptr, n, P, p, L, ws, nullptr, nullptr, M_all, maxC_all, st_all, nullptr,
+                         (hipStream_t)stream);
     for (int g0 = 0; g0 < n; g0 += L.G) {
         const int m = (n - g0) < L.G ? (n - g0) : L.G;
         rc = run_stats_group(rgb, g0, m, P, p, L, ws, M_all, maxC_all, st_all, (hipStream_t)stream);
@@ -200,7 +208,8 @@ extern "C" int sl_macenko_transform(const uint8_t* rgb, uint8_t* out, int n, int
     double* maxC_all = maxC_src_out ? maxC_src_out : (double*)(ws + L.off_maxC);
     int32_t* st_all = status ? status : (int32_t*)(ws + L.off_status);
     if (L.fused)
-        return run_fused(rgb, out, n, P, p, L, ws, M_tgt, maxC_tgt, M_all, maxC_all, st_all, (hipStream_t)stream);
+        return run_fused(kMethodMacenko, rgb, out, n, P, p, L, ws, M_tgt, maxC_tgt, M_all, maxC_all, st_all, nullptr,
+                         (hipStream_t)stream);
     for (int g0 = 0; g0 < n; g0 += L.G) {
         const int m = (n - g0) < L.G ? (n - g0) : L.G;
         rc = run_stats_group(rgb, g0, m, P, p, L, ws, M_all, maxC_all, st_all, (hipStream_t)stream);
@@ -214,6 +223,42 @@ extern "C" int sl_macenko_transform(const uint8_t* rgb, uint8_t* out, int n, int
         if (rc) return rc;
     }
     return SL_OK;
+}
+
+// Vahadane always runs the persistent schedule (its dictionary sweeps live inside the kernel).
+extern "C" int sl_vahadane_fit(const uint8_t* rgb, int n, int h, int w, const SlParams* params, double* M_out,
+                               double* maxC_out, int32_t* status, int32_t* sweeps_out, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    const long P = (long)h * w;
+    const Layout L = (n > 0 && h > 0 && w > 0) ? make_layout(n, P, true) : Layout{};
+    int rc = check_common(rgb, n, h, w, workspace, workspace_bytes, L.total);
+    if (rc) return rc;
+    SlParams p;
+    sl_default_params(&p);
+    if (params) p = *params;
+    char* ws = (char*)workspace;
+    return run_fused(kMethodVahadane, rgb, nullptr, n, P, p, L, ws, nullptr, nullptr,
+                     M_out ? M_out : (double*)(ws + L.off_M), maxC_out ? maxC_out : (double*)(ws + L.off_maxC),
+                     status ? status : (int32_t*)(ws + L.off_status), sweeps_out, (hipStream_t)stream);
+}
+
+extern "C" int sl_vahadane_transform(const uint8_t* rgb, uint8_t* out, int n, int h, int w, const SlParams* params,
+                                     const double* M_tgt, const double* maxC_tgt, double* M_src_out,
+                                     double* maxC_src_out, int32_t* status, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+    const long P = (long)h * w;
+    const Layout L = (n > 0 && h > 0 && w > 0) ? make_layout(n, P, true) : Layout{};
+    int rc = check_common(rgb, n, h, w, workspace, workspace_bytes, L.total);
+    if (rc) return rc;
+    if (!out || !M_tgt || !maxC_tgt) return SL_ERR_BADARG;
+    SlParams p;
+    sl_default_params(&p);
+    if (params) p = *params;
+    char* ws = (char*)workspace;
+    return run_fused(kMethodVahadane, rgb, out, n, P, p, L, ws, M_tgt, maxC_tgt,
+                     M_src_out ? M_src_out : (double*)(ws + L.off_M),
+                     maxC_src_out ? maxC_src_out : (double*)(ws + L.off_maxC),
+                     status ? status : (int32_t*)(ws + L.off_status), nullptr, (hipStream_t)stream);
 }
 
 // Development aid (not part of the public header): where the per-tile state lives in the workspace.

@@ -32,6 +32,8 @@
 //     workgroups.  Used for small batches, where a tile per workgroup would leave most CUs idle.
 #pragma once
 #include "../../include/stainlib_hip.h"
+#include <type_traits>
+
 #include "apply_kernels.hpp"
 
 namespace sl {
@@ -706,6 +708,174 @@ __device__ __forceinline__ void stage_order_stats(const float* cand, float lo, f
 }
 
 // ------------------------------------------------------------------------------------------
+// Vahadane: sparse-NMF dictionary (vahadane_stain_extractor.py:35-36, spams.trainDL K=2, lambda1,
+// posAlpha, posD, unit-ball atoms) by CLASS MOMENTS.
+//
+// For a fixed dictionary D the exact non-negative code of a pixel is affine in its OD vector x once
+// its active set is known: alpha = P_c (D x - lambda 1), c in {both atoms, atom 1 only, atom 2 only,
+// none}.  Hence A = sum alpha alpha^T and B = sum x alpha^T -- all the online-dictionary-learning
+// update needs (Mairal et al. 2010, Alg. 2) -- are closed-form functions of D and of the per-class
+// moments {n_c, sum x, sum x x^T}.  One sweep over the tile classifies the pixels under the current D
+// and accumulates 3 x 10 moment sums; one lane then iterates the block-coordinate dictionary update
+// on those 30 numbers until it stalls (no pixel is touched); the next sweep re-classifies.  The
+// fixed point is the one plain full-batch block-coordinate descent reaches (oracle:
+// vahadane_dictionary), but in ~9 sweeps instead of ~90.
+// ------------------------------------------------------------------------------------------
+struct ClsAcc {
+    double sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+    uint32_t n = 0;
+    __device__ __forceinline__ void add(double x, double y, double z) {
+        n += 1;
+        sx += x; sy += y; sz += z;
+        sxx = fma(x, x, sxx); sxy = fma(x, y, sxy); sxz = fma(x, z, sxz);
+        syy = fma(y, y, syy); syz = fma(y, z, syz); szz = fma(z, z, szz);
+    }
+    __device__ __forceinline__ void to_array(double* v) const {
+        v[0] = (double)n; v[1] = sx; v[2] = sy; v[3] = sz; v[4] = sxx; v[5] = sxy; v[6] = sxz;
+        v[7] = syy; v[8] = syz; v[9] = szz;
+    }
+};
+
+// classify every tissue pixel of chunks [c0,c1) under the dictionary L (binary32 lasso constants) and
+// accumulate the moments of classes both / only-1 / only-2; n_tissue counts all tissue pixels.
+template <bool ALIGNED, bool SAMPLE, class TABS, class SampleStore>
+__device__ __forceinline__ void dict_sweep(const uint8_t* src, int P, int c0, int c1, int t, int nthreads, const TABS& T,
+                                           uint32_t y_lim, int stride_log2, const LassoK& L, SampleStore store_sample,
+                                           ClsAcc (&acc)[3], uint32_t& n_tissue) {
+    const size_t nbytes = (size_t)P * 3;
+    const int cps_log2 = stride_log2 - 2;
+    for (int c = c0 + t; c < c1; c += nthreads * 2) {
+        Chunk in[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int cc = c + u * nthreads;
+            in[u] = cc < c1 ? load_chunk<ALIGNED>(src, nbytes, cc) : Chunk{0xffffffffu, 0xffffffffu, 0xffffffffu};
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int cc = c + u * nthreads;
+            const bool live = cc < c1;
+            const uint32_t b = (uint32_t)cc >> cps_log2;
+            const uint32_t off = SAMPLE ? sample_offset(b, stride_log2) : 0u;
+            const bool has_sample = SAMPLE & live & ((off >> 2) == ((uint32_t)cc & ((1u << cps_log2) - 1)));
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                const uint32_t r = chunk_byte(in[u], 3 * px), g = chunk_byte(in[u], 3 * px + 1),
+                               bb = chunk_byte(in[u], 3 * px + 2);
+                const uint32_t gr = T.gam(r, t), gg = T.gam(g, t), gb = T.gam(bb, t);
+                const float fx = T.odf(r, t), fy = T.odf(g, t), fz = T.odf(bb, t);
+                const double ox = T.od64(r, t), oy = T.od64(g, t), oz = T.od64(bb, t);
+                const bool inb = live & (ALIGNED | ((size_t)cc * 4 + px < (size_t)P));
+                const bool tissue = inb & is_tissue(gr, gg, gb, y_lim);
+                // active set of the exact code (same enumeration as lasso2)
+                const float b1 = fmaf(L.m[0][2], fz, fmaf(L.m[0][1], fy, fmaf(L.m[0][0], fx, -L.lam)));
+                const float b2 = fmaf(L.m[1][2], fz, fmaf(L.m[1][1], fy, fmaf(L.m[1][0], fx, -L.lam)));
+                const float a1 = fmaf(L.i12, b2, L.i11 * b1);
+                const float a2 = fmaf(L.i12, b1, L.i22 * b2);
+                const bool both = (a1 >= 0.0f) & (a2 >= 0.0f);
+                const bool only1 = !both & (b1 > 0.0f) & (fmaf(-L.g12, b1 * L.r1, b2) <= 0.0f);
+                const bool only2 = !both & !only1 & (b2 * L.r2 > 0.0f);
+                n_tissue += tissue ? 1u : 0u;
+                if (tissue & both) acc[0].add(ox, oy, oz);
+                if (tissue & only1) acc[1].add(ox, oy, oz);
+                if (tissue & only2) acc[2].add(ox, oy, oz);
+                if (SAMPLE) {
+                    if (has_sample & ((off & 3) == (uint32_t)px) & inb)
+                        store_sample(b, r | (g << 8) | (bb << 16) | ((tissue ? 1u : 0u) << 24));
+                }
+            }
+        }
+    }
+}
+
+// A (a11, a12, a22) and B (3x2) of the dictionary update from the class moments m[c] = {n, s(3), q(6)}
+__device__ __forceinline__ void ab_from_class_moments(const double* mom /*[3][10]*/, const double (&D)[2][3], double lam,
+                                                      double (&A)[2][2], double (&B)[3][2]) {
+    const double g11 = D[0][0] * D[0][0] + D[0][1] * D[0][1] + D[0][2] * D[0][2];
+    const double g22 = D[1][0] * D[1][0] + D[1][1] * D[1][1] + D[1][2] * D[1][2];
+    const double g12 = D[0][0] * D[1][0] + D[0][1] * D[1][1] + D[0][2] * D[1][2];
+    const double det = g11 * g22 - g12 * g12;
+    A[0][0] = A[0][1] = A[1][0] = A[1][1] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) B[k][0] = B[k][1] = 0.0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double Pm[2][2];
+        if (c == 0) { Pm[0][0] = g22 / det; Pm[0][1] = -g12 / det; Pm[1][0] = -g12 / det; Pm[1][1] = g11 / det; }
+        else if (c == 1) { Pm[0][0] = 1.0 / g11; Pm[0][1] = 0; Pm[1][0] = 0; Pm[1][1] = 0; }
+        else { Pm[0][0] = 0; Pm[0][1] = 0; Pm[1][0] = 0; Pm[1][1] = 1.0 / g22; }
+        const double* m = mom + 10 * c;
+        const double n = m[0];
+        if (!(n > 0)) continue;
+        const double s1[3] = {m[1], m[2], m[3]};
+        const double S2[3][3] = {{m[4], m[5], m[6]}, {m[5], m[7], m[8]}, {m[6], m[8], m[9]}};
+        double W[2][3], w[2], Ws1[2], WS2[2][3];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            w[r] = lam * (Pm[r][0] + Pm[r][1]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) W[r][k] = Pm[r][0] * D[0][k] + Pm[r][1] * D[1][k];
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            Ws1[r] = W[r][0] * s1[0] + W[r][1] * s1[1] + W[r][2] * s1[2];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) WS2[r][k] = W[r][0] * S2[0][k] + W[r][1] * S2[1][k] + W[r][2] * S2[2][k];
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                A[r][q] += WS2[r][0] * W[q][0] + WS2[r][1] * W[q][1] + WS2[r][2] * W[q][2] - Ws1[r] * w[q] - w[r] * Ws1[q] +
+                           n * w[r] * w[q];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) B[k][r] += WS2[r][k] - s1[k] * w[r];
+    }
+}
+
+// Iterate the block-coordinate dictionary update on frozen class moments until it stalls.
+// Returns the largest change of D over the whole call.
+__device__ __forceinline__ double dict_inner_solve(const double* mom, double (&D)[2][3], double lam) {
+    double D0[2][3];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) D0[j][k] = D[j][k];
+    for (int it = 0; it < 500; ++it) {
+        double A[2][2], B[3][2];
+        ab_from_class_moments(mom, D, lam, A, B);
+        double step = 0.0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (A[j][j] > 1e-300) {
+                double u[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    u[k] = (B[k][j] - (D[0][k] * A[0][j] + D[1][k] * A[1][j])) / A[j][j] + D[j][k];
+                    u[k] = fmax(u[k], 0.0);                               // posD
+                }
+                const double nrm = fmax(sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]), 1.0);   // unit ball (modeD=0)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const double v = u[k] / nrm;
+                    step = fmax(step, fabs(v - D[j][k]));
+                    D[j][k] = v;
+                }
+            }
+        }
+        if (step < 1e-13) break;
+    }
+    double delta = 0.0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) delta = fmax(delta, fabs(D[j][k] - D0[j][k]));
+    return delta;
+}
+
+// ------------------------------------------------------------------------------------------
 // multi-kernel schedule
 // ------------------------------------------------------------------------------------------
 template <bool ALIGNED>
@@ -986,14 +1156,21 @@ struct FusedArgs {
     int32_t* status_out;     // [n_tiles]
     int32_t* diag_out;       // [n_tiles] fallbacks (may be NULL)
     long long* phase_clock;  // [n_tiles][8] wall_clock64() at phase boundaries (development aid, may be NULL)
+    // Vahadane
+    double dl_lambda;
+    double dl_tol;
+    int dl_max_sweeps;
+    int32_t* sweeps_out;     // [n_tiles] (may be NULL)
 };
 
 struct FusedShared {
     Tabs<32, 16, 4> tab;     // 32 + 16 + 8 KB
     float stage[2][kFusedThreads / 64][kStageFused];   // 8 KB
     SelScratch S;
-    double red[kFusedThreads / 64][10];
-    double sum[10];
+    double red[kFusedThreads / 64][32];
+    double sum[32];
+    double D[6];
+    double delta;
     double Vd[6];
     double M[6];
     double maxC[2];
@@ -1005,10 +1182,12 @@ struct FusedShared {
     int status;
 };
 
-template <bool TRANSFORM, bool ALIGNED>
-static __global__ __launch_bounds__(kFusedThreads, 4) void k_macenko_fused(FusedArgs a) {
+enum { kMethodMacenko = 0, kMethodVahadane = 1 };
+
+template <int METHOD, bool TRANSFORM, bool ALIGNED>
+static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) {
     __shared__ FusedShared sh;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     sh.tab.fill();
     __syncthreads();
     const int nch = (a.P + 3) >> 2;
@@ -1016,81 +1195,88 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_macenko_fused(Fused
     float* cand0 = a.cand + ((size_t)blockIdx.x * 2 + 0) * kCapList;
     float* cand1 = a.cand + ((size_t)blockIdx.x * 2 + 1) * kCapList;
 
+    // sweeps 2/3 share this: select around sh.lo/hi with constants K, counts and candidates into sh.*
+    auto run_select = [&](auto stage_tag, const uint8_t* src, SelConsts& K) {
+        constexpr int STAGE = decltype(stage_tag)::value;
+        K.lo0 = uni(sh.lo[0]); K.hi0 = uni(sh.hi[0]); K.lo1 = uni(sh.lo[1]); K.hi1 = uni(sh.hi[1]);
+        StagedSink<kStageFused> sink;
+        sink.buf[0] = sh.stage[0][wave]; sink.buf[1] = sh.stage[1][wave];
+        sink.n[0] = sink.n[1] = 0;
+        sink.dst[0] = cand0; sink.dst[1] = cand1;
+        sink.counter[0] = &sh.ncand[0]; sink.counter[1] = &sh.ncand[1];
+        uint32_t cnt[4] = {0, 0, 0, 0};
+        select_sweep<STAGE, ALIGNED>(src, a.P, 0, nch, tid, kFusedThreads, sh.tab, a.y_lim, K, sink, cnt);
+        sink.flush(0, lane);
+        sink.flush(1, lane);
+        for (int i = 0; i < 4; ++i)
+            for (int o = 32; o > 0; o >>= 1) cnt[i] += __shfl_xor((int)cnt[i], o, 64);
+        if (lane == 0) {
+            if (cnt[0]) atomicAdd(&sh.lt[0], cnt[0]);
+            if (cnt[1]) atomicAdd(&sh.le[0], cnt[1]);
+            if (cnt[2]) atomicAdd(&sh.lt[1], cnt[2]);
+            if (cnt[3]) atomicAdd(&sh.le[1], cnt[3]);
+        }
+        __threadfence_block();
+        __syncthreads();
+    };
+
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         const size_t nbytes = (size_t)a.P * 3;
         const uint8_t* src = a.rgb + (size_t)tile * nbytes;
         int fallbacks = 0;
+        int sweeps_used = 0;
 #define SL_PHASE(i) do { if (a.phase_clock && tid == 0) a.phase_clock[(size_t)tile * 8 + (i)] = wall_clock64(); } while (0)
         SL_PHASE(0);
-        // ---------------- sweep 1: moments + sample (into LDS)
-        {
-            Moments mo;
-            auto store = [&](uint32_t b, uint32_t v) { samp[b] = v; };
-            moments_sweep<ALIGNED>(src, a.P, 0, nch, tid, kFusedThreads, sh.tab, a.y_lim, a.stride_log2, store, mo);
-            double v[10];
-            mo.to_array(v);
+        auto store = [&](uint32_t b, uint32_t v) { samp[b] = v; };
+
+        if (METHOD == kMethodMacenko) {
+            // ---------------- sweep 1: moments + sample
+            {
+                Moments mo;
+                moments_sweep<ALIGNED>(src, a.P, 0, nch, tid, kFusedThreads, sh.tab, a.y_lim, a.stride_log2, store, mo);
+                double v[10];
+                mo.to_array(v);
 #pragma unroll
-            for (int i = 0; i < 10; ++i) v[i] = wave_sum(v[i]);
-            if (lane == 0)
-                for (int i = 0; i < 10; ++i) sh.red[tid >> 6][i] = v[i];
-        }
-        __syncthreads();
-        if (tid < 10) {
-            double t = 0;
-            for (int w = 0; w < kFusedThreads / 64; ++w) t += sh.red[w][tid];
-            sh.sum[tid] = t;
-        }
-        __syncthreads();
-        SL_PHASE(1);
-        // ---------------- finish 1: eigenvectors, angle brackets
-        if (tid == 0) {
-            double Vd[6];
-            float Vf[6];
-            sh.status = eigvecs_from_moments(sh.sum, Vd, Vf);
-            for (int i = 0; i < 6; ++i) { sh.Vd[i] = Vd[i]; sh.Vf[i] = Vf[i]; }
-            for (int i = 0; i < 2; ++i) { sh.lt[i] = 0; sh.le[i] = 0; sh.ncand[i] = 0; }
-        }
-        __syncthreads();
-        const bool bad = sh.status == SL_TILE_EMPTY_MASK || sh.status == SL_TILE_DEGENERATE_COV;   // block-uniform
-        if (!bad) {
-            {
-                SampleAngleKey key;
-                key.sample = samp; key.tab = sh.tab.view(); key.stride_log2 = a.stride_log2; key.P = a.P;
-                for (int i = 0; i < 6; ++i) key.V[i] = sh.Vf[i];
-                float lo[2], hi[2];
-                angle_brackets(key, a.n_sample, a.pct, lo, hi, sh.S);
-                if (tid == 0) { sh.lo[0] = lo[0]; sh.hi[0] = hi[0]; sh.lo[1] = lo[1]; sh.hi[1] = hi[1]; }
-                __syncthreads();
+                for (int i = 0; i < 10; ++i) v[i] = wave_sum(v[i]);
+                if (lane == 0)
+                    for (int i = 0; i < 10; ++i) sh.red[wave][i] = v[i];
             }
-            SL_PHASE(2);
-            // ---------------- sweep 2: angle select
-            {
-                SelConsts K;
-                for (int i = 0; i < 6; ++i) K.V[i] = uni(sh.Vf[i]);
-                K.lo0 = uni(sh.lo[0]); K.hi0 = uni(sh.hi[0]); K.lo1 = uni(sh.lo[1]); K.hi1 = uni(sh.hi[1]);
-                StagedSink<kStageFused> sink;
-                sink.buf[0] = sh.stage[0][tid >> 6]; sink.buf[1] = sh.stage[1][tid >> 6];
-                sink.n[0] = sink.n[1] = 0;
-                sink.dst[0] = cand0; sink.dst[1] = cand1;
-                sink.counter[0] = &sh.ncand[0]; sink.counter[1] = &sh.ncand[1];
-                uint32_t cnt[4] = {0, 0, 0, 0};
-                select_sweep<kStageAngle, ALIGNED>(src, a.P, 0, nch, tid, kFusedThreads, sh.tab, a.y_lim, K, sink, cnt);
-                sink.flush(0, lane);
-                sink.flush(1, lane);
-                for (int i = 0; i < 4; ++i)
-                    for (int o = 32; o > 0; o >>= 1) cnt[i] += __shfl_xor((int)cnt[i], o, 64);
-                if (lane == 0) {
-                    if (cnt[0]) atomicAdd(&sh.lt[0], cnt[0]);
-                    if (cnt[1]) atomicAdd(&sh.le[0], cnt[1]);
-                    if (cnt[2]) atomicAdd(&sh.lt[1], cnt[2]);
-                    if (cnt[3]) atomicAdd(&sh.le[1], cnt[3]);
-                }
-            }
-            __threadfence_block();
             __syncthreads();
-            SL_PHASE(3);
-            // ---------------- finish 2: exact angular percentiles -> M ; concentration brackets
-            {
+            if (tid < 10) {
+                double t = 0;
+                for (int w = 0; w < kFusedThreads / 64; ++w) t += sh.red[w][tid];
+                sh.sum[tid] = t;
+            }
+            __syncthreads();
+            SL_PHASE(1);
+            // ---------------- finish 1: eigenvectors, angle brackets
+            if (tid == 0) {
+                double Vd[6];
+                float Vf[6];
+                sh.status = eigvecs_from_moments(sh.sum, Vd, Vf);
+                for (int i = 0; i < 6; ++i) { sh.Vd[i] = Vd[i]; sh.Vf[i] = Vf[i]; }
+                for (int i = 0; i < 2; ++i) { sh.lt[i] = 0; sh.le[i] = 0; sh.ncand[i] = 0; }
+            }
+            __syncthreads();
+            if (sh.status == SL_TILE_OK) {                                    // block-uniform
+                {
+                    SampleAngleKey key;
+                    key.sample = samp; key.tab = sh.tab.view(); key.stride_log2 = a.stride_log2; key.P = a.P;
+                    for (int i = 0; i < 6; ++i) key.V[i] = sh.Vf[i];
+                    float lo[2], hi[2];
+                    angle_brackets(key, a.n_sample, a.pct, lo, hi, sh.S);
+                    if (tid == 0) { sh.lo[0] = lo[0]; sh.hi[0] = hi[0]; sh.lo[1] = lo[1]; sh.hi[1] = hi[1]; }
+                    __syncthreads();
+                }
+                SL_PHASE(2);
+                // ---------------- sweep 2: angle select
+                {
+                    SelConsts K;
+                    for (int i = 0; i < 6; ++i) K.V[i] = uni(sh.Vf[i]);
+                    run_select(std::integral_constant<int, kStageAngle>{}, src, K);
+                }
+                SL_PHASE(3);
+                // ---------------- finish 2: exact angular percentiles -> M
                 const uint32_t T = (uint32_t)sh.sum[0];
                 long long k[2];
                 double gfrac[2];
@@ -1110,12 +1296,82 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_macenko_fused(Fused
                     double M[6];
                     stain_matrix_from_angles(sh.Vd, sh.res, gfrac, M);
                     for (int i = 0; i < 6; ++i) sh.M[i] = M[i];
-                    LassoK L;
-                    lasso_consts(M, a.lam, L);
-                    sh.L = L;
-                    for (int i = 0; i < 2; ++i) { sh.lt[i] = 0; sh.le[i] = 0; sh.ncand[i] = 0; }
+                }
+            }
+        } else {
+            // ---------------- Vahadane: class-moment dictionary learning
+            if (tid == 0) {
+                // deterministic start: Ruifrok's H and E optical-density vectors, unit norm
+                const double h[3] = {0.65, 0.70, 0.29}, e[3] = {0.07, 0.99, 0.11};
+                const double nh = sqrt(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]), ne = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+                for (int k = 0; k < 3; ++k) { sh.D[k] = h[k] / nh; sh.D[3 + k] = e[k] / ne; }
+                sh.status = SL_TILE_OK;
+                sh.delta = 1.0;
+            }
+            __syncthreads();
+            for (int outer = 0; outer < a.dl_max_sweeps; ++outer) {
+                LassoK Ld;
+                lasso_consts(sh.D, a.dl_lambda, Ld);
+                uni(Ld);
+                ClsAcc acc[3];
+                uint32_t n_tissue = 0;
+                if (outer == 0)
+                    dict_sweep<ALIGNED, true>(src, a.P, 0, nch, tid, kFusedThreads, sh.tab, a.y_lim, a.stride_log2, Ld, store, acc, n_tissue);
+                else
+                    dict_sweep<ALIGNED, false>(src, a.P, 0, nch, tid, kFusedThreads, sh.tab, a.y_lim, a.stride_log2, Ld, store, acc, n_tissue);
+                double v[31];
+                acc[0].to_array(v); acc[1].to_array(v + 10); acc[2].to_array(v + 20);
+                v[30] = (double)n_tissue;
+#pragma unroll
+                for (int i = 0; i < 31; ++i) v[i] = wave_sum(v[i]);
+                __syncthreads();                                             // previous iteration's readers of sh.red are done
+                if (lane == 0)
+                    for (int i = 0; i < 31; ++i) sh.red[wave][i] = v[i];
+                __syncthreads();
+                if (tid < 31) {
+                    double t = 0;
+                    for (int w = 0; w < kFusedThreads / 64; ++w) t += sh.red[w][tid];
+                    sh.sum[tid] = t;
                 }
                 __syncthreads();
+                if (tid == 0) {
+                    if (sh.sum[30] < 1.0) {
+                        sh.status = SL_TILE_EMPTY_MASK;
+                        sh.delta = 0.0;
+                    } else {
+                        double D[2][3];
+                        for (int j = 0; j < 2; ++j)
+                            for (int k = 0; k < 3; ++k) D[j][k] = sh.D[3 * j + k];
+                        sh.delta = dict_inner_solve(sh.sum, D, a.dl_lambda);
+                        for (int j = 0; j < 2; ++j)
+                            for (int k = 0; k < 3; ++k) sh.D[3 * j + k] = D[j][k];
+                    }
+                }
+                __syncthreads();
+                sweeps_used = outer + 1;
+                if (sh.delta < a.dl_tol) break;                               // block-uniform
+            }
+            if (tid == 0 && sh.status == SL_TILE_OK) {
+                // H first: swap when D[0,0] < D[1,0] (vahadane_stain_extractor.py:40-41), unit-norm rows (:43)
+                const bool swap = sh.D[0] < sh.D[3];
+                double h[3], e[3];
+                for (int k = 0; k < 3; ++k) { h[k] = swap ? sh.D[3 + k] : sh.D[k]; e[k] = swap ? sh.D[k] : sh.D[3 + k]; }
+                const double nh = sqrt(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]), ne = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+                for (int k = 0; k < 3; ++k) { sh.M[k] = h[k] / nh; sh.M[3 + k] = e[k] / ne; }
+            }
+        }
+        __syncthreads();
+        const bool bad = sh.status != SL_TILE_OK;                               // block-uniform
+        if (!bad) {
+            if (tid == 0) {
+                LassoK L;
+                lasso_consts(sh.M, a.lam, L);
+                sh.L = L;
+                for (int i = 0; i < 2; ++i) { sh.lt[i] = 0; sh.le[i] = 0; sh.ncand[i] = 0; }
+            }
+            __syncthreads();
+            // ---------------- concentration brackets from the sample
+            {
                 SampleConcKey ckey;
                 ckey.sample = samp; ckey.tab = sh.tab.view(); ckey.L = sh.L; ckey.stride_log2 = a.stride_log2;
                 ckey.P = a.P; ckey.col = 0;
@@ -1130,27 +1386,8 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_macenko_fused(Fused
                 SelConsts K;
                 K.L = sh.L;
                 uni(K.L);
-                K.lo0 = uni(sh.lo[0]); K.hi0 = uni(sh.hi[0]); K.lo1 = uni(sh.lo[1]); K.hi1 = uni(sh.hi[1]);
-                StagedSink<kStageFused> sink;
-                sink.buf[0] = sh.stage[0][tid >> 6]; sink.buf[1] = sh.stage[1][tid >> 6];
-                sink.n[0] = sink.n[1] = 0;
-                sink.dst[0] = cand0; sink.dst[1] = cand1;
-                sink.counter[0] = &sh.ncand[0]; sink.counter[1] = &sh.ncand[1];
-                uint32_t cnt[4] = {0, 0, 0, 0};
-                select_sweep<kStageConc, ALIGNED>(src, a.P, 0, nch, tid, kFusedThreads, sh.tab, a.y_lim, K, sink, cnt);
-                sink.flush(0, lane);
-                sink.flush(1, lane);
-                for (int i = 0; i < 4; ++i)
-                    for (int o = 32; o > 0; o >>= 1) cnt[i] += __shfl_xor((int)cnt[i], o, 64);
-                if (lane == 0) {
-                    if (cnt[0]) atomicAdd(&sh.lt[0], cnt[0]);
-                    if (cnt[1]) atomicAdd(&sh.le[0], cnt[1]);
-                    if (cnt[2]) atomicAdd(&sh.lt[1], cnt[2]);
-                    if (cnt[3]) atomicAdd(&sh.le[1], cnt[3]);
-                }
+                run_select(std::integral_constant<int, kStageConc>{}, src, K);
             }
-            __threadfence_block();
-            __syncthreads();
             SL_PHASE(5);
             // ---------------- finish 3: exact 99th percentiles -> maxC
             {
@@ -1183,6 +1420,7 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_macenko_fused(Fused
         if (tid < 2 && a.maxC_out) a.maxC_out[(size_t)tile * 2 + tid] = sh.maxC[tid];
         if (tid == 0 && a.status_out) a.status_out[tile] = sh.status;
         if (tid == 0 && a.diag_out) a.diag_out[tile] = fallbacks;
+        if (tid == 0 && a.sweeps_out) a.sweeps_out[tile] = sweeps_used;
         SL_PHASE(6);
         // ---------------- sweep 4: apply
         if (TRANSFORM) {
