@@ -30,6 +30,9 @@ def _check_tiles(rgb: torch.Tensor):
 
 
 def _f64(x, shape, device):
+    if not isinstance(x, torch.Tensor):
+        import numpy as np
+        x = np.asarray(x, dtype=np.float64)
     t = torch.as_tensor(x, dtype=torch.float64, device=device).reshape(shape)
     return t.contiguous()
 
@@ -136,9 +139,8 @@ def hed_augment(rgb, sigma, bias, cutoff=(0.05, 0.95), skimage_mode=0, out=None,
     """Batched HedColorAugmenter.transform for uint8 tiles -> (out, applied (N,) i32)."""
     n, h, w = _check_tiles(rgb)
     dev = rgb.device
-    import numpy as np
-    sigma = torch.as_tensor(np.asarray(sigma, dtype=np.float64), device=dev).reshape(n, 3).contiguous()
-    bias = torch.as_tensor(np.asarray(bias, dtype=np.float64), device=dev).reshape(n, 3).contiguous()
+    sigma = _f64(sigma, (n, 3), dev)
+    bias = _f64(bias, (n, 3), dev)
     if out is None:
         out = torch.empty_like(rgb)
     applied = torch.empty((n,), dtype=torch.int32, device=dev)

@@ -1,0 +1,83 @@
+"""CPU, world_size = 2, gloo: the N>1 host path (sharding, stats gather with uneven shards, slide statistics).
+No GPU compute is involved: per-tile statistics are synthetic tensors."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from stainlib_amd import distributed as sd
+
+
+def test_shard_range_partitions_exactly():
+    for n in (0, 1, 7, 8, 100000):
+        for world in (1, 2, 3, 8):
+            spans = [sd.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        sd.shard_range(4, 2, 2)
+
+
+def _table(n, seed=0):
+    rng = np.random.RandomState(seed)
+    M = rng.rand(n, 2, 3) + 0.1
+    M /= np.linalg.norm(M, axis=2, keepdims=True)
+    maxC = rng.rand(n, 2) + 1.0
+    status = (rng.rand(n) < 0.2).astype(np.int32)
+    status[0] = 0
+    return torch.from_numpy(M), torch.from_numpy(maxC), torch.from_numpy(status)
+
+
+def _worker(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    M, maxC, status = _table(n)
+    lo, hi = sd.shard_range(n, rank, world)
+    Ma, ca, sa = sd.gather_tile_stats(M[lo:hi], maxC[lo:hi], status[lo:hi])
+    Ms, cs = sd.slide_statistics(Ma, ca, sa)
+    q.put((rank, Ma.numpy(), ca.numpy(), sa.numpy(), Ms.numpy(), cs.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("n", [7, 10])           # 7: uneven shards (3 + 4)
+def test_gather_and_slide_statistics_world2(n):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    M, maxC, status = _table(n)
+    Ms1, cs1 = sd.slide_statistics(M, maxC, status)          # the single-process answer
+    for rank, Ma, ca, sa, Ms, cs in res:
+        assert np.array_equal(Ma, M.numpy()) and np.array_equal(ca, maxC.numpy()) and np.array_equal(sa, status.numpy())
+        assert np.array_equal(Ms, Ms1.numpy()) and np.array_equal(cs, cs1.numpy())   # identical on every rank
+    np.testing.assert_allclose(np.linalg.norm(res[0][4], axis=1), 1.0, atol=1e-12)
+
+
+def test_single_process_passthrough_and_errors():
+    M, maxC, status = _table(5)
+    Ma, ca, sa = sd.gather_tile_stats(M, maxC, status)
+    assert torch.equal(Ma, M) and torch.equal(ca, maxC) and torch.equal(sa, status)
+    with pytest.raises(ValueError):
+        sd.slide_statistics(M, maxC, torch.ones(5, dtype=torch.int32))

@@ -123,3 +123,28 @@ def test_stain_augmentor_vs_reference_golden(path):
     u8_parity(o1, g["out1"], max_rate=4e-4)
     assert np.array_equal(a.tissue_mask, so.tissue_mask(I).ravel())
     assert a.source_concentrations.shape == (I.shape[0] * I.shape[1], 2)
+
+
+def test_slide_level_mode_single_rank():
+    """configs[4] extension, world_size 1: per-slide median statistics, then one apply pass."""
+    import torch
+    import stainlib_amd as sl
+    from stainlib_amd.distributed import SlideNormalizer
+    tiles = [so.synth_tile(96, 96, 40 + s) for s in range(6)] + [np.full((96, 96, 3), 255, np.uint8)]
+    tgt = so.synth_tile(128, 128, 1001, so.M_TRUE_TGT)
+    n = sl.MacenkoNormalizer()
+    n.fit(tgt)
+    out, M_s, mc_s, status = SlideNormalizer(n).transform_shard(to_dev(tiles))
+    assert list(status.cpu().numpy()) == [0] * 6 + [1]
+    fits = [(so.macenko_stain_matrix(I), None) for I in tiles[:6]]
+    Ms = np.median(np.stack([f[0] for f in fits]), axis=0)
+    Ms /= np.linalg.norm(Ms, axis=1)[:, None]
+    mcs = np.median(np.stack([np.percentile(so.get_concentrations(I, f[0]), 99, axis=0) for I, f in zip(tiles[:6], fits)]), axis=0)
+    np.testing.assert_allclose(M_s.cpu().numpy(), Ms, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(mc_s.cpu().numpy(), mcs, rtol=2e-6)
+    on = so.ExtractiveStainNormalizer("macenko")
+    on.fit(tgt)
+    for i in range(6):
+        C = so.get_concentrations(tiles[i], Ms) * (on.maxC_target / mcs)
+        want = so.truncate_u8(255 * np.exp(-C @ on.stain_matrix_target)).reshape(tiles[i].shape)
+        u8_parity(out[i].cpu().numpy(), want, max_rate=4e-4)
