@@ -245,6 +245,19 @@ def main():
         tiles_per_s = world * B * a.steps / elapsed
         per_gpu = tiles_per_s / world
 
+        # HBM traffic from PMC counters: collected in separate rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json
+        # documents command, units and the gfx950 FETCH_SIZE correction), scaled to this launch's pixel count
+        traffic_dom = traffic_ap = None
+        try:
+            pmc = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))["kernels"]
+            if fused:
+                traffic_dom = pmc["k_fused<macenko,transform>"]["bytes_per_pixel"] * P * (sum(t for t, _ in dom) / len(dom))
+            traffic_ap = pmc["k_apply"]["bytes_per_pixel"] * P * B
+            if not fused:
+                traffic_dom = pmc["k_apply"]["bytes_per_pixel"] * P * (sum(t for t, _ in dom) / max(len(dom), 1))
+        except Exception:  # noqa: BLE001
+            pass
+
         parity = None
         if world == 1:
             I = rgb[0].cpu().numpy()
@@ -274,13 +287,14 @@ def main():
                        "tiles_per_gpu": B, "tile": [h, w, 3], "sharding": f"independent tiles x{world}, no data-path collective",
                        "failed_tiles": n_bad},
             "roofline": {"kernel": dom_name, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic_dom,
+                         "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
                          "bytes_per_launch": dom_bytes, "bytes_per_pixel_model": bpp,
                          "avg_launch_ms": round(dom_ms, 5), "launches_timed": len(dom),
                          "frac_compulsory_6Bpx": round(achieved * 6.0 / bpp / HBM_PEAK_GBS, 4)},
             "roofline_apply": {"kernel": "k_apply (OD + reconstruction pass, sl_normalize_apply)", "bound": "hbm",
                                "achieved": round(ap_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(ap_gbs / HBM_PEAK_GBS, 4), "traffic": None, "bytes_per_launch": ap_bytes,
+                               "frac": round(ap_gbs / HBM_PEAK_GBS, 4), "traffic": traffic_ap, "bytes_per_launch": ap_bytes,
                                "avg_launch_ms": round(ap_ms, 5), "launches_timed": reps},
             "end_to_end": {"per_gpu_tiles_per_s": round(per_gpu, 1),
                            "frac_hbm_compulsory_6Bpx": round(per_gpu * 6.0 * P / 1e9 / HBM_PEAK_GBS, 4),

@@ -1,0 +1,17 @@
+"""A few launches of the fused transform / apply / copy on 512 tiles: PMC profiling target."""
+import sys
+import torch
+sys.path.insert(0, ".")
+from stainlib_amd import engine
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+rgb = engine.synth_tiles(n, 1024, 1024, seed=3)
+tgt = engine.synth_tiles(1, 1024, 1024, seed=1, M_true=[[0.55, 0.75, 0.35], [0.10, 0.95, 0.20]])
+Mt, mct, st = engine.macenko_fit(tgt)
+out = torch.empty_like(rgb)
+for _ in range(3):
+    o, M, mc, s = engine.macenko_transform(rgb, Mt[0], mct[0], out=out)
+for _ in range(3):
+    engine.normalize_apply(rgb, M, mc, Mt[0], mct[0], out=out)
+for _ in range(3):
+    out.copy_(rgb)          # calibration: a plain 1.6 GB read + 1.6 GB write
+torch.cuda.synchronize()
