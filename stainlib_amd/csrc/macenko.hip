@@ -20,7 +20,7 @@ struct Layout {
     int parts, stride_log2, n_sample, G;
     bool fused;
     int grid;                               // fused: workgroups launched
-    size_t off_M, off_maxC, off_status, off_partials, off_sample, off_cand, off_state, off_diag, total;
+    size_t off_M, off_maxC, off_status, off_partials, off_sample, off_cand, off_list, off_state, off_diag, total;
 };
 
 size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -47,7 +47,8 @@ Layout make_layout(int n, long P, bool force_fused = false) {
     L.off_diag = o;     o = align_up(o + sizeof(int32_t) * (size_t)n);
     L.off_partials = o; o = align_up(o + sizeof(double) * 10 * (size_t)L.parts * L.G);
     L.off_sample = o;   o = align_up(o + sizeof(uint32_t) * (size_t)L.n_sample * slots);
-    L.off_cand = o;     o = align_up(o + sizeof(float) * 2 * (size_t)kCapList * slots);
+    L.off_cand = o;     o = align_up(o + sizeof(uint32_t) * (size_t)kCapRaw * slots);
+    L.off_list = o;     o = align_up(o + sizeof(float) * 2 * (size_t)kCapList * slots);
     L.off_state = o;    o = align_up(o + sizeof(TileState) * (size_t)L.G);
     L.total = o;
     return L;
@@ -67,7 +68,8 @@ int run_stats_group(const uint8_t* rgb, int g0, int m, long P, const SlParams& p
     a.pct = p.angular_percentile;
     a.partials = (double*)(ws + L.off_partials);
     a.sample = (uint32_t*)(ws + L.off_sample);
-    a.cand = (float*)(ws + L.off_cand);
+    a.raw = (uint32_t*)(ws + L.off_cand);
+    a.cand = (float*)(ws + L.off_list);
     a.state = (TileState*)(ws + L.off_state);
     const bool al = aligned4(a.rgb, P);
     const dim3 gs((unsigned)((long)m * L.parts)), bs(kWG), gf((unsigned)m), bf(kFinishThreads);
@@ -114,7 +116,8 @@ int run_fused(int method, const uint8_t* rgb, uint8_t* out, int n, long P, const
     a.pct = p.angular_percentile;
     a.M_tgt = M_tgt;
     a.maxC_tgt = maxC_tgt;
-    a.cand = (float*)(ws + L.off_cand);
+    a.raw = (uint32_t*)(ws + L.off_cand);
+    a.cand = (float*)(ws + L.off_list);
     a.sample = (uint32_t*)(ws + L.off_sample);
     a.M_out = M_all;
     a.maxC_out = maxC_all;

@@ -39,11 +39,13 @@
 namespace sl {
 
 constexpr int kMaxSample = 16384;   // samples per tile (<= P/64)
-constexpr int kCapList = 16384;     // candidate capacity per bracket list
+constexpr int kCapRaw = 65536;      // raw-pixel candidate capacity per tile and selection stage
+constexpr int kCapList = 16384;     // exact-key bracket members per list after the refine pass
 constexpr int kFinishThreads = 1024;
-constexpr int kFusedThreads = 512;     // 2 resident workgroups per CU (<=128 VGPRs, 75 KB LDS each)
-constexpr int kWaveStage_unused = 0;    // per-wave LDS staging entries per list (multi-kernel select); a trip adds <= 512
+constexpr int kFusedThreads = 512;  // 2 resident workgroups per CU (<=128 VGPRs, <80 KB LDS each)
+constexpr int kStageWave = 256;     // per-wave LDS staging entries for raw candidates (8 KB per 8 waves)
 constexpr float kBracketZ = 6.0f;   // bracket half-width in standard deviations of the sample rank
+constexpr float kAngleMargin = 2e-5f;  // safety margin of the cheap pseudo-angle test (keys carry ~1e-7)
 
 struct TileState {
     // ---- after finish 1
@@ -51,9 +53,10 @@ struct TileState {
     double Vd[6];            // V[c][k], c = channel, k = 0 (largest eigenvalue), 1 (second)
     float Vf[6];
     float lo[2], hi[2];      // brackets of the current selection stage
-    unsigned int lt[2];      // keys <  lo   (per list)
-    unsigned int le[2];      // keys <= hi
-    unsigned int ncand[2];   // appended candidates (may exceed kCapList => overflow)
+    unsigned int n_plain;    // pixels the sweep classified without collecting them
+    unsigned int n_raw;      // raw candidates appended (may exceed kCapRaw => overflow)
+    unsigned int overflow;   // a wave's staging buffer overflowed: the collected list is incomplete
+    unsigned int pad_;
     // ---- after finish 2
     double M[6];
     // ---- after finish 3
@@ -73,9 +76,11 @@ struct StatsArgs {
     double pct;              // angular percentile
     double* partials;        // [tile][part][10]          (multi-kernel)
     uint32_t* sample;        // [tile][n_sample]          (multi-kernel)
-    float* cand;             // [tile or workgroup][2][kCapList]
+    uint32_t* raw;           // [tile or workgroup][kCapRaw] raw candidate pixels (r | g<<8 | b<<16)
+    float* cand;             // [tile or workgroup][2][kCapList] bracket members (exact keys)
     TileState* state;        // [tile]                    (multi-kernel)
 };
+
 
 // LDS lookup tables of the 256 byte values, bank-replicated: copy (lane & (R-1)) of entry v sits at
 // [v*R + copy], so the lanes a DS instruction services together hit distinct banks whatever bytes
@@ -525,9 +530,8 @@ __device__ __forceinline__ void stain_matrix_from_angles(const double* Vd, const
 struct Moments {
     double sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
     uint32_t cnt = 0;
-    __device__ __forceinline__ void add(bool on, double x, double y, double z) {
-        x = on ? x : 0.0; y = on ? y : 0.0; z = on ? z : 0.0;
-        cnt += on ? 1u : 0u;
+    __device__ __forceinline__ void add(double x, double y, double z) {
+        cnt += 1u;
         sx += x; sy += y; sz += z;
         sxx = fma(x, x, sxx); sxy = fma(x, y, sxy); sxz = fma(x, z, sxz);
         syy = fma(y, y, syy); syz = fma(y, z, syz); szz = fma(z, z, szz);
@@ -545,35 +549,31 @@ __device__ __forceinline__ void moments_sweep(const uint8_t* src, int P, int c0,
                                               SampleStore store_sample, Moments& mo) {
     const size_t nbytes = (size_t)P * 3;
     const int cps_log2 = stride_log2 - 2;          // chunks per sampling block
+    auto process = [&](const Chunk& ch, int cc) {
+        const bool live = cc < c1;
+        const uint32_t b = (uint32_t)cc >> cps_log2;        // stratified sample: block b keeps pixel b*stride+off
+        const uint32_t off = sample_offset(b, stride_log2);
+        const bool has_sample = live & ((off >> 2) == ((uint32_t)cc & ((1u << cps_log2) - 1)));
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            const uint32_t r = chunk_byte(ch, 3 * px), g = chunk_byte(ch, 3 * px + 1), bb = chunk_byte(ch, 3 * px + 2);
+            // every table read is unconditional so that the LDS gathers of a chunk issue back to back
+            const uint32_t gr = T.gam(r, t), gg = T.gam(g, t), gb = T.gam(bb, t);
+            const double ox = T.od64(r, t), oy = T.od64(g, t), oz = T.od64(bb, t);
+            const bool inb = live & (ALIGNED | ((size_t)cc * 4 + px < (size_t)P));
+            const bool tissue = inb & is_tissue(gr, gg, gb, y_lim);
+            if (tissue) mo.add(ox, oy, oz);                  // exec-masked accumulate, no loads inside
+            if (has_sample & ((off & 3) == (uint32_t)px) & inb)
+                store_sample(b, r | (g << 8) | (bb << 16) | ((tissue ? 1u : 0u) << 24));
+        }
+    };
     for (int c = c0 + t; c < c1; c += nthreads * 2) {
-        Chunk in[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int cc = c + u * nthreads;
-            in[u] = cc < c1 ? load_chunk<ALIGNED>(src, nbytes, cc) : Chunk{0xffffffffu, 0xffffffffu, 0xffffffffu};
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int cc = c + u * nthreads;
-            const bool live = cc < c1;
-            const uint32_t b = (uint32_t)cc >> cps_log2;        // stratified sample: block b keeps pixel b*stride+off
-            const uint32_t off = sample_offset(b, stride_log2);
-            const bool has_sample = live & ((off >> 2) == ((uint32_t)cc & ((1u << cps_log2) - 1)));
-#pragma unroll
-            for (int px = 0; px < 4; ++px) {
-                const uint32_t r = chunk_byte(in[u], 3 * px), g = chunk_byte(in[u], 3 * px + 1),
-                               bb = chunk_byte(in[u], 3 * px + 2);
-                // branch-free on purpose: every table read is unconditional so that the compiler can issue
-                // all LDS gathers of a trip back to back (a short-circuit && here costs 2.5x in time)
-                const uint32_t gr = T.gam(r, t), gg = T.gam(g, t), gb = T.gam(bb, t);
-                const double ox = T.od64(r, t), oy = T.od64(g, t), oz = T.od64(bb, t);
-                const bool inb = live & (ALIGNED | ((size_t)cc * 4 + px < (size_t)P));
-                const bool tissue = inb & is_tissue(gr, gg, gb, y_lim);
-                mo.add(tissue, ox, oy, oz);
-                if (has_sample & ((off & 3) == (uint32_t)px) & inb)
-                    store_sample(b, r | (g << 8) | (bb << 16) | ((tissue ? 1u : 0u) << 24));
-            }
-        }
+        const int cA = c, cB = c + nthreads;
+        const Chunk inA = cA < c1 ? load_chunk<ALIGNED>(src, nbytes, cA) : Chunk{0xffffffffu, 0xffffffffu, 0xffffffffu};
+        const Chunk inB = cB < c1 ? load_chunk<ALIGNED>(src, nbytes, cB) : Chunk{0xffffffffu, 0xffffffffu, 0xffffffffu};
+        process(inA, cA);
+        __builtin_amdgcn_sched_barrier(0);   // keep the two chunks' 24 table reads from being hoisted together (spills)
+        process(inB, cB);
     }
 }
 
@@ -585,15 +585,24 @@ struct SelConsts {
     float lo0, hi0, lo1, hi1;
 };
 
-// sweeps 2/3 over chunks [c0, c1): wave-uniform trip count so that ballots see every lane.
-// Per trip a lane classifies 8 pixels against both brackets; the bracket members are handed to the
-// sink in ONE commit per list (one reservation per trip instead of one per pixel).
+// Sweeps 2/3.  The sweep does NOT evaluate the selection keys of every pixel.  A cheap conservative
+// test proves, for ~97 % of the pixels, on which side of both brackets their keys fall; those are
+// only counted ("plain").  The remaining pixels -- inside or near a bracket, or beyond the outer
+// ends -- are appended as raw RGB to a per-tile list and resolved exactly by the finish step.
+//   angle stage (one key p for both brackets, tissue only): plain <=> hi0 < p < lo1, tested without the
+//     division as  y > (hi0+eps) d  and  y < (lo1-eps) d  with d = x + |y|, x > 0
+//   concentration stage (g12 >= 0): c_i <= max(0, a_i) exactly, so  a1 < lo0 and a2 < lo1  =>  both
+//     keys lie below their brackets (needs lo > 0; otherwise nothing is plain)
 template <int STAGE, bool ALIGNED, class TABS, class Sink>
 __device__ __forceinline__ void select_sweep(const uint8_t* src, int P, int c0, int c1, int t, int nthreads,
                                              const TABS& T, uint32_t y_lim, const SelConsts& K, Sink& sink,
-                                             uint32_t (&cnt)[4]) {
+                                             uint32_t& n_plain) {
     const size_t nbytes = (size_t)P * 3;
     const int lane = t & 63;
+    // thresholds of the cheap tests (wave-uniform)
+    const float hi0m = K.hi0 + kAngleMargin, lo1m = K.lo1 - kAngleMargin;
+    const bool conc_ok = (K.L.g12 >= 0.0f) & (K.lo0 > 0.0f) & (K.lo1 > 0.0f);
+    const float clo0 = conc_ok ? K.lo0 : -INFINITY, clo1 = conc_ok ? K.lo1 : -INFINITY;
     for (int cb = c0 + (t & ~63); cb < c1; cb += nthreads * 2) {
         Chunk in[2];
 #pragma unroll
@@ -601,8 +610,8 @@ __device__ __forceinline__ void select_sweep(const uint8_t* src, int P, int c0, 
             const int cc = cb + lane + u * nthreads;
             in[u] = cc < c1 ? load_chunk<ALIGNED>(src, nbytes, cc) : Chunk{0xffffffffu, 0xffffffffu, 0xffffffffu};
         }
-        float k0[8], k1[8];
-        bool f0[8], f1[8];
+        uint32_t raw[8];
+        bool flag[8];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int cc = cb + lane + u * nthreads;
@@ -614,37 +623,30 @@ __device__ __forceinline__ void select_sweep(const uint8_t* src, int P, int c0, 
                                bb = chunk_byte(in[u], 3 * px + 2);
                 const float ox = T.odf(r, t), oy = T.odf(g, t), oz = T.odf(bb, t);
                 const bool inb = live & (ALIGNED | ((size_t)cc * 4 + px < (size_t)P));
-                bool valid;
+                bool valid, plain;
                 if (STAGE == kStageAngle) {
                     const uint32_t gr = T.gam(r, t), gg = T.gam(g, t), gb = T.gam(bb, t);
                     valid = inb & is_tissue(gr, gg, gb, y_lim);
-                    k0[j] = k1[j] = angle_key(K.V, ox, oy, oz);
+                    const float x = fmaf(K.V[4], oz, fmaf(K.V[2], oy, K.V[0] * ox));
+                    const float y = fmaf(K.V[5], oz, fmaf(K.V[3], oy, K.V[1] * ox));
+                    const float d = x + fabsf(y);
+                    plain = valid & (x > 0.0f) & (fmaf(-hi0m, d, y) > 0.0f) & (fmaf(-lo1m, d, y) < 0.0f);
                 } else {
                     valid = inb;
-                    lasso2(K.L, ox, oy, oz, k0[j], k1[j]);
+                    float a1, a2;
+                    lasso_interior(K.L, ox, oy, oz, a1, a2);
+                    plain = valid & (a1 < clo0) & (a2 < clo1);
                 }
-                const bool b_lt0 = valid & (k0[j] < K.lo0), b_le0 = valid & (k0[j] <= K.hi0);
-                const bool b_lt1 = valid & (k1[j] < K.lo1), b_le1 = valid & (k1[j] <= K.hi1);
-                // per-LANE counters (v_cmp + v_addc): a ballot/popcount per pixel serialises the wave on the
-                // scalar unit (measured: 25 SALU instructions per pixel slot, 2x the sweep time)
-                cnt[0] += b_lt0 ? 1u : 0u;
-                cnt[1] += b_le0 ? 1u : 0u;
-                cnt[2] += b_lt1 ? 1u : 0u;
-                cnt[3] += b_le1 ? 1u : 0u;
-                f0[j] = b_le0 & !b_lt0;
-                f1[j] = b_le1 & !b_lt1;
+                n_plain += plain ? 1u : 0u;
+                flag[j] = valid & !plain;
+                raw[j] = r | (g << 8) | (bb << 16);
             }
         }
-        sink.commit(0, f0, k0, lane);
-        sink.commit(1, f1, k1, lane);
+        sink.commit(flag, raw, lane);
     }
 }
 
-// ---- key functors handed BY VALUE to the (non-inlined) selection primitives ----
-struct CandKey {
-    const float* cand;
-    __device__ __forceinline__ float operator()(int i) const { return cand[i]; }
-};
+// ---- key functors handed BY VALUE to the selection primitives ----
 // pseudo-angle of sample entry b (NaN: not tissue / beyond the tile)
 struct SampleAngleKey {
     const uint32_t* sample; TabView tab; float V[6]; int stride_log2; int P;
@@ -685,27 +687,138 @@ struct ConcTileKey {
         return col == 0 ? c1 : c2;
     }
 };
+// exact keys (for bracket 0 and bracket 1) of raw candidate i
+struct RawAngleKey2 {                 // one pseudo-angle serves both brackets; every raw candidate is tissue
+    const uint32_t* raw; TabView tab; float V[6];
+    __device__ __forceinline__ void operator()(int i, float& k0, float& k1) const {
+        const uint32_t s = raw[i];
+        k0 = k1 = angle_key(V, tab.odf(s & 255u), tab.odf((s >> 8) & 255u), tab.odf((s >> 16) & 255u));
+    }
+};
+struct RawConcKey2 {
+    const uint32_t* raw; TabView tab; LassoK L;
+    __device__ __forceinline__ void operator()(int i, float& k0, float& k1) const {
+        const uint32_t s = raw[i];
+        lasso2(L, tab.odf(s & 255u), tab.odf((s >> 8) & 255u), tab.odf((s >> 16) & 255u), k0, k1);
+    }
+};
 
-// Exact order statistics (k, k+1) of one list of a selection stage: from the collected candidates
-// when the bracket verified, else by exact selection over the whole tile (rare).
+struct CandKey {
+    const float* cand;
+    __device__ __forceinline__ float operator()(int i) const { return cand[i]; }
+};
+
+// One pass over the raw candidates of a stage: exact key(s) of every raw pixel, #keys below each
+// bracket, and the bracket members written compactly to cand[li][...] (<= kCapList each).
+// key2(i, k0, k1) yields both keys of raw entry i.
+template <class Key2>
+__device__ __forceinline__ void wg_refine(int n_raw, const Key2& key2, const float* lo, const float* hi, float* cand0,
+                                          float* cand1, uint32_t* n_lt /*[2]*/, uint32_t* n_in /*[2]*/, SelScratch& S) {
+    if (threadIdx.x < 4) S.misc[12 + threadIdx.x] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    uint32_t lt0 = 0, lt1 = 0;
+    const int bd = blockDim.x;
+    for (int i0 = threadIdx.x - lane; i0 < n_raw; i0 += bd) {      // wave-uniform trip count
+        const int i = i0 + lane;
+        float k0 = nan_f(), k1 = nan_f();
+        if (i < n_raw) key2(i, k0, k1);
+        lt0 += k0 < lo[0] ? 1u : 0u;
+        lt1 += k1 < lo[1] ? 1u : 0u;
+        const bool in0 = (k0 >= lo[0]) & (k0 <= hi[0]), in1 = (k1 >= lo[1]) & (k1 <= hi[1]);
+        const unsigned long long m0 = __ballot(in0), m1 = __ballot(in1);
+        if (m0) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&S.misc[14], (uint32_t)__popcll(m0));
+            base = __builtin_amdgcn_readfirstlane(base);
+            const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0));
+            if (in0 && pos < (uint32_t)kCapList) cand0[pos] = k0;
+        }
+        if (m1) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&S.misc[15], (uint32_t)__popcll(m1));
+            base = __builtin_amdgcn_readfirstlane(base);
+            const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0));
+            if (in1 && pos < (uint32_t)kCapList) cand1[pos] = k1;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { lt0 += __shfl_xor((int)lt0, o, 64); lt1 += __shfl_xor((int)lt1, o, 64); }
+    if (lane == 0) { if (lt0) atomicAdd(&S.misc[12], lt0); if (lt1) atomicAdd(&S.misc[13], lt1); }
+    __threadfence_block();
+    __syncthreads();
+    n_lt[0] = S.misc[12]; n_lt[1] = S.misc[13]; n_in[0] = S.misc[14]; n_in[1] = S.misc[15];
+    __syncthreads();
+}
+
+// Exact order statistics (k, k+1) of one bracket of a selection stage from the refined lists:
+// lt = pixels proven or found below the bracket, n_in = members collected in cand[].  Falls back to
+// exact selection over the whole tile when the bracket missed or a list was incomplete.
 template <class TileKeyAt>
-__device__ __forceinline__ void stage_order_stats(const float* cand, float lo, float hi, uint32_t lt, uint32_t le, uint32_t nc,
-                                  int P, TileKeyAt tile_key_at, uint32_t n, long long k, float& xa, float& xb,
-                                  int& fallbacks, SelScratch& S) {
+__device__ __forceinline__ void stage_order_stats(const float* cand, uint32_t n_in, bool complete, float lo, float hi,
+                                                  long long lt, int P, const TileKeyAt& tile_key_at, uint32_t n,
+                                                  long long k, float& xa, float& xb, int& fallbacks, SelScratch& S) {
     const long long k2 = (k + 1 < (long long)n) ? k + 1 : k;
-    const long long in = (long long)le - (long long)lt;
-    const bool covered = (k >= (long long)lt) && (k2 < (long long)lt + in);
-    if (covered && lo == hi) {               // every member of the bracket equals lo
-        xa = xb = lo;
-    } else if (covered && (long long)nc == in && nc <= (uint32_t)kCapList) {
-        wg_select_pair_small((int)nc, CandKey{cand}, (uint32_t)(k - lt), xa, xb, S);
+    const bool covered = complete && k >= lt && k2 < lt + (long long)n_in;
+    if (covered && lo == hi) {
+        xa = xb = lo;                                  // every member of the bracket equals lo
+    } else if (covered && n_in <= (uint32_t)kCapList) {
+        wg_select_pair_small((int)n_in, CandKey{cand}, (uint32_t)(k - lt), xa, xb, S);
         if (k2 == k) xb = xa;
-    } else {                                 // exact, slow, rare
+    } else {                                           // exact, slow, rare
         wg_select_pair(P, tile_key_at, (uint32_t)k, xa, xb, S);
         if (k2 == k) xb = xa;
         fallbacks += 1;
     }
 }
+
+// inclusive prefix sum over the 64 lanes of a wave with DPP row shifts / broadcasts (gfx9)
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+// Raw candidates are staged per wave in LDS and written out in dense bursts; the tile's list head is
+// touched once per burst.  Positions come from a DPP prefix sum of the per-lane counts: no atomics, no
+// LDS round trip, the fill level stays in an SGPR.
+struct RawSink {
+    uint32_t* buf;              // LDS, this wave's kStageWave entries
+    uint32_t n;                 // wave-uniform fill
+    uint32_t* dst;              // global raw list of the tile
+    unsigned int* head;         // list head (LDS in the fused kernel, global otherwise)
+    unsigned int* overflow;     // set when entries were lost (list incomplete => exact slow path)
+    __device__ __forceinline__ void flush(int lane) {
+        if (n == 0) return;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(head, n);
+        base = __builtin_amdgcn_readfirstlane(base);
+        for (uint32_t i = lane; i < n; i += 64)
+            if (base + i < (uint32_t)kCapRaw) dst[base + i] = buf[i];
+        n = 0;
+    }
+    __device__ __forceinline__ void commit(const bool (&f)[8], const uint32_t (&raw)[8], int lane) {
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cnt += f[j] ? 1u : 0u;
+        const uint32_t inc = wave_inclusive_scan(cnt);
+        const uint32_t total = __builtin_amdgcn_readlane(inc, 63);
+        if (total == 0) return;                                     // wave-uniform
+        if (n + total > (uint32_t)kStageWave) flush(lane);
+        if (total > (uint32_t)kStageWave) {                         // pathological trip: more than the buffer holds
+            if (lane == 0) *overflow = 1u;
+            return;
+        }
+        uint32_t pos = n + inc - cnt;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (f[j]) buf[pos++] = raw[j];
+        n += total;
+    }
+};
 
 // ------------------------------------------------------------------------------------------
 // Vahadane: sparse-NMF dictionary (vahadane_stain_extractor.py:35-36, spams.trainDL K=2, lambda1,
@@ -721,6 +834,36 @@ __device__ __forceinline__ void stage_order_stats(const float* cand, float lo, f
 // fixed point is the one plain full-batch block-coordinate descent reaches (oracle:
 // vahadane_dictionary), but in ~9 sweeps instead of ~90.
 // ------------------------------------------------------------------------------------------
+// binary64 twin of LassoK for the dictionary sweep: the active set is decided in binary64 so that the
+// partition (and with it the fixed-point iteration) is reproducible to ~1e-16, far below any dl_tol
+struct LassoK64 {
+    double wa1[3], ka1, wa2[3], ka2, ws1[3], ks1, ws2[3], ks2, g12, g22;
+};
+__device__ __forceinline__ void lasso_consts64(const double* M, double lam, LassoK64& k) {
+    const double g11 = M[0] * M[0] + M[1] * M[1] + M[2] * M[2];
+    const double g22 = M[3] * M[3] + M[4] * M[4] + M[5] * M[5];
+    const double g12 = M[0] * M[3] + M[1] * M[4] + M[2] * M[5];
+    const double det = g11 * g22 - g12 * g12;
+    const double i11 = g22 / det, i12 = -g12 / det, i22 = g11 / det;
+    for (int c = 0; c < 3; ++c) {
+        k.wa1[c] = i11 * M[c] + i12 * M[3 + c];
+        k.wa2[c] = i12 * M[c] + i22 * M[3 + c];
+        k.ws1[c] = M[c] / g11;
+        k.ws2[c] = M[3 + c] / g22;
+    }
+    k.ka1 = -lam * (i11 + i12); k.ka2 = -lam * (i12 + i22); k.ks1 = -lam / g11; k.ks2 = -lam / g22;
+    k.g12 = g12; k.g22 = g22;
+}
+__device__ __forceinline__ double uni(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffLL)), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ void uni(LassoK64& k) {
+    for (int c = 0; c < 3; ++c) { k.wa1[c] = uni(k.wa1[c]); k.wa2[c] = uni(k.wa2[c]); k.ws1[c] = uni(k.ws1[c]); k.ws2[c] = uni(k.ws2[c]); }
+    k.ka1 = uni(k.ka1); k.ka2 = uni(k.ka2); k.ks1 = uni(k.ks1); k.ks2 = uni(k.ks2); k.g12 = uni(k.g12); k.g22 = uni(k.g22);
+}
+
 struct ClsAcc {
     double sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
     uint32_t n = 0;
@@ -740,7 +883,7 @@ struct ClsAcc {
 // accumulate the moments of classes both / only-1 / only-2; n_tissue counts all tissue pixels.
 template <bool ALIGNED, bool SAMPLE, class TABS, class SampleStore>
 __device__ __forceinline__ void dict_sweep(const uint8_t* src, int P, int c0, int c1, int t, int nthreads, const TABS& T,
-                                           uint32_t y_lim, int stride_log2, const LassoK& L, SampleStore store_sample,
+                                           uint32_t y_lim, int stride_log2, const LassoK64& L, SampleStore store_sample,
                                            ClsAcc (&acc)[3], uint32_t& n_tissue) {
     const size_t nbytes = (size_t)P * 3;
     const int cps_log2 = stride_log2 - 2;
@@ -763,18 +906,17 @@ __device__ __forceinline__ void dict_sweep(const uint8_t* src, int P, int c0, in
                 const uint32_t r = chunk_byte(in[u], 3 * px), g = chunk_byte(in[u], 3 * px + 1),
                                bb = chunk_byte(in[u], 3 * px + 2);
                 const uint32_t gr = T.gam(r, t), gg = T.gam(g, t), gb = T.gam(bb, t);
-                const float fx = T.odf(r, t), fy = T.odf(g, t), fz = T.odf(bb, t);
                 const double ox = T.od64(r, t), oy = T.od64(g, t), oz = T.od64(bb, t);
                 const bool inb = live & (ALIGNED | ((size_t)cc * 4 + px < (size_t)P));
                 const bool tissue = inb & is_tissue(gr, gg, gb, y_lim);
-                // active set of the exact code (same enumeration as lasso2)
-                const float b1 = fmaf(L.m[0][2], fz, fmaf(L.m[0][1], fy, fmaf(L.m[0][0], fx, -L.lam)));
-                const float b2 = fmaf(L.m[1][2], fz, fmaf(L.m[1][1], fy, fmaf(L.m[1][0], fx, -L.lam)));
-                const float a1 = fmaf(L.i12, b2, L.i11 * b1);
-                const float a2 = fmaf(L.i12, b1, L.i22 * b2);
-                const bool both = (a1 >= 0.0f) & (a2 >= 0.0f);
-                const bool only1 = !both & (b1 > 0.0f) & (fmaf(-L.g12, b1 * L.r1, b2) <= 0.0f);
-                const bool only2 = !both & !only1 & (b2 * L.r2 > 0.0f);
+                // active set of the exact code (same quantities as lasso2, in binary64)
+                const double a1 = fma(L.wa1[2], oz, fma(L.wa1[1], oy, fma(L.wa1[0], ox, L.ka1)));
+                const double a2 = fma(L.wa2[2], oz, fma(L.wa2[1], oy, fma(L.wa2[0], ox, L.ka2)));
+                const double s1 = fma(L.ws1[2], oz, fma(L.ws1[1], oy, fma(L.ws1[0], ox, L.ks1)));
+                const double s2 = fma(L.ws2[2], oz, fma(L.ws2[1], oy, fma(L.ws2[0], ox, L.ks2)));
+                const bool both = (a1 >= 0.0) & (a2 >= 0.0);
+                const bool only1 = !both & (s1 > 0.0) & (fma(-L.g12, s1, L.g22 * s2) <= 0.0);
+                const bool only2 = !both & !only1 & (s2 > 0.0);
                 n_tissue += tissue ? 1u : 0u;
                 if (tissue & both) acc[0].add(ox, oy, oz);
                 if (tissue & only1) acc[1].add(ox, oy, oz);
@@ -944,7 +1086,7 @@ static __global__ __launch_bounds__(kFinishThreads) void k_finish_moments(StatsA
         for (int i = 0; i < 6; ++i) { st.Vd[i] = Vd[i]; st.Vf[i] = Vf[i]; s_V[i] = Vf[i]; }
         st.n_tissue = s_sum[0];
         st.fallbacks = 0;
-        for (int i = 0; i < 2; ++i) { st.lt[i] = 0; st.le[i] = 0; st.ncand[i] = 0; }
+        st.n_plain = 0; st.n_raw = 0; st.overflow = 0;
     }
     __syncthreads();
     SampleAngleKey key;
@@ -958,54 +1100,19 @@ static __global__ __launch_bounds__(kFinishThreads) void k_finish_moments(StatsA
     if (tid == 0) { st.lo[0] = lo[0]; st.hi[0] = hi[0]; st.lo[1] = lo[1]; st.hi[1] = hi[1]; }
 }
 
-// Bracket members are staged per wave in LDS and written out in bursts: the list head (a global
-// or LDS counter) is touched once per burst and the global stores are dense.  Scattered masked
-// stores straight from the sweep made it VMEM-issue bound (16 mostly-empty store instructions per
-// 8 pixels).
-template <int CAP>
-struct StagedSink {
-    float* buf[2];              // LDS, this wave's CAP entries per list
-    uint32_t n[2];              // wave-uniform fill
-    float* dst[2];              // global candidate lists
-    unsigned int* counter[2];   // list heads
-    __device__ __forceinline__ void flush(int li, int lane) {
-        if (n[li] == 0) return;
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(counter[li], n[li]);
-        base = __builtin_amdgcn_readfirstlane(base);
-        for (uint32_t i = lane; i < n[li]; i += 64)
-            if (base + i < (uint32_t)kCapList) dst[li][base + i] = buf[li][i];
-        n[li] = 0;
-    }
-    __device__ __forceinline__ void commit(int li, const bool (&f)[8], const float (&k)[8], int lane) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const unsigned long long m = __ballot(f[j]);
-            if (m) {                                                   // wave-uniform
-                const uint32_t c = __popcll(m);
-                if (n[li] + c > (uint32_t)CAP) flush(li, lane);
-                const uint32_t pos = n[li] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-                if (f[j]) buf[li][pos] = k[j];
-                n[li] += c;
-            }
-        }
-    }
-};
-constexpr int kStageMulti = 256;    // per-wave staging entries per list, multi-kernel select (4 waves)
-constexpr int kStageFused = 128;    // fused kernel (8 waves)
-
 template <int STAGE, bool ALIGNED>
 static __global__ __launch_bounds__(kWG) void k_select(StatsArgs a) {
     __shared__ Tabs<8, 8, 0> s_tab;
-    __shared__ float s_stage[2][kWG / 64][kStageMulti];
+    __shared__ uint32_t s_stage[kWG / 64][kStageWave];
     s_tab.fill();
     const int tile = blockIdx.x / a.parts, part = blockIdx.x % a.parts;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     TileState& st = a.state[tile];
-    if (st.status == SL_TILE_EMPTY_MASK || st.status == SL_TILE_DEGENERATE_COV) return;   // block-uniform
+    if (st.status != SL_TILE_OK) return;                                   // block-uniform
     SelConsts K;
     if (STAGE == kStageAngle) {
         for (int i = 0; i < 6; ++i) K.V[i] = uni(st.Vf[i]);
+        K.L.g12 = 0.0f;
     } else {
         lasso_consts(st.M, a.lam, K.L);
         uni(K.L);
@@ -1016,25 +1123,12 @@ static __global__ __launch_bounds__(kWG) void k_select(StatsArgs a) {
     const int nch = (a.P + 3) >> 2;
     const int span = (nch + a.parts - 1) / a.parts;
     const int c0 = part * span, c1 = min(nch, c0 + span);
-    StagedSink<kStageMulti> sink;
-    for (int li = 0; li < 2; ++li) {
-        sink.buf[li] = s_stage[li][wave];
-        sink.n[li] = 0;
-        sink.dst[li] = a.cand + ((size_t)tile * 2 + li) * kCapList;
-        sink.counter[li] = &st.ncand[li];
-    }
-    uint32_t cnt[4] = {0, 0, 0, 0};
-    select_sweep<STAGE, ALIGNED>(src, a.P, c0, c1, tid, kWG, s_tab, a.y_lim, K, sink, cnt);
-    sink.flush(0, lane);
-    sink.flush(1, lane);
-    for (int i = 0; i < 4; ++i)
-        for (int o = 32; o > 0; o >>= 1) cnt[i] += __shfl_xor((int)cnt[i], o, 64);
-    if (lane == 0) {
-        if (cnt[0]) atomicAdd(&st.lt[0], cnt[0]);
-        if (cnt[1]) atomicAdd(&st.le[0], cnt[1]);
-        if (cnt[2]) atomicAdd(&st.lt[1], cnt[2]);
-        if (cnt[3]) atomicAdd(&st.le[1], cnt[3]);
-    }
+    RawSink sink{s_stage[wave], 0u, a.raw + (size_t)tile * kCapRaw, &st.n_raw, &st.overflow};
+    uint32_t n_plain = 0;
+    select_sweep<STAGE, ALIGNED>(src, a.P, c0, c1, tid, kWG, s_tab, a.y_lim, K, sink, n_plain);
+    sink.flush(lane);
+    for (int o = 32; o > 0; o >>= 1) n_plain += __shfl_xor((int)n_plain, o, 64);
+    if (lane == 0 && n_plain) atomicAdd(&st.n_plain, n_plain);
 }
 
 static __global__ __launch_bounds__(kFinishThreads) void k_finish_angle(StatsArgs a) {
@@ -1044,7 +1138,7 @@ static __global__ __launch_bounds__(kFinishThreads) void k_finish_angle(StatsArg
     __shared__ LassoK s_L;
     const int tile = blockIdx.x, tid = threadIdx.x;
     TileState& st = a.state[tile];
-    if (st.status == SL_TILE_EMPTY_MASK || st.status == SL_TILE_DEGENERATE_COV) {
+    if (st.status != SL_TILE_OK) {
         if (tid < 6) st.M[tid] = nan_d();
         return;
     }
@@ -1053,17 +1147,27 @@ static __global__ __launch_bounds__(kFinishThreads) void k_finish_angle(StatsArg
     const uint8_t* src = a.rgb + (size_t)tile * a.P * 3;
     AngleTileKey tkey;
     tkey.src = src; tkey.tab = s_tab.view(); tkey.y_lim = a.y_lim;
-    for (int i = 0; i < 6; ++i) tkey.V[i] = st.Vf[i];
+    RawAngleKey2 rkey;
+    rkey.raw = a.raw + (size_t)tile * kCapRaw; rkey.tab = s_tab.view();
+    for (int i = 0; i < 6; ++i) { tkey.V[i] = st.Vf[i]; rkey.V[i] = st.Vf[i]; }
     const uint32_t T = (uint32_t)st.n_tissue;
     long long k[2];
     double gfrac[2];
     percentile_pos((double)T, 100.0 - a.pct, k[0], gfrac[0]);
     percentile_pos((double)T, a.pct, k[1], gfrac[1]);
+    const bool complete = st.n_raw <= (uint32_t)kCapRaw && st.overflow == 0;
+    const uint32_t n_raw = st.n_raw < (uint32_t)kCapRaw ? st.n_raw : (uint32_t)kCapRaw;
+    float* cand0 = a.cand + ((size_t)tile * 2 + 0) * kCapList;
+    float* cand1 = a.cand + ((size_t)tile * 2 + 1) * kCapList;
+    const float los[2] = {st.lo[0], st.lo[1]}, his[2] = {st.hi[0], st.hi[1]};
+    uint32_t n_lt[2], n_in[2];
+    wg_refine((int)n_raw, rkey, los, his, cand0, cand1, n_lt, n_in, S);
+    const long long base[2] = {0, (long long)st.n_plain};        // plain pixels sit between the two brackets
     int fallbacks = 0;
     for (int li = 0; li < 2; ++li) {
         float xa, xb;
-        stage_order_stats(a.cand + ((size_t)tile * 2 + li) * kCapList, st.lo[li], st.hi[li], st.lt[li], st.le[li],
-                          st.ncand[li], a.P, tkey, T, k[li], xa, xb, fallbacks, S);
+        stage_order_stats(li ? cand1 : cand0, n_in[li], complete, los[li], his[li], base[li] + n_lt[li], a.P, tkey, T,
+                          k[li], xa, xb, fallbacks, S);
         if (tid == 0) { s_res[2 * li] = xa; s_res[2 * li + 1] = xb; }
         __syncthreads();
     }
@@ -1075,7 +1179,7 @@ static __global__ __launch_bounds__(kFinishThreads) void k_finish_angle(StatsArg
         LassoK L;
         lasso_consts(M, a.lam, L);
         s_L = L;
-        for (int i = 0; i < 2; ++i) { st.lt[i] = 0; st.le[i] = 0; st.ncand[i] = 0; }
+        st.n_plain = 0; st.n_raw = 0; st.overflow = 0;
     }
     __syncthreads();
     SampleConcKey ckey;
@@ -1098,7 +1202,7 @@ static __global__ __launch_bounds__(kFinishThreads) void k_finish_conc(StatsArgs
     __shared__ LassoK s_L;
     const int tile = blockIdx.x, tid = threadIdx.x;
     TileState& st = a.state[tile];
-    const bool bad = st.status == SL_TILE_EMPTY_MASK || st.status == SL_TILE_DEGENERATE_COV;
+    const bool bad = st.status != SL_TILE_OK;
     if (!bad) {
         s_tab.fill();
         if (tid == 0) { LassoK L; lasso_consts(st.M, a.lam, L); s_L = L; }
@@ -1111,11 +1215,20 @@ static __global__ __launch_bounds__(kFinishThreads) void k_finish_conc(StatsArgs
         tkey.src = a.rgb + (size_t)tile * a.P * 3;
         tkey.tab = s_tab.view();
         tkey.L = s_L;
+        RawConcKey2 rkey;
+        rkey.raw = a.raw + (size_t)tile * kCapRaw; rkey.tab = s_tab.view(); rkey.L = s_L;
+        const bool complete = st.n_raw <= (uint32_t)kCapRaw && st.overflow == 0;
+        const uint32_t n_raw = st.n_raw < (uint32_t)kCapRaw ? st.n_raw : (uint32_t)kCapRaw;
+        float* cand0 = a.cand + ((size_t)tile * 2 + 0) * kCapList;
+        float* cand1 = a.cand + ((size_t)tile * 2 + 1) * kCapList;
+        const float los[2] = {st.lo[0], st.lo[1]}, his[2] = {st.hi[0], st.hi[1]};
+        uint32_t n_lt[2], n_in[2];
+        wg_refine((int)n_raw, rkey, los, his, cand0, cand1, n_lt, n_in, S);
         for (int col = 0; col < 2; ++col) {
             tkey.col = col;
             float xa, xb;
-            stage_order_stats(a.cand + ((size_t)tile * 2 + col) * kCapList, st.lo[col], st.hi[col], st.lt[col],
-                              st.le[col], st.ncand[col], a.P, tkey, (uint32_t)a.P, k, xa, xb, fallbacks, S);
+            stage_order_stats(col ? cand1 : cand0, n_in[col], complete, los[col], his[col], (long long)st.n_plain + n_lt[col],
+                              a.P, tkey, (uint32_t)a.P, k, xa, xb, fallbacks, S);
             if (tid == 0) { s_res[2 * col] = xa; s_res[2 * col + 1] = xb; }
             __syncthreads();
         }
@@ -1149,6 +1262,7 @@ struct FusedArgs {
     double pct;
     const double* M_tgt;     // transform only
     const double* maxC_tgt;  // transform only
+    uint32_t* raw;           // [gridDim.x][kCapRaw]
     float* cand;             // [gridDim.x][2][kCapList]
     uint32_t* sample;        // [gridDim.x][n_sample]
     double* M_out;           // [n_tiles][6]
@@ -1165,7 +1279,8 @@ struct FusedArgs {
 
 struct FusedShared {
     Tabs<32, 16, 4> tab;     // 32 + 16 + 8 KB
-    float stage[2][kFusedThreads / 64][kStageFused];   // 8 KB
+    uint32_t stage[kFusedThreads / 64][kStageWave];     // 16 KB
+    unsigned int n_plain, n_raw, overflow;
     SelScratch S;
     double red[kFusedThreads / 64][32];
     double sum[32];
@@ -1178,7 +1293,6 @@ struct FusedShared {
     double maxC[2];
     float Vf[6];
     float lo[2], hi[2];
-    unsigned int lt[2], le[2], ncand[2];
     float res[4];
     LassoK L;
     int status;
@@ -1194,30 +1308,20 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
     __syncthreads();
     const int nch = (a.P + 3) >> 2;
     uint32_t* samp = a.sample + (size_t)blockIdx.x * a.n_sample;
+    uint32_t* rawl = a.raw + (size_t)blockIdx.x * kCapRaw;
     float* cand0 = a.cand + ((size_t)blockIdx.x * 2 + 0) * kCapList;
     float* cand1 = a.cand + ((size_t)blockIdx.x * 2 + 1) * kCapList;
 
-    // sweeps 2/3 share this: select around sh.lo/hi with constants K, counts and candidates into sh.*
+    // sweeps 2/3 share this: classify against sh.lo/hi with constants K; plain count and raw candidates into sh.*
     auto run_select = [&](auto stage_tag, const uint8_t* src, SelConsts& K) {
         constexpr int STAGE = decltype(stage_tag)::value;
         K.lo0 = uni(sh.lo[0]); K.hi0 = uni(sh.hi[0]); K.lo1 = uni(sh.lo[1]); K.hi1 = uni(sh.hi[1]);
-        StagedSink<kStageFused> sink;
-        sink.buf[0] = sh.stage[0][wave]; sink.buf[1] = sh.stage[1][wave];
-        sink.n[0] = sink.n[1] = 0;
-        sink.dst[0] = cand0; sink.dst[1] = cand1;
-        sink.counter[0] = &sh.ncand[0]; sink.counter[1] = &sh.ncand[1];
-        uint32_t cnt[4] = {0, 0, 0, 0};
-        select_sweep<STAGE, ALIGNED>(src, a.P, 0, nch, tid, kFusedThreads, sh.tab, a.y_lim, K, sink, cnt);
-        sink.flush(0, lane);
-        sink.flush(1, lane);
-        for (int i = 0; i < 4; ++i)
-            for (int o = 32; o > 0; o >>= 1) cnt[i] += __shfl_xor((int)cnt[i], o, 64);
-        if (lane == 0) {
-            if (cnt[0]) atomicAdd(&sh.lt[0], cnt[0]);
-            if (cnt[1]) atomicAdd(&sh.le[0], cnt[1]);
-            if (cnt[2]) atomicAdd(&sh.lt[1], cnt[2]);
-            if (cnt[3]) atomicAdd(&sh.le[1], cnt[3]);
-        }
+        RawSink sink{sh.stage[wave], 0u, rawl, &sh.n_raw, &sh.overflow};
+        uint32_t n_plain = 0;
+        select_sweep<STAGE, ALIGNED>(src, a.P, 0, nch, tid, kFusedThreads, sh.tab, a.y_lim, K, sink, n_plain);
+        sink.flush(lane);
+        for (int o = 32; o > 0; o >>= 1) n_plain += __shfl_xor((int)n_plain, o, 64);
+        if (lane == 0 && n_plain) atomicAdd(&sh.n_plain, n_plain);
         __threadfence_block();
         __syncthreads();
     };
@@ -1257,7 +1361,7 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
                 float Vf[6];
                 sh.status = eigvecs_from_moments(sh.sum, Vd, Vf);
                 for (int i = 0; i < 6; ++i) { sh.Vd[i] = Vd[i]; sh.Vf[i] = Vf[i]; }
-                for (int i = 0; i < 2; ++i) { sh.lt[i] = 0; sh.le[i] = 0; sh.ncand[i] = 0; }
+                sh.n_plain = 0; sh.n_raw = 0; sh.overflow = 0;
             }
             __syncthreads();
             if (sh.status == SL_TILE_OK) {                                    // block-uniform
@@ -1275,6 +1379,7 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
                 {
                     SelConsts K;
                     for (int i = 0; i < 6; ++i) K.V[i] = uni(sh.Vf[i]);
+                    K.L.g12 = 0.0f;
                     run_select(std::integral_constant<int, kStageAngle>{}, src, K);
                 }
                 SL_PHASE(3);
@@ -1286,11 +1391,19 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
                 percentile_pos((double)T, a.pct, k[1], gfrac[1]);
                 AngleTileKey tkey;
                 tkey.src = src; tkey.tab = sh.tab.view(); tkey.y_lim = a.y_lim;
-                for (int i = 0; i < 6; ++i) tkey.V[i] = sh.Vf[i];
+                RawAngleKey2 rkey;
+                rkey.raw = rawl; rkey.tab = sh.tab.view();
+                for (int i = 0; i < 6; ++i) { tkey.V[i] = sh.Vf[i]; rkey.V[i] = sh.Vf[i]; }
+                const bool complete = sh.n_raw <= (uint32_t)kCapRaw && sh.overflow == 0;
+                const uint32_t n_raw = sh.n_raw < (uint32_t)kCapRaw ? sh.n_raw : (uint32_t)kCapRaw;
+                const float los[2] = {sh.lo[0], sh.lo[1]}, his[2] = {sh.hi[0], sh.hi[1]};
+                const long long base[2] = {0, (long long)sh.n_plain};
+                uint32_t n_lt[2], n_in[2];
+                wg_refine((int)n_raw, rkey, los, his, cand0, cand1, n_lt, n_in, sh.S);
                 for (int li = 0; li < 2; ++li) {
                     float xa, xb;
-                    stage_order_stats(li ? cand1 : cand0, sh.lo[li], sh.hi[li], sh.lt[li], sh.le[li], sh.ncand[li], a.P,
-                                      tkey, T, k[li], xa, xb, fallbacks, sh.S);
+                    stage_order_stats(li ? cand1 : cand0, n_in[li], complete, los[li], his[li], base[li] + n_lt[li], a.P, tkey,
+                                      T, k[li], xa, xb, fallbacks, sh.S);
                     if (tid == 0) { sh.res[2 * li] = xa; sh.res[2 * li + 1] = xb; }
                     __syncthreads();
                 }
@@ -1309,13 +1422,14 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
                 for (int k = 0; k < 3; ++k) { sh.D[k] = h[k] / nh; sh.D[3 + k] = e[k] / ne; }
                 sh.status = SL_TILE_OK;
                 sh.delta = 1.0;
+                sh.n_plain = 0; sh.n_raw = 0; sh.overflow = 0;
                 for (int k = 0; k < 6; ++k) sh.Dprev[k] = 1e300;
                 sh.inner_cap = 500;
             }
             __syncthreads();
             for (int outer = 0; outer < a.dl_max_sweeps; ++outer) {
-                LassoK Ld;
-                lasso_consts(sh.D, a.dl_lambda, Ld);
+                LassoK64 Ld;
+                lasso_consts64(sh.D, a.dl_lambda, Ld);
                 uni(Ld);
                 ClsAcc acc[3];
                 uint32_t n_tissue = 0;
@@ -1386,7 +1500,7 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
                 LassoK L;
                 lasso_consts(sh.M, a.lam, L);
                 sh.L = L;
-                for (int i = 0; i < 2; ++i) { sh.lt[i] = 0; sh.le[i] = 0; sh.ncand[i] = 0; }
+                sh.n_plain = 0; sh.n_raw = 0; sh.overflow = 0;
             }
             __syncthreads();
             // ---------------- concentration brackets from the sample
@@ -1415,11 +1529,19 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
                 percentile_pos((double)a.P, 99.0, k, gfrac);
                 ConcTileKey tkey;
                 tkey.src = src; tkey.tab = sh.tab.view(); tkey.L = sh.L;
+                RawConcKey2 rkey;
+                rkey.raw = rawl; rkey.tab = sh.tab.view(); rkey.L = sh.L;
+                const bool complete = sh.n_raw <= (uint32_t)kCapRaw && sh.overflow == 0;
+                const uint32_t n_raw = sh.n_raw < (uint32_t)kCapRaw ? sh.n_raw : (uint32_t)kCapRaw;
+                const float los[2] = {sh.lo[0], sh.lo[1]}, his[2] = {sh.hi[0], sh.hi[1]};
+                const long long n_plain = sh.n_plain;
+                uint32_t n_lt[2], n_in[2];
+                wg_refine((int)n_raw, rkey, los, his, cand0, cand1, n_lt, n_in, sh.S);
                 for (int col = 0; col < 2; ++col) {
                     tkey.col = col;
                     float xa, xb;
-                    stage_order_stats(col ? cand1 : cand0, sh.lo[col], sh.hi[col], sh.lt[col], sh.le[col], sh.ncand[col],
-                                      a.P, tkey, (uint32_t)a.P, k, xa, xb, fallbacks, sh.S);
+                    stage_order_stats(col ? cand1 : cand0, n_in[col], complete, los[col], his[col], n_plain + n_lt[col], a.P,
+                                      tkey, (uint32_t)a.P, k, xa, xb, fallbacks, sh.S);
                     if (tid == 0) { sh.res[2 * col] = xa; sh.res[2 * col + 1] = xb; }
                     __syncthreads();
                 }
