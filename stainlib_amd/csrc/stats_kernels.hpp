@@ -95,12 +95,12 @@ template <int RF, int RG, int RD>
 struct Tabs {
     float f[256 * RF];                       // max(-ln(v/255), 1e-6) in binary32
     uint32_t g[256 * RG];                    // OpenCV inverse-sRGB-gamma table
-    double d[256 * (RD > 0 ? RD : 1)];       // OD in binary64 (moment sums only)
+    double d[257 * (RD > 0 ? RD : 1)];       // OD in binary64 (moment sums only); entry 256 = 0.0 (masked-out pixel)
     __device__ __forceinline__ void fill() {
         for (int i = threadIdx.x; i < 256 * RF; i += blockDim.x) f[i] = d_od_f32[i / RF];
         for (int i = threadIdx.x; i < 256 * RG; i += blockDim.x) g[i] = d_gamma[i / RG];
         if (RD > 0)
-            for (int i = threadIdx.x; i < 256 * RD; i += blockDim.x) d[i] = d_od_f64[i / RD];
+            for (int i = threadIdx.x; i < 257 * RD; i += blockDim.x) d[i] = i < 256 * RD ? d_od_f64[i / RD] : 0.0;
     }
     __device__ __forceinline__ float odf(uint32_t v, uint32_t lane) const { return f[v * RF + (lane & (RF - 1))]; }
     __device__ __forceinline__ uint32_t gam(uint32_t v, uint32_t lane) const { return g[v * RG + (lane & (RG - 1))]; }
@@ -530,8 +530,8 @@ __device__ __forceinline__ void stain_matrix_from_angles(const double* Vd, const
 struct Moments {
     double sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
     uint32_t cnt = 0;
-    __device__ __forceinline__ void add(double x, double y, double z) {
-        cnt += 1u;
+    __device__ __forceinline__ void add(bool on, double x, double y, double z) {   // x = y = z = 0 when !on
+        cnt += on ? 1u : 0u;
         sx += x; sy += y; sz += z;
         sxx = fma(x, x, sxx); sxy = fma(x, y, sxy); sxz = fma(x, z, sxz);
         syy = fma(y, y, syy); syz = fma(y, z, syz); szz = fma(z, z, szz);
@@ -557,12 +557,13 @@ __device__ __forceinline__ void moments_sweep(const uint8_t* src, int P, int c0,
 #pragma unroll
         for (int px = 0; px < 4; ++px) {
             const uint32_t r = chunk_byte(ch, 3 * px), g = chunk_byte(ch, 3 * px + 1), bb = chunk_byte(ch, 3 * px + 2);
-            // every table read is unconditional so that the LDS gathers of a chunk issue back to back
+            // branch-free: a non-tissue pixel reads table entry 256 (= 0.0) instead of being skipped, so the
+            // whole chunk stays one basic block and its LDS gathers issue back to back
             const uint32_t gr = T.gam(r, t), gg = T.gam(g, t), gb = T.gam(bb, t);
-            const double ox = T.od64(r, t), oy = T.od64(g, t), oz = T.od64(bb, t);
             const bool inb = live & (ALIGNED | ((size_t)cc * 4 + px < (size_t)P));
             const bool tissue = inb & is_tissue(gr, gg, gb, y_lim);
-            if (tissue) mo.add(ox, oy, oz);                  // exec-masked accumulate, no loads inside
+            const double ox = T.od64(tissue ? r : 256u, t), oy = T.od64(tissue ? g : 256u, t), oz = T.od64(tissue ? bb : 256u, t);
+            mo.add(tissue, ox, oy, oz);
             if (has_sample & ((off & 3) == (uint32_t)px) & inb)
                 store_sample(b, r | (g << 8) | (bb << 16) | ((tissue ? 1u : 0u) << 24));
         }
