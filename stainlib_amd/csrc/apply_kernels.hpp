@@ -54,7 +54,8 @@ __device__ __forceinline__ void recon_px(const ReconK& R, float c1, float c2, fl
 // Truncating cast of normalizer.py:50 (`astype(np.uint8)`): toward zero, then modulo 256.
 __device__ __forceinline__ uint32_t trunc_u8(float t) { return ((uint32_t)t) & 0xffu; }
 
-constexpr int kU = 4;  // chunks in flight per lane per trip (4 x 12 B loads issued back to back)
+constexpr int kU = 4;       // chunks in flight per lane per trip (plain sweeps: 4 x 12 B loads issued back to back)
+constexpr int kUApply = 2;  // k_apply: 2 chunks per trip with the following trip prefetched
 
 template <bool ALIGNED, bool PREQ>
 static __global__ __launch_bounds__(kWG) void k_apply(const uint8_t* __restrict__ rgb, uint8_t* __restrict__ out,
@@ -97,15 +98,20 @@ static __global__ __launch_bounds__(kWG) void k_apply(const uint8_t* __restrict_
         return;
     }
 
-    for (int c = c0 + tid; c < c1; c += kWG * kU) {
-        Chunk in[kU];
+    // software pipeline: the next trip's chunks are requested before this trip's arithmetic (measured +5 %)
+    auto fetch = [&](int cc) { return cc < c1 ? load_chunk<ALIGNED>(src, nbytes, cc) : Chunk{0, 0, 0}; };
+    Chunk nxt[kUApply];
 #pragma unroll
-        for (int u = 0; u < kU; ++u) {
-            const int cc = c + u * kWG;
-            in[u] = cc < c1 ? load_chunk<ALIGNED>(src, nbytes, cc) : Chunk{0, 0, 0};
+    for (int u = 0; u < kUApply; ++u) nxt[u] = fetch(c0 + tid + u * kWG);
+    for (int c = c0 + tid; c < c1; c += kWG * kUApply) {
+        Chunk in[kUApply];
+#pragma unroll
+        for (int u = 0; u < kUApply; ++u) {
+            in[u] = nxt[u];
+            nxt[u] = fetch(c + (kUApply + u) * kWG);
         }
 #pragma unroll
-        for (int u = 0; u < kU; ++u) {
+        for (int u = 0; u < kUApply; ++u) {
             const int cc = c + u * kWG;
             uint32_t ob[12];
 #pragma unroll
