@@ -148,3 +148,18 @@ def test_slide_level_mode_single_rank():
         C = so.get_concentrations(tiles[i], Ms) * (on.maxC_target / mcs)
         want = so.truncate_u8(255 * np.exp(-C @ on.stain_matrix_target)).reshape(tiles[i].shape)
         u8_parity(out[i].cpu().numpy(), want, max_rate=4e-4)
+
+
+def test_tile_pipeline_matches_direct_transform():
+    """H2D / kernels / D2H on three streams with double-buffered pinned staging."""
+    import stainlib_amd as sl
+    from stainlib_amd.pipeline import normalizer_pipeline
+    n = sl.MacenkoNormalizer()
+    n.fit(so.synth_tile(128, 128, 1001, so.M_TRUE_TGT))
+    batches = [np.stack([so.synth_tile(96, 96, 500 + 8 * b + i) for i in range(8 if b < 4 else 3)]) for b in range(5)]
+    pipe = normalizer_pipeline(n, (8, 96, 96, 3))
+    outs = [o.copy() for o in pipe.run(batches)]
+    assert [o.shape[0] for o in outs] == [8, 8, 8, 8, 3]
+    for b, o in zip(batches, outs):
+        direct = n.transform_batch(to_dev(b))[0].cpu().numpy()
+        assert np.array_equal(o, direct)
