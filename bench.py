@@ -146,15 +146,23 @@ def main():
     from oracle import stain_oracle as so
     from stainlib_amd import _ffi, engine
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    backend = os.environ.get("SL_BENCH_BACKEND", "nccl")      # "gloo" only for single-GPU dry runs of the N>1 logic
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            if backend == "nccl":
+                dist.barrier(device_ids=[dev_index])
+            else:
+                dist.barrier()
 
     h = w = a.size
     P = h * w
@@ -307,7 +315,7 @@ def main():
             line["gpu_over_cpu"] = round(tiles_per_s / cpu["value"], 1)
     ev.close()
     if world > 1:
-        dist.barrier(device_ids=[local_rank])
+        barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(line))

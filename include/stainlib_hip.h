@@ -154,6 +154,17 @@ int sl_hed_augment(const uint8_t* rgb, uint8_t* out, int n, int h, int w,
                    int skimage_mode, int32_t* applied,
                    void* workspace, size_t workspace_bytes, void* stream);
 
+/* The float branch of HedColorAugmenter.transform (augmentation/augmenter.py:288-289, 319-320): patches of
+ * binary64 values in [0,1], n x h x w x 3; cutoff on np.mean(patch); binary64 arithmetic; clipped output.
+ * workspace: 8 n bytes. */
+int sl_hed_augment_f64(const double* rgb, double* out, int n, int h, int w,
+                       const double* sigma, const double* bias, double cutoff_lo, double cutoff_hi,
+                       int skimage_mode, int32_t* applied,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* convert_RGB_to_OD (utils/stain_utils.py:101-112) materialised: od_out n x h x w x 3 double. */
+int sl_rgb_to_od(const uint8_t* rgb, int n, int h, int w, double* od_out, void* stream);
+
 /* StainAugmentor.pop (augmentation/augmenter.py:428-449): concentrations with the tile's
  * stain matrix M (n x 2 x 3), C[:,i] = C[:,i]*alpha_i + beta_i on tissue pixels (all pixels
  * when augment_background), 255*exp(-C @ M), clip to [0,255], truncate.

@@ -64,6 +64,8 @@ _SIGNATURES = {
     "sl_macenko_transform": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(SlParams), _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "sl_vahadane_transform": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(SlParams), _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "sl_hed_augment": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_double, C.c_double, C.c_int, _P, _P, C.c_size_t, _P]),
+    "sl_hed_augment_f64": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_double, C.c_double, C.c_int, _P, _P, C.c_size_t, _P]),
+    "sl_rgb_to_od": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "sl_stain_augment": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.POINTER(SlParams), _P]),
     "sl_tissue_mask": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_double, _P, _P, _P]),
     "sl_concentrations": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_double, _P, _P]),

@@ -83,10 +83,16 @@ class HedColorAugmenter(ColorAugmenterBase):
     def transform(self, patch):
         """augmenter.py:276-331 for uint8 patches.  A patch whose mean is outside the cutoff interval is
         returned as the same object."""
-        if not is_uint8_image(patch):
-            raise NotImplementedError("stainlib_amd implements the uint8 branch of HedColorAugmenter.transform "
-                                      "(augmenter.py:290-291, 323-325); float patches are not supported")
         from .. import engine
+        if isinstance(patch, np.ndarray) and patch.ndim == 3 and patch.dtype.kind == "f":
+            # float branch (augmenter.py:288-289): values in [0,1]; the result is float64, clipped, not rescaled
+            import torch
+            dev = torch.from_numpy(np.ascontiguousarray(patch, dtype=np.float64)[None]).cuda()
+            out, applied = engine.hed_augment_float(dev, [self._sigmas], [self._biases], cutoff=self._cutoff_range,
+                                                    skimage_mode=self._skimage_mode)
+            return out[0].cpu().numpy() if int(applied[0]) else patch
+        if not is_uint8_image(patch):
+            raise TypeError("HedColorAugmenter.transform expects a uint8 or float (H, W, 3) ndarray")
         out, applied = engine.hed_augment(_to_device(patch), [self._sigmas], [self._biases],
                                           cutoff=self._cutoff_range, skimage_mode=self._skimage_mode)
         if int(applied[0]) == 0:

@@ -142,6 +142,68 @@ static __global__ __launch_bounds__(kWG) void k_hed_fixup(const uint8_t* __restr
     for (int c = c0 + threadIdx.x; c < c1; c += kWG) store_chunk<ALIGNED>(dst, nbytes, c, load_chunk<ALIGNED>(src, nbytes, c));
 }
 
+
+// ---- float patches (augmenter.py:288-289, 319-320): values in [0,1], binary64 in and out -------------
+template <int MODE>
+static __global__ __launch_bounds__(kWG) void k_hed_f64(const double* __restrict__ rgb, double* __restrict__ out, int P,
+                                                        int parts, const double* __restrict__ sigma,
+                                                        const double* __restrict__ bias, HedConst hc,
+                                                        double* __restrict__ sums) {
+    __shared__ double s_sum;
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x / parts, part = blockIdx.x % parts;
+    if (tid == 0) s_sum = 0;
+    __syncthreads();
+    const double Ladj = log(1e-6);
+    const double* sg = sigma + 3 * (size_t)tile;
+    const double* bs = bias + 3 * (size_t)tile;
+    const int span = (P + parts - 1) / parts;
+    const int p0 = part * span, p1 = min(P, p0 + span);
+    const double* src = rgb + (size_t)tile * P * 3;
+    double* dst = out + (size_t)tile * P * 3;
+    double acc = 0;
+    for (int p = p0 + tid; p < p1; p += kWG) {
+        const double r = src[3 * (size_t)p], g = src[3 * (size_t)p + 1], b = src[3 * (size_t)p + 2];
+        acc += r + g + b;
+        const double x[3] = {log(fmax(r, 1e-6)) / Ladj, log(fmax(g, 1e-6)) / Ladj, log(fmax(b, 1e-6)) / Ladj};
+        double st[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            st[k] = x[0] * hc.H[k] + x[1] * hc.H[3 + k] + x[2] * hc.H[6 + k];       // separate_stains
+            if (MODE == 1) st[k] = fmax(st[k], 0.0);
+            st[k] = st[k] * (1.0 + sg[k]) + bs[k];                                  // augmenter.py:298-316
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double lr = -(st[0] * (-Ladj)) * hc.R[c] - (st[1] * (-Ladj)) * hc.R[3 + c] - (st[2] * (-Ladj)) * hc.R[6 + c];
+            dst[3 * (size_t)p + c] = fmin(fmax(exp(lr), 0.0), 1.0);                 // combine_stains + clip
+        }
+    }
+    acc = wave_sum(acc);
+    if ((tid & 63) == 0) atomicAdd(&s_sum, acc);
+    __syncthreads();
+    if (tid == 0) atomicAdd(&sums[tile], s_sum);
+}
+
+static __global__ __launch_bounds__(kWG) void k_hed_f64_fixup(const double* __restrict__ rgb, double* __restrict__ out,
+                                                              int P, int parts, const double* __restrict__ sums,
+                                                              double lo, double hi, int32_t* __restrict__ applied) {
+    const int tile = blockIdx.x / parts, part = blockIdx.x % parts;
+    const double mean = sums[tile] / (3.0 * (double)P);                              // np.mean(patch), augmenter.py:289
+    const bool ok = (lo <= mean) && (mean <= hi);
+    if (part == 0 && threadIdx.x == 0 && applied) applied[tile] = ok ? 1 : 0;
+    if (ok) return;
+    const int span = (P + parts - 1) / parts;
+    const int p0 = part * span, p1 = min(P, p0 + span);
+    for (size_t i = 3 * (size_t)p0 + threadIdx.x; i < 3 * (size_t)p1; i += kWG)
+        out[(size_t)tile * P * 3 + i] = rgb[(size_t)tile * P * 3 + i];
+}
+
+// convert_RGB_to_OD (stain_utils.py:101-112) materialised
+static __global__ __launch_bounds__(kWG) void k_rgb_to_od(const uint8_t* __restrict__ rgb, size_t nbytes, double* __restrict__ od) {
+    for (size_t i = blockIdx.x * (size_t)kWG + threadIdx.x; i < nbytes; i += (size_t)gridDim.x * kWG) od[i] = d_od_f64[rgb[i]];
+}
+
 }  // namespace sl
 
 using namespace sl;
@@ -182,5 +244,36 @@ extern "C" int sl_hed_augment(const uint8_t* rgb, uint8_t* out, int n, int h, in
 #undef SL_GO
     if (al) hipLaunchKernelGGL((k_hed_fixup<true>), grid, block, 0, s, rgb, out, (int)P, parts, sums, cutoff_lo, cutoff_hi, applied);
     else    hipLaunchKernelGGL((k_hed_fixup<false>), grid, block, 0, s, rgb, out, (int)P, parts, sums, cutoff_lo, cutoff_hi, applied);
+    return launch_status();
+}
+
+extern "C" int sl_hed_augment_f64(const double* rgb, double* out, int n, int h, int w, const double* sigma,
+                                  const double* bias, double cutoff_lo, double cutoff_hi, int skimage_mode,
+                                  int32_t* applied, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!rgb || !out || !sigma || !bias || n <= 0 || h <= 0 || w <= 0) return SL_ERR_BADARG;
+    if (skimage_mode != SL_HED_SKIMAGE_018 && skimage_mode != SL_HED_SKIMAGE_019) return SL_ERR_BADARG;
+    const long P = (long)h * w;
+    if (P > (1L << 30)) return SL_ERR_BADARG;
+    if (!workspace || workspace_bytes < sizeof(double) * (size_t)n || ((uintptr_t)workspace & 7u)) return SL_ERR_WORKSPACE;
+    HedConst hc;
+    const double R[9] = {0.65, 0.70, 0.29, 0.07, 0.99, 0.11, 0.27, 0.57, 0.78};
+    for (int i = 0; i < 9; ++i) hc.R[i] = R[i];
+    inv3(R, hc.H);
+    hipStream_t s = (hipStream_t)stream;
+    double* sums = (double*)workspace;
+    SL_HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * (size_t)n, s));
+    const int parts = parts_for(P);
+    const dim3 grid((unsigned)((long)n * parts)), block(kWG);
+    if (skimage_mode == SL_HED_SKIMAGE_018) hipLaunchKernelGGL((k_hed_f64<0>), grid, block, 0, s, rgb, out, (int)P, parts, sigma, bias, hc, sums);
+    else hipLaunchKernelGGL((k_hed_f64<1>), grid, block, 0, s, rgb, out, (int)P, parts, sigma, bias, hc, sums);
+    hipLaunchKernelGGL(k_hed_f64_fixup, grid, block, 0, s, rgb, out, (int)P, parts, sums, cutoff_lo, cutoff_hi, applied);
+    return launch_status();
+}
+
+extern "C" int sl_rgb_to_od(const uint8_t* rgb, int n, int h, int w, double* od_out, void* stream) {
+    if (!rgb || !od_out || n <= 0 || h <= 0 || w <= 0) return SL_ERR_BADARG;
+    const size_t nbytes = (size_t)n * h * w * 3;
+    const size_t blocks = (nbytes + kWG - 1) / kWG;
+    hipLaunchKernelGGL(k_rgb_to_od, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(kWG), 0, (hipStream_t)stream, rgb, nbytes, od_out);
     return launch_status();
 }

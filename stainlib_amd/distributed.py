@@ -12,7 +12,7 @@ The only exchange is small and optional:
     estimates over valid tiles.  Each rank fits its own tiles, the 9 numbers per tile are all-gathered
     (RCCL over xGMI on GPUs, gloo in the CPU tests; latency-bound: 36 B/tile), every rank reduces the
     same gathered table to the same slide statistics, and the apply pass runs locally.
-This is an extension (the reference has no notion of a slide); its oracle is the same recipe on one process.
+This is an extension (the reference has no notion of a slide); its check is the same recipe run on one process.
 """
 from __future__ import annotations
 

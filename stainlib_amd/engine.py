@@ -151,6 +151,31 @@ def hed_augment(rgb, sigma, bias, cutoff=(0.05, 0.95), skimage_mode=0, out=None,
     return out, applied
 
 
+def hed_augment_float(patches, sigma, bias, cutoff=(0.05, 0.95), skimage_mode=0):
+    """Float branch: (N,H,W,3) float64 CUDA tensor in [0,1] -> (out float64, applied)."""
+    if not (patches.is_cuda and patches.dtype == torch.float64 and patches.dim() == 4 and patches.is_contiguous()):
+        raise ValueError("expected a contiguous CUDA float64 tensor of shape (N, H, W, 3)")
+    n, h, w, _ = patches.shape
+    dev = patches.device
+    sigma = _f64(sigma, (n, 3), dev)
+    bias = _f64(bias, (n, 3), dev)
+    out = torch.empty_like(patches)
+    applied = torch.empty((n,), dtype=torch.int32, device=dev)
+    wsb = torch.empty(max(8 * n, 256), dtype=torch.uint8, device=dev)
+    _ffi.check(_ffi.lib().sl_hed_augment_f64(_ptr(patches), _ptr(out), n, h, w, _ptr(sigma), _ptr(bias), float(cutoff[0]),
+                                             float(cutoff[1]), int(skimage_mode), _ptr(applied), _ptr(wsb), wsb.numel(),
+                                             _stream()), "sl_hed_augment_f64")
+    return out, applied
+
+
+def rgb_to_od(rgb):
+    """convert_RGB_to_OD materialised: (N,H,W,3) float64."""
+    n, h, w = _check_tiles(rgb)
+    od = torch.empty((n, h, w, 3), dtype=torch.float64, device=rgb.device)
+    _ffi.check(_ffi.lib().sl_rgb_to_od(_ptr(rgb), n, h, w, _ptr(od), _stream()), "sl_rgb_to_od")
+    return od
+
+
 def stain_augment(rgb, M, alpha_beta, augment_background=False, params=None, out=None):
     """Batched StainAugmentor.pop given per-tile M (N,2,3) and (alpha0,beta0,alpha1,beta1) (N,4)."""
     n, h, w = _check_tiles(rgb)

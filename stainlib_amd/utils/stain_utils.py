@@ -86,3 +86,10 @@ def normalize_matrix_rows(A):
     """stain_utils.py:93-99 (six numbers: host arithmetic)."""
     A = np.asarray(A, dtype=np.float64)
     return A / np.linalg.norm(A, axis=1)[:, None]
+
+
+def convert_RGB_to_OD(I):
+    """stain_utils.py:101-112: max(-ln(max(I,1)/255), 1e-6), float64, same shape (a 256-entry table on the device)."""
+    assert is_uint8_image(I), _UINT8_MSG
+    from .. import engine
+    return engine.rgb_to_od(_to_device(I))[0].cpu().numpy()

@@ -51,6 +51,8 @@ def test_extractor_and_utils():
     assert np.array_equal(su.LuminosityThresholdTissueLocator.get_tissue_mask(I, 0.6), so.tissue_mask(I, 0.6))
     rnd = np.random.RandomState(0).randint(0, 256, (64, 64, 3)).astype(np.uint8)
     assert np.array_equal(su.LuminosityThresholdTissueLocator.get_tissue_mask(rnd), so.tissue_mask(rnd))
+    assert np.array_equal(su.convert_RGB_to_OD(I), so.rgb_to_od(I)) or \
+        np.abs(su.convert_RGB_to_OD(I) - so.rgb_to_od(I)).max() < 1e-15
     C = su.get_concentrations(I, M)
     Co = so.get_concentrations(I, M)
     np.testing.assert_allclose(C, Co, rtol=0, atol=5e-6)
@@ -83,6 +85,12 @@ def test_hed_lighter_vs_reference_golden(path):
     white = np.full((16, 16, 3), 255, np.uint8)
     dark = np.full((16, 16, 3), 3, np.uint8)
     assert a.transform(white) is white and a.transform(dark) is dark     # cutoff: same object back
+    f = I[:32, :32].astype(np.float64) / 255.0                            # float branch (augmenter.py:288-289)
+    of = a.transform(f)
+    assert of.dtype == np.float64
+    np.testing.assert_allclose(of, g["out_float"], rtol=0, atol=1e-12)
+    wf = np.ones((8, 8, 3))
+    assert a.transform(wf) is wf
 
 
 def test_hed_batch_modes_and_ragged():

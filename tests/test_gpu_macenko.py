@@ -187,3 +187,28 @@ def test_fused_equals_multikernel_schedule():
     Mm, mcm, stm = engine.macenko_fit(dev[:8].contiguous())   # 8 tiles -> one launch per phase
     np.testing.assert_allclose(Mf[:8].cpu().numpy(), Mm.cpu().numpy(), rtol=0, atol=1e-12)
     np.testing.assert_allclose(mcf[:8].cpu().numpy(), mcm.cpu().numpy(), rtol=1e-12)
+
+
+def test_full_size_fused_vs_per_phase_schedule_and_oracle():
+    """BASELINE configs[1] tile size (1024x1024): the persistent schedule (>= 64 tiles) and the
+    one-launch-per-phase schedule must agree, and both must match the oracle on a full-size tile."""
+    from stainlib_amd import engine
+    base = [so.synth_tile(1024, 1024, 700 + s) for s in range(3)]
+    dev3 = to_dev(base)
+    big = dev3[torch.arange(66, device="cuda") % 3].contiguous()              # 66 tiles -> fused kernel
+    tgt = so.synth_tile(256, 256, 1001, so.M_TRUE_TGT)
+    Mt, mct = _fit_oracle(tgt)
+    of, Mf, mcf, stf = engine.macenko_transform(big, Mt, mct)
+    om, Mm, mcm, stm = engine.macenko_transform(dev3, Mt, mct)                # 3 tiles -> per-phase kernels
+    assert int(stf.sum()) == 0 and int(stm.sum()) == 0
+    np.testing.assert_allclose(Mf[:3].cpu().numpy(), Mm.cpu().numpy(), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(mcf[:3].cpu().numpy(), mcm.cpu().numpy(), rtol=1e-12)
+    assert torch.equal(of[3:6], of[:3]) and torch.equal(of[63:66], of[:3])     # repeats give identical bytes
+    d = (of[:3].to(torch.int16) - om.to(torch.int16)).abs()
+    assert int(d.max()) <= 1 and float((d != 0).float().mean()) < 1e-5
+    Mo, mco = _fit_oracle(base[0])
+    np.testing.assert_allclose(Mf[0].cpu().numpy(), Mo, rtol=0, atol=M_ATOL)
+    np.testing.assert_allclose(mcf[0].cpu().numpy(), mco, rtol=MAXC_RTOL)
+    n = so.ExtractiveStainNormalizer("macenko")
+    n.stain_matrix_target, n.maxC_target = Mt, mct.reshape(1, 2)
+    u8_parity(of[0].cpu().numpy(), n.transform(base[0]), max_rate=4e-4)
