@@ -174,8 +174,7 @@ static __global__ __launch_bounds__(kWG) void k_stain_augment(const uint8_t* __r
     const int span = (nch + parts - 1) / parts;
     const int c0 = part * span;
     const int c1 = min(nch, c0 + span);
-    for (int c = c0 + tid; c < c1; c += kWG) {
-        const Chunk in = load_chunk<ALIGNED>(src, nbytes, c);
+    auto process = [&](const Chunk& in, int c) {
         uint32_t ob[12];
 #pragma unroll
         for (int px = 0; px < 4; ++px) {
@@ -194,7 +193,17 @@ static __global__ __launch_bounds__(kWG) void k_stain_augment(const uint8_t* __r
         o.w0 = ob[0] | (ob[1] << 8) | (ob[2] << 16) | (ob[3] << 24);
         o.w1 = ob[4] | (ob[5] << 8) | (ob[6] << 16) | (ob[7] << 24);
         o.w2 = ob[8] | (ob[9] << 8) | (ob[10] << 16) | (ob[11] << 24);
-        store_chunk<ALIGNED>(dst, nbytes, c, o);
+        if (c < c1) store_chunk<ALIGNED>(dst, nbytes, c, o);
+    };
+    for (int c = c0 + tid; c < c1; c += kWG * kU) {
+        Chunk in[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int cc = c + u * kWG;
+            in[u] = cc < c1 ? load_chunk<ALIGNED>(src, nbytes, cc) : Chunk{0, 0, 0};
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) process(in[u], c + u * kWG);
     }
 }
 
