@@ -931,6 +931,32 @@ __device__ __forceinline__ void dict_sweep(const uint8_t* src, int P, int c0, in
     }
 }
 
+// the same classification + accumulation over the tile's stratified SAMPLE (tissue entries only): a
+// 1/64-cost stand-in for a full sweep, used to bring D close to its fixed point before touching the tile again
+template <class TABS>
+__device__ __forceinline__ void dict_sweep_sample(const uint32_t* samp, int n_sample, int stride_log2, int P, int t,
+                                                  int nthreads, const TABS& T, const LassoK64& L, ClsAcc (&acc)[3],
+                                                  uint32_t& n_tissue) {
+    for (int b = t; b < n_sample; b += nthreads) {
+        const long long pix = ((long long)b << stride_log2) + sample_offset(b, stride_log2);
+        if (pix >= P) continue;
+        const uint32_t s = samp[b];
+        if (!(s >> 24)) continue;
+        const double ox = T.od64(s & 255u, t), oy = T.od64((s >> 8) & 255u, t), oz = T.od64((s >> 16) & 255u, t);
+        const double a1 = fma(L.wa1[2], oz, fma(L.wa1[1], oy, fma(L.wa1[0], ox, L.ka1)));
+        const double a2 = fma(L.wa2[2], oz, fma(L.wa2[1], oy, fma(L.wa2[0], ox, L.ka2)));
+        const double s1 = fma(L.ws1[2], oz, fma(L.ws1[1], oy, fma(L.ws1[0], ox, L.ks1)));
+        const double s2 = fma(L.ws2[2], oz, fma(L.ws2[1], oy, fma(L.ws2[0], ox, L.ks2)));
+        const bool both = (a1 >= 0.0) & (a2 >= 0.0);
+        const bool only1 = !both & (s1 > 0.0) & (fma(-L.g12, s1, L.g22 * s2) <= 0.0);
+        const bool only2 = !both & !only1 & (s2 > 0.0);
+        n_tissue += 1u;
+        if (both) acc[0].add(ox, oy, oz);
+        if (only1) acc[1].add(ox, oy, oz);
+        if (only2) acc[2].add(ox, oy, oz);
+    }
+}
+
 // A (a11, a12, a22) and B (3x2) of the dictionary update from the class moments m[c] = {n, s(3), q(6)}
 __device__ __forceinline__ void ab_from_class_moments(const double* mom /*[3][10]*/, const double (&D)[2][3], double lam,
                                                       double (&A)[2][2], double (&B)[3][2]) {
@@ -1428,14 +1454,21 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
                 sh.inner_cap = 500;
             }
             __syncthreads();
-            for (int outer = 0; outer < a.dl_max_sweeps; ++outer) {
+            // Schedule: one full sweep (it also drops the sample), then the SAME fixed-point iteration on the
+            // 16 Ki-pixel sample until it settles (each step costs 1/64 of a sweep), then full sweeps from that
+            // warm start until the dictionary moves by less than dl_tol: ~4 full sweeps instead of ~9.
+            int stage = 0;                   // 0: first full sweep, 1: sample iterations, 2: full sweeps
+            int sample_its = 0, outer = 0;   // outer counts steps of the current stage (cycle detector)
+            while (sweeps_used < a.dl_max_sweeps) {
                 LassoK64 Ld;
                 lasso_consts64(sh.D, a.dl_lambda, Ld);
                 uni(Ld);
                 ClsAcc acc[3];
                 uint32_t n_tissue = 0;
-                if (outer == 0)
+                if (stage == 0)
                     dict_sweep<ALIGNED, true>(src, a.P, 0, nch, tid, kFusedThreads, sh.tab, a.y_lim, a.stride_log2, Ld, store, acc, n_tissue);
+                else if (stage == 1)
+                    dict_sweep_sample(samp, a.n_sample, a.stride_log2, a.P, tid, kFusedThreads, sh.tab, Ld, acc, n_tissue);
                 else
                     dict_sweep<ALIGNED, false>(src, a.P, 0, nch, tid, kFusedThreads, sh.tab, a.y_lim, a.stride_log2, Ld, store, acc, n_tissue);
                 double v[31];
@@ -1455,7 +1488,7 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
                 __syncthreads();
                 if (tid == 0) {
                     if (sh.sum[30] < 1.0) {
-                        sh.status = SL_TILE_EMPTY_MASK;
+                        if (stage != 1) sh.status = SL_TILE_EMPTY_MASK;      // (an empty SAMPLE only ends the sample stage)
                         sh.delta = 0.0;
                     } else {
                         double D[2][3];
@@ -1463,10 +1496,9 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
                             for (int k = 0; k < 3; ++k) D[j][k] = sh.D[3 * j + k];
                         const double delta = dict_inner_solve(sh.sum, D, a.dl_lambda, sh.inner_cap);
                         // The frozen-partition solve is a Newton-like step on a piecewise-smooth map and can fall
-                        // into a 2-cycle between two partitions (seen on ~2 % of 1024^2 tiles, amplitude ~1e-4):
-                        // the new iterate then returns to the one before last.  In that case restart from the
-                        // midpoint and shorten the inner solve; at one inner iteration the scheme IS plain
-                        // block-coordinate descent (monotone).
+                        // into a 2-cycle between two partitions: the new iterate then returns to the one before
+                        // last.  In that case restart from the midpoint and shorten the inner solve; at one inner
+                        // iteration the scheme IS plain block-coordinate descent (monotone).
                         double back = 0.0;
                         for (int j = 0; j < 2; ++j)
                             for (int k = 0; k < 3; ++k) back = fmax(back, fabs(D[j][k] - sh.Dprev[3 * j + k]));
@@ -1482,8 +1514,22 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
                     }
                 }
                 __syncthreads();
-                sweeps_used = outer + 1;
-                if (sh.delta < a.dl_tol) break;                               // block-uniform
+                ++outer;
+                if (stage != 1) ++sweeps_used;
+                if (sh.status != SL_TILE_OK) break;                           // block-uniform
+                if (stage == 0) {
+                    stage = 1; outer = 0;
+                } else if (stage == 1) {
+                    ++sample_its;
+                    if (sh.delta < 1e-6 || sample_its >= 40) {                // sample fixed point reached: back to the tile
+                        stage = 2; outer = 0;
+                        __syncthreads();
+                        if (tid == 0) { for (int k = 0; k < 6; ++k) sh.Dprev[k] = 1e300; sh.inner_cap = 500; sh.delta = 1.0; }
+                        __syncthreads();
+                    }
+                } else if (sh.delta < a.dl_tol) {
+                    break;
+                }
             }
             if (tid == 0 && sh.status == SL_TILE_OK) {
                 // H first: swap when D[0,0] < D[1,0] (vahadane_stain_extractor.py:40-41), unit-norm rows (:43)
