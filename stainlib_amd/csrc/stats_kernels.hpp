@@ -86,10 +86,10 @@ struct StatsArgs {
 // [v*R + copy], so the lanes a DS instruction services together hit distinct banks whatever bytes
 // they look up (R = 32: conflict-free ds_read_b32; smaller R trades LDS for a few conflicts).
 // The sweeps are LDS-gather bound with a single 1 KB table (measured), hence the replication.
-struct TabView {                    // copy 0 of the tables, for the finish steps and key functors
-    const float* f; const uint32_t* g; int rf, rg;
-    __device__ __forceinline__ float odf(uint32_t v) const { return f[v * rf]; }
-    __device__ __forceinline__ uint32_t gam(uint32_t v) const { return g[v * rg]; }
+struct TabView {                    // this thread's copy of the tables, for the finish steps and key functors
+    const float* f; const uint32_t* g; int rf, rg, cf, cg;
+    __device__ __forceinline__ float odf(uint32_t v) const { return f[v * rf + cf]; }
+    __device__ __forceinline__ uint32_t gam(uint32_t v) const { return g[v * rg + cg]; }
 };
 template <int RF, int RG, int RD>
 struct Tabs {
@@ -105,7 +105,34 @@ struct Tabs {
     __device__ __forceinline__ float odf(uint32_t v, uint32_t lane) const { return f[v * RF + (lane & (RF - 1))]; }
     __device__ __forceinline__ uint32_t gam(uint32_t v, uint32_t lane) const { return g[v * RG + (lane & (RG - 1))]; }
     __device__ __forceinline__ double od64(uint32_t v, uint32_t lane) const { return d[v * RD + (lane & (RD - 1))]; }
-    __device__ __forceinline__ TabView view() const { return TabView{f, g, RF, RG}; }
+    __device__ __forceinline__ void pair(uint32_t v, uint32_t lane, float& o, uint32_t& gm) const { o = odf(v, lane); gm = gam(v, lane); }
+    __device__ __forceinline__ TabView view() const {
+        return TabView{f, g, RF, RG, (int)(threadIdx.x & (RF - 1)), (int)(threadIdx.x & (RG - 1))};
+    }
+};
+
+// Fused-kernel variant: OD-f32 and gamma interleaved in one 8-byte entry, so the angle sweep gets both with
+// ONE ds_read_b64 per channel (3 LDS instructions + 3 address computations per pixel instead of 6 + 6).
+template <int R, int RD>
+struct TabsFG {
+    struct __attribute__((aligned(8))) FG { float o; uint32_t g; };
+    FG fg[256 * R];
+    double d[257 * RD];                      // entry 256 = 0.0 (masked-out pixel)
+    __device__ __forceinline__ void fill() {
+        for (int i = threadIdx.x; i < 256 * R; i += blockDim.x) { FG e; e.o = d_od_f32[i / R]; e.g = d_gamma[i / R]; fg[i] = e; }
+        for (int i = threadIdx.x; i < 257 * RD; i += blockDim.x) d[i] = i < 256 * RD ? d_od_f64[i / RD] : 0.0;
+    }
+    __device__ __forceinline__ float odf(uint32_t v, uint32_t lane) const { return fg[v * R + (lane & (R - 1))].o; }
+    __device__ __forceinline__ uint32_t gam(uint32_t v, uint32_t lane) const { return fg[v * R + (lane & (R - 1))].g; }
+    __device__ __forceinline__ double od64(uint32_t v, uint32_t lane) const { return d[v * RD + (lane & (RD - 1))]; }
+    __device__ __forceinline__ void pair(uint32_t v, uint32_t lane, float& o, uint32_t& gm) const {
+        const FG e = fg[v * R + (lane & (R - 1))];
+        o = e.o; gm = e.g;
+    }
+    __device__ __forceinline__ TabView view() const {
+        const int c = 2 * (int)(threadIdx.x & (R - 1));
+        return TabView{&fg[0].o, &fg[0].g, 2 * R, 2 * R, c, c};
+    }
 };
 
 // Which pixel of sampling block b is kept (same function in the sweep and in the finish steps).
@@ -622,11 +649,13 @@ __device__ __forceinline__ void select_sweep(const uint8_t* src, int P, int c0, 
                 const int j = u * 4 + px;
                 const uint32_t r = chunk_byte(in[u], 3 * px), g = chunk_byte(in[u], 3 * px + 1),
                                bb = chunk_byte(in[u], 3 * px + 2);
-                const float ox = T.odf(r, t), oy = T.odf(g, t), oz = T.odf(bb, t);
+                float ox, oy, oz;
+                uint32_t gr = 0, gg = 0, gb = 0;
+                if (STAGE == kStageAngle) { T.pair(r, t, ox, gr); T.pair(g, t, oy, gg); T.pair(bb, t, oz, gb); }
+                else { ox = T.odf(r, t); oy = T.odf(g, t); oz = T.odf(bb, t); }
                 const bool inb = live & (ALIGNED | ((size_t)cc * 4 + px < (size_t)P));
                 bool valid, plain;
                 if (STAGE == kStageAngle) {
-                    const uint32_t gr = T.gam(r, t), gg = T.gam(g, t), gb = T.gam(bb, t);
                     valid = inb & is_tissue(gr, gg, gb, y_lim);
                     const float x = fmaf(K.V[4], oz, fmaf(K.V[2], oy, K.V[0] * ox));
                     const float y = fmaf(K.V[5], oz, fmaf(K.V[3], oy, K.V[1] * ox));
@@ -1305,7 +1334,7 @@ struct FusedArgs {
 };
 
 struct FusedShared {
-    Tabs<32, 16, 4> tab;     // 32 + 16 + 8 KB
+    TabsFG<16, 4> tab;       // 32 + 8 KB
     uint32_t stage[kFusedThreads / 64][kStageWave];     // 16 KB
     unsigned int n_plain, n_raw, overflow;
     SelScratch S;
