@@ -17,7 +17,7 @@ constexpr int kFusedMinTiles = 64;          // from this batch size on, one work
 constexpr int kFusedMaxGrid = 512;          // 2 resident 1024-thread workgroups per CU x 256 CUs
 
 struct Layout {
-    int parts, stride_log2, n_sample, G;
+    int parts, stride_log2, n_sample, G, cap_raw, cap_list;
     bool fused;
     int grid;                               // fused: workgroups launched
     size_t off_M, off_maxC, off_status, off_partials, off_sample, off_cand, off_list, off_state, off_diag, total;
@@ -47,8 +47,11 @@ Layout make_layout(int n, long P, bool force_fused = false) {
     L.off_diag = o;     o = align_up(o + sizeof(int32_t) * (size_t)n);
     L.off_partials = o; o = align_up(o + sizeof(double) * 10 * (size_t)L.parts * L.G);
     L.off_sample = o;   o = align_up(o + sizeof(uint32_t) * (size_t)L.n_sample * slots);
-    L.off_cand = o;     o = align_up(o + sizeof(uint32_t) * (size_t)kCapRaw * slots);
-    L.off_list = o;     o = align_up(o + sizeof(float) * 2 * (size_t)kCapList * slots);
+    // list capacities scale with the tile: ~3 % of the pixels are raw candidates, ~1 % end up in a bracket
+    L.cap_raw = (int)(P / 12 > kMinCapRaw ? P / 12 : kMinCapRaw);
+    L.cap_list = (int)(P / 40 > kMinCapList ? P / 40 : kMinCapList);
+    L.off_cand = o;     o = align_up(o + sizeof(uint32_t) * (size_t)L.cap_raw * slots);
+    L.off_list = o;     o = align_up(o + sizeof(float) * 2 * (size_t)L.cap_list * slots);
     L.off_state = o;    o = align_up(o + sizeof(TileState) * (size_t)L.G);
     L.total = o;
     return L;
@@ -68,6 +71,8 @@ int run_stats_group(const uint8_t* rgb, int g0, int m, long P, const SlParams& p
     a.pct = p.angular_percentile;
     a.partials = (double*)(ws + L.off_partials);
     a.sample = (uint32_t*)(ws + L.off_sample);
+    a.cap_raw = L.cap_raw;
+    a.cap_list = L.cap_list;
     a.raw = (uint32_t*)(ws + L.off_cand);
     a.cand = (float*)(ws + L.off_list);
     a.state = (TileState*)(ws + L.off_state);
@@ -116,6 +121,8 @@ int run_fused(int method, const uint8_t* rgb, uint8_t* out, int n, long P, const
     a.pct = p.angular_percentile;
     a.M_tgt = M_tgt;
     a.maxC_tgt = maxC_tgt;
+    a.cap_raw = L.cap_raw;
+    a.cap_list = L.cap_list;
     a.raw = (uint32_t*)(ws + L.off_cand);
     a.cand = (float*)(ws + L.off_list);
     a.sample = (uint32_t*)(ws + L.off_sample);

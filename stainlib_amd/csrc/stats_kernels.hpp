@@ -39,8 +39,8 @@
 namespace sl {
 
 constexpr int kMaxSample = 16384;   // samples per tile (<= P/64)
-constexpr int kCapRaw = 65536;      // raw-pixel candidate capacity per tile and selection stage
-constexpr int kCapList = 16384;     // exact-key bracket members per list after the refine pass
+constexpr int kMinCapRaw = 65536;   // raw-pixel candidate capacity per tile and stage: max(this, P/12), set by the host
+constexpr int kMinCapList = 16384;  // exact-key bracket members per list after the refine pass: max(this, P/40)
 constexpr int kFinishThreads = 1024;
 constexpr int kFusedThreads = 512;  // 2 resident workgroups per CU (<=128 VGPRs, <80 KB LDS each)
 constexpr int kStageWave = 256;     // per-wave LDS staging entries for raw candidates (8 KB per 8 waves)
@@ -54,7 +54,7 @@ struct TileState {
     float Vf[6];
     float lo[2], hi[2];      // brackets of the current selection stage
     unsigned int n_plain;    // pixels the sweep classified without collecting them
-    unsigned int n_raw;      // raw candidates appended (may exceed kCapRaw => overflow)
+    unsigned int n_raw;      // raw candidates appended (may exceed cap_raw => overflow)
     unsigned int overflow;   // a wave's staging buffer overflowed: the collected list is incomplete
     unsigned int pad_;
     // ---- after finish 2
@@ -76,8 +76,9 @@ struct StatsArgs {
     double pct;              // angular percentile
     double* partials;        // [tile][part][10]          (multi-kernel)
     uint32_t* sample;        // [tile][n_sample]          (multi-kernel)
-    uint32_t* raw;           // [tile or workgroup][kCapRaw] raw candidate pixels (r | g<<8 | b<<16)
-    float* cand;             // [tile or workgroup][2][kCapList] bracket members (exact keys)
+    int cap_raw, cap_list;   // capacities of the two lists below (scale with the tile size)
+    uint32_t* raw;           // [tile][cap_raw] raw candidate pixels (r | g<<8 | b<<16)
+    float* cand;             // [tile][2][cap_list] bracket members (exact keys)
     TileState* state;        // [tile]                    (multi-kernel)
 };
 
@@ -739,11 +740,12 @@ struct CandKey {
 };
 
 // One pass over the raw candidates of a stage: exact key(s) of every raw pixel, #keys below each
-// bracket, and the bracket members written compactly to cand[li][...] (<= kCapList each).
+// bracket, and the bracket members written compactly to cand[li][...] (<= cap_list each).
 // key2(i, k0, k1) yields both keys of raw entry i.
 template <class Key2>
 __device__ __forceinline__ void wg_refine(int n_raw, const Key2& key2, const float* lo, const float* hi, float* cand0,
-                                          float* cand1, uint32_t* n_lt /*[2]*/, uint32_t* n_in /*[2]*/, SelScratch& S) {
+                                          float* cand1, uint32_t cap_list, uint32_t* n_lt /*[2]*/, uint32_t* n_in /*[2]*/,
+                                          SelScratch& S) {
     if (threadIdx.x < 4) S.misc[12 + threadIdx.x] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -762,14 +764,14 @@ __device__ __forceinline__ void wg_refine(int n_raw, const Key2& key2, const flo
             if (lane == 0) base = atomicAdd(&S.misc[14], (uint32_t)__popcll(m0));
             base = __builtin_amdgcn_readfirstlane(base);
             const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0));
-            if (in0 && pos < (uint32_t)kCapList) cand0[pos] = k0;
+            if (in0 && pos < cap_list) cand0[pos] = k0;
         }
         if (m1) {
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(&S.misc[15], (uint32_t)__popcll(m1));
             base = __builtin_amdgcn_readfirstlane(base);
             const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0));
-            if (in1 && pos < (uint32_t)kCapList) cand1[pos] = k1;
+            if (in1 && pos < cap_list) cand1[pos] = k1;
         }
     }
     for (int o = 32; o > 0; o >>= 1) { lt0 += __shfl_xor((int)lt0, o, 64); lt1 += __shfl_xor((int)lt1, o, 64); }
@@ -784,14 +786,14 @@ __device__ __forceinline__ void wg_refine(int n_raw, const Key2& key2, const flo
 // lt = pixels proven or found below the bracket, n_in = members collected in cand[].  Falls back to
 // exact selection over the whole tile when the bracket missed or a list was incomplete.
 template <class TileKeyAt>
-__device__ __forceinline__ void stage_order_stats(const float* cand, uint32_t n_in, bool complete, float lo, float hi,
+__device__ __forceinline__ void stage_order_stats(const float* cand, uint32_t n_in, uint32_t cap_list, bool complete, float lo, float hi,
                                                   long long lt, int P, const TileKeyAt& tile_key_at, uint32_t n,
                                                   long long k, float& xa, float& xb, int& fallbacks, SelScratch& S) {
     const long long k2 = (k + 1 < (long long)n) ? k + 1 : k;
     const bool covered = complete && k >= lt && k2 < lt + (long long)n_in;
     if (covered && lo == hi) {
         xa = xb = lo;                                  // every member of the bracket equals lo
-    } else if (covered && n_in <= (uint32_t)kCapList) {
+    } else if (covered && n_in <= cap_list) {
         wg_select_pair_small((int)n_in, CandKey{cand}, (uint32_t)(k - lt), xa, xb, S);
         if (k2 == k) xb = xa;
     } else {                                           // exact, slow, rare
@@ -821,13 +823,14 @@ struct RawSink {
     uint32_t* dst;              // global raw list of the tile
     unsigned int* head;         // list head (LDS in the fused kernel, global otherwise)
     unsigned int* overflow;     // set when entries were lost (list incomplete => exact slow path)
+    uint32_t cap;               // capacity of dst
     __device__ __forceinline__ void flush(int lane) {
         if (n == 0) return;
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(head, n);
         base = __builtin_amdgcn_readfirstlane(base);
         for (uint32_t i = lane; i < n; i += 64)
-            if (base + i < (uint32_t)kCapRaw) dst[base + i] = buf[i];
+            if (base + i < cap) dst[base + i] = buf[i];
         n = 0;
     }
     __device__ __forceinline__ void commit(const bool (&f)[8], const uint32_t (&raw)[8], int lane) {
@@ -1179,7 +1182,7 @@ static __global__ __launch_bounds__(kWG) void k_select(StatsArgs a) {
     const int nch = (a.P + 3) >> 2;
     const int span = (nch + a.parts - 1) / a.parts;
     const int c0 = part * span, c1 = min(nch, c0 + span);
-    RawSink sink{s_stage[wave], 0u, a.raw + (size_t)tile * kCapRaw, &st.n_raw, &st.overflow};
+    RawSink sink{s_stage[wave], 0u, a.raw + (size_t)tile * a.cap_raw, &st.n_raw, &st.overflow, (uint32_t)a.cap_raw};
     uint32_t n_plain = 0;
     select_sweep<STAGE, ALIGNED>(src, a.P, c0, c1, tid, kWG, s_tab, a.y_lim, K, sink, n_plain);
     sink.flush(lane);
@@ -1204,25 +1207,25 @@ static __global__ __launch_bounds__(kFinishThreads) void k_finish_angle(StatsArg
     AngleTileKey tkey;
     tkey.src = src; tkey.tab = s_tab.view(); tkey.y_lim = a.y_lim;
     RawAngleKey2 rkey;
-    rkey.raw = a.raw + (size_t)tile * kCapRaw; rkey.tab = s_tab.view();
+    rkey.raw = a.raw + (size_t)tile * a.cap_raw; rkey.tab = s_tab.view();
     for (int i = 0; i < 6; ++i) { tkey.V[i] = st.Vf[i]; rkey.V[i] = st.Vf[i]; }
     const uint32_t T = (uint32_t)st.n_tissue;
     long long k[2];
     double gfrac[2];
     percentile_pos((double)T, 100.0 - a.pct, k[0], gfrac[0]);
     percentile_pos((double)T, a.pct, k[1], gfrac[1]);
-    const bool complete = st.n_raw <= (uint32_t)kCapRaw && st.overflow == 0;
-    const uint32_t n_raw = st.n_raw < (uint32_t)kCapRaw ? st.n_raw : (uint32_t)kCapRaw;
-    float* cand0 = a.cand + ((size_t)tile * 2 + 0) * kCapList;
-    float* cand1 = a.cand + ((size_t)tile * 2 + 1) * kCapList;
+    const bool complete = st.n_raw <= (uint32_t)a.cap_raw && st.overflow == 0;
+    const uint32_t n_raw = st.n_raw < (uint32_t)a.cap_raw ? st.n_raw : (uint32_t)a.cap_raw;
+    float* cand0 = a.cand + ((size_t)tile * 2 + 0) * a.cap_list;
+    float* cand1 = a.cand + ((size_t)tile * 2 + 1) * a.cap_list;
     const float los[2] = {st.lo[0], st.lo[1]}, his[2] = {st.hi[0], st.hi[1]};
     uint32_t n_lt[2], n_in[2];
-    wg_refine((int)n_raw, rkey, los, his, cand0, cand1, n_lt, n_in, S);
+    wg_refine((int)n_raw, rkey, los, his, cand0, cand1, (uint32_t)a.cap_list, n_lt, n_in, S);
     const long long base[2] = {0, (long long)st.n_plain};        // plain pixels sit between the two brackets
     int fallbacks = 0;
     for (int li = 0; li < 2; ++li) {
         float xa, xb;
-        stage_order_stats(li ? cand1 : cand0, n_in[li], complete, los[li], his[li], base[li] + n_lt[li], a.P, tkey, T,
+        stage_order_stats(li ? cand1 : cand0, n_in[li], (uint32_t)a.cap_list, complete, los[li], his[li], base[li] + n_lt[li], a.P, tkey, T,
                           k[li], xa, xb, fallbacks, S);
         if (tid == 0) { s_res[2 * li] = xa; s_res[2 * li + 1] = xb; }
         __syncthreads();
@@ -1272,18 +1275,18 @@ static __global__ __launch_bounds__(kFinishThreads) void k_finish_conc(StatsArgs
         tkey.tab = s_tab.view();
         tkey.L = s_L;
         RawConcKey2 rkey;
-        rkey.raw = a.raw + (size_t)tile * kCapRaw; rkey.tab = s_tab.view(); rkey.L = s_L;
-        const bool complete = st.n_raw <= (uint32_t)kCapRaw && st.overflow == 0;
-        const uint32_t n_raw = st.n_raw < (uint32_t)kCapRaw ? st.n_raw : (uint32_t)kCapRaw;
-        float* cand0 = a.cand + ((size_t)tile * 2 + 0) * kCapList;
-        float* cand1 = a.cand + ((size_t)tile * 2 + 1) * kCapList;
+        rkey.raw = a.raw + (size_t)tile * a.cap_raw; rkey.tab = s_tab.view(); rkey.L = s_L;
+        const bool complete = st.n_raw <= (uint32_t)a.cap_raw && st.overflow == 0;
+        const uint32_t n_raw = st.n_raw < (uint32_t)a.cap_raw ? st.n_raw : (uint32_t)a.cap_raw;
+        float* cand0 = a.cand + ((size_t)tile * 2 + 0) * a.cap_list;
+        float* cand1 = a.cand + ((size_t)tile * 2 + 1) * a.cap_list;
         const float los[2] = {st.lo[0], st.lo[1]}, his[2] = {st.hi[0], st.hi[1]};
         uint32_t n_lt[2], n_in[2];
-        wg_refine((int)n_raw, rkey, los, his, cand0, cand1, n_lt, n_in, S);
+        wg_refine((int)n_raw, rkey, los, his, cand0, cand1, (uint32_t)a.cap_list, n_lt, n_in, S);
         for (int col = 0; col < 2; ++col) {
             tkey.col = col;
             float xa, xb;
-            stage_order_stats(col ? cand1 : cand0, n_in[col], complete, los[col], his[col], (long long)st.n_plain + n_lt[col],
+            stage_order_stats(col ? cand1 : cand0, n_in[col], (uint32_t)a.cap_list, complete, los[col], his[col], (long long)st.n_plain + n_lt[col],
                               a.P, tkey, (uint32_t)a.P, k, xa, xb, fallbacks, S);
             if (tid == 0) { s_res[2 * col] = xa; s_res[2 * col + 1] = xb; }
             __syncthreads();
@@ -1318,8 +1321,9 @@ struct FusedArgs {
     double pct;
     const double* M_tgt;     // transform only
     const double* maxC_tgt;  // transform only
-    uint32_t* raw;           // [gridDim.x][kCapRaw]
-    float* cand;             // [gridDim.x][2][kCapList]
+    int cap_raw, cap_list;
+    uint32_t* raw;           // [gridDim.x][cap_raw]
+    float* cand;             // [gridDim.x][2][cap_list]
     uint32_t* sample;        // [gridDim.x][n_sample]
     double* M_out;           // [n_tiles][6]
     double* maxC_out;        // [n_tiles][2]
@@ -1364,15 +1368,15 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
     __syncthreads();
     const int nch = (a.P + 3) >> 2;
     uint32_t* samp = a.sample + (size_t)blockIdx.x * a.n_sample;
-    uint32_t* rawl = a.raw + (size_t)blockIdx.x * kCapRaw;
-    float* cand0 = a.cand + ((size_t)blockIdx.x * 2 + 0) * kCapList;
-    float* cand1 = a.cand + ((size_t)blockIdx.x * 2 + 1) * kCapList;
+    uint32_t* rawl = a.raw + (size_t)blockIdx.x * a.cap_raw;
+    float* cand0 = a.cand + ((size_t)blockIdx.x * 2 + 0) * a.cap_list;
+    float* cand1 = a.cand + ((size_t)blockIdx.x * 2 + 1) * a.cap_list;
 
     // sweeps 2/3 share this: classify against sh.lo/hi with constants K; plain count and raw candidates into sh.*
     auto run_select = [&](auto stage_tag, const uint8_t* src, SelConsts& K) {
         constexpr int STAGE = decltype(stage_tag)::value;
         K.lo0 = uni(sh.lo[0]); K.hi0 = uni(sh.hi[0]); K.lo1 = uni(sh.lo[1]); K.hi1 = uni(sh.hi[1]);
-        RawSink sink{sh.stage[wave], 0u, rawl, &sh.n_raw, &sh.overflow};
+        RawSink sink{sh.stage[wave], 0u, rawl, &sh.n_raw, &sh.overflow, (uint32_t)a.cap_raw};
         uint32_t n_plain = 0;
         select_sweep<STAGE, ALIGNED>(src, a.P, 0, nch, tid, kFusedThreads, sh.tab, a.y_lim, K, sink, n_plain);
         sink.flush(lane);
@@ -1450,15 +1454,15 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
                 RawAngleKey2 rkey;
                 rkey.raw = rawl; rkey.tab = sh.tab.view();
                 for (int i = 0; i < 6; ++i) { tkey.V[i] = sh.Vf[i]; rkey.V[i] = sh.Vf[i]; }
-                const bool complete = sh.n_raw <= (uint32_t)kCapRaw && sh.overflow == 0;
-                const uint32_t n_raw = sh.n_raw < (uint32_t)kCapRaw ? sh.n_raw : (uint32_t)kCapRaw;
+                const bool complete = sh.n_raw <= (uint32_t)a.cap_raw && sh.overflow == 0;
+                const uint32_t n_raw = sh.n_raw < (uint32_t)a.cap_raw ? sh.n_raw : (uint32_t)a.cap_raw;
                 const float los[2] = {sh.lo[0], sh.lo[1]}, his[2] = {sh.hi[0], sh.hi[1]};
                 const long long base[2] = {0, (long long)sh.n_plain};
                 uint32_t n_lt[2], n_in[2];
-                wg_refine((int)n_raw, rkey, los, his, cand0, cand1, n_lt, n_in, sh.S);
+                wg_refine((int)n_raw, rkey, los, his, cand0, cand1, (uint32_t)a.cap_list, n_lt, n_in, sh.S);
                 for (int li = 0; li < 2; ++li) {
                     float xa, xb;
-                    stage_order_stats(li ? cand1 : cand0, n_in[li], complete, los[li], his[li], base[li] + n_lt[li], a.P, tkey,
+                    stage_order_stats(li ? cand1 : cand0, n_in[li], (uint32_t)a.cap_list, complete, los[li], his[li], base[li] + n_lt[li], a.P, tkey,
                                       T, k[li], xa, xb, fallbacks, sh.S);
                     if (tid == 0) { sh.res[2 * li] = xa; sh.res[2 * li + 1] = xb; }
                     __syncthreads();
@@ -1607,16 +1611,16 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
                 tkey.src = src; tkey.tab = sh.tab.view(); tkey.L = sh.L;
                 RawConcKey2 rkey;
                 rkey.raw = rawl; rkey.tab = sh.tab.view(); rkey.L = sh.L;
-                const bool complete = sh.n_raw <= (uint32_t)kCapRaw && sh.overflow == 0;
-                const uint32_t n_raw = sh.n_raw < (uint32_t)kCapRaw ? sh.n_raw : (uint32_t)kCapRaw;
+                const bool complete = sh.n_raw <= (uint32_t)a.cap_raw && sh.overflow == 0;
+                const uint32_t n_raw = sh.n_raw < (uint32_t)a.cap_raw ? sh.n_raw : (uint32_t)a.cap_raw;
                 const float los[2] = {sh.lo[0], sh.lo[1]}, his[2] = {sh.hi[0], sh.hi[1]};
                 const long long n_plain = sh.n_plain;
                 uint32_t n_lt[2], n_in[2];
-                wg_refine((int)n_raw, rkey, los, his, cand0, cand1, n_lt, n_in, sh.S);
+                wg_refine((int)n_raw, rkey, los, his, cand0, cand1, (uint32_t)a.cap_list, n_lt, n_in, sh.S);
                 for (int col = 0; col < 2; ++col) {
                     tkey.col = col;
                     float xa, xb;
-                    stage_order_stats(col ? cand1 : cand0, n_in[col], complete, los[col], his[col], n_plain + n_lt[col], a.P,
+                    stage_order_stats(col ? cand1 : cand0, n_in[col], (uint32_t)a.cap_list, complete, los[col], his[col], n_plain + n_lt[col], a.P,
                                       tkey, (uint32_t)a.P, k, xa, xb, fallbacks, sh.S);
                     if (tid == 0) { sh.res[2 * col] = xa; sh.res[2 * col + 1] = xb; }
                     __syncthreads();

@@ -212,3 +212,14 @@ def test_full_size_fused_vs_per_phase_schedule_and_oracle():
     n = so.ExtractiveStainNormalizer("macenko")
     n.stain_matrix_target, n.maxC_target = Mt, mct.reshape(1, 2)
     u8_parity(of[0].cpu().numpy(), n.transform(base[0]), max_rate=4e-4)
+
+
+def test_multi_megapixel_tile():
+    """Tiles larger than 1024^2: sample stride and list capacities scale with the tile."""
+    from stainlib_amd import engine
+    I = so.synth_tile(1536, 2048, 77)
+    M, mc, st = engine.macenko_fit(to_dev([I]))
+    assert int(st[0]) == 0
+    Mo, mco = _fit_oracle(I)
+    np.testing.assert_allclose(M.cpu().numpy()[0], Mo, rtol=0, atol=M_ATOL)
+    np.testing.assert_allclose(mc.cpu().numpy()[0], mco, rtol=MAXC_RTOL)
