@@ -37,7 +37,7 @@ class SlParams(C.Structure):
         ("lasso_lambda", C.c_double),
         ("dl_lambda", C.c_double),
         ("dl_max_sweeps", C.c_int32),
-        ("reserved", C.c_int32),
+        ("schedule", C.c_int32),
         ("dl_tol", C.c_double),
         ("profile", C.POINTER(SlProfile)),
     ]

@@ -13,7 +13,7 @@ namespace {
 
 constexpr size_t kGroupBytes = 96u << 20;   // uint8 bytes of one tile group (fits the 256 MiB MALL with output + slack)
 
-constexpr int kFusedMinTiles = 64;          // from this batch size on, one workgroup per tile fills the chip better
+constexpr int kFusedMinTiles = 160;         // measured crossover (tools/crossover.py): below it one launch per phase wins
 constexpr int kFusedMaxGrid = 512;          // 2 resident 1024-thread workgroups per CU x 256 CUs
 
 struct Layout {
@@ -25,7 +25,7 @@ struct Layout {
 
 size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
-Layout make_layout(int n, long P, bool force_fused = false) {
+Layout make_layout(int n, long P, bool force_fused = false, int schedule = 0) {
     Layout L;
     L.parts = parts_for(P);
     L.stride_log2 = 6;
@@ -37,7 +37,7 @@ Layout make_layout(int n, long P, bool force_fused = false) {
     if (g > n) g = n;
     if (g < 1) g = 1;
     L.G = (int)g;
-    L.fused = force_fused || n >= kFusedMinTiles;
+    L.fused = force_fused || (schedule == 2) || (schedule != 1 && n >= kFusedMinTiles);
     L.grid = n < kFusedMaxGrid ? n : kFusedMaxGrid;
     const size_t slots = L.fused ? (size_t)L.grid : (size_t)L.G;     // candidate buffers: per workgroup / per tile of a group
     size_t o = 0;
@@ -165,7 +165,10 @@ extern "C" size_t sl_workspace_bytes(int op, int n_tiles, int h, int w) {
     switch (op) {
         case SL_OP_MACENKO_FIT:
         case SL_OP_MACENKO_TRANSFORM:
-            return make_layout(n_tiles, (long)h * w).total;
+        {   // SlParams.schedule may force either schedule: size for the larger of the two
+            const size_t a = make_layout(n_tiles, (long)h * w, false, 1).total, b = make_layout(n_tiles, (long)h * w, false, 2).total;
+            return a > b ? a : b;
+        }
         case SL_OP_VAHADANE_FIT:
         case SL_OP_VAHADANE_TRANSFORM:
             return make_layout(n_tiles, (long)h * w, true).total;
@@ -180,7 +183,7 @@ extern "C" int sl_macenko_fit(const uint8_t* rgb, int n, int h, int w, const SlP
                               double* maxC_out, int32_t* status, void* workspace, size_t workspace_bytes,
                               void* stream) {
     const long P = (long)h * w;
-    const Layout L = (n > 0 && h > 0 && w > 0) ? make_layout(n, P) : Layout{};
+    const Layout L = (n > 0 && h > 0 && w > 0) ? make_layout(n, P, false, params ? params->schedule : 0) : Layout{};
     int rc = check_common(rgb, n, h, w, workspace, workspace_bytes, L.total);
     if (rc) return rc;
     SlParams p;
@@ -206,7 +209,7 @@ extern "C" int sl_macenko_transform(const uint8_t* rgb, uint8_t* out, int n, int
                                     double* maxC_src_out, int32_t* status, void* workspace, size_t workspace_bytes,
                                     void* stream) {
     const long P = (long)h * w;
-    const Layout L = (n > 0 && h > 0 && w > 0) ? make_layout(n, P) : Layout{};
+    const Layout L = (n > 0 && h > 0 && w > 0) ? make_layout(n, P, false, params ? params->schedule : 0) : Layout{};
     int rc = check_common(rgb, n, h, w, workspace, workspace_bytes, L.total);
     if (rc) return rc;
     if (!out || !M_tgt || !maxC_tgt) return SL_ERR_BADARG;

@@ -144,7 +144,9 @@ def test_params_are_honoured():
     np.testing.assert_allclose(M.cpu().numpy()[0], Mo, rtol=0, atol=M_ATOL)
 
 
-# ---- the persistent one-workgroup-per-tile schedule kicks in from 64 tiles ---------------------
+# ---- the persistent one-workgroup-per-tile schedule (automatic from 160 tiles; forced here) ----
+FUSED = dict(schedule=2)
+PHASED = dict(schedule=1)
 def _fused_batch(h, w, n=66):
     tiles = [so.synth_tile(h, w, 100 + s) for s in range(n)]
     tiles[5] = np.full((h, w, 3), 255, np.uint8)                       # empty mask
@@ -161,8 +163,8 @@ def test_fused_schedule_vs_oracle(h, w):
     tgt = so.synth_tile(128, 128, 1001, so.M_TRUE_TGT)
     Mt, mct = _fit_oracle(tgt)
     dev = to_dev(tiles)
-    M, mc, st = engine.macenko_fit(dev)
-    out, M2, mc2, st2 = engine.macenko_transform(dev, Mt, mct)
+    M, mc, st = engine.macenko_fit(dev, params=engine.make_params(**FUSED))
+    out, M2, mc2, st2 = engine.macenko_transform(dev, Mt, mct, params=engine.make_params(**FUSED))
     assert torch.equal(st, st2) and torch.equal(M[st == 0], M2[st2 == 0]) and torch.equal(mc[st == 0], mc2[st2 == 0])
     M, mc, st, out = M.cpu().numpy(), mc.cpu().numpy(), st.cpu().numpy(), out.cpu().numpy()
     assert st[5] == 1 and np.array_equal(out[5], tiles[5])
@@ -183,8 +185,8 @@ def test_fused_equals_multikernel_schedule():
     from stainlib_amd import engine
     tiles = [so.synth_tile(128, 128, 300 + s) for s in range(64)]
     dev = to_dev(tiles)
-    Mf, mcf, stf = engine.macenko_fit(dev)                    # 64 tiles -> fused
-    Mm, mcm, stm = engine.macenko_fit(dev[:8].contiguous())   # 8 tiles -> one launch per phase
+    Mf, mcf, stf = engine.macenko_fit(dev, params=engine.make_params(**FUSED))
+    Mm, mcm, stm = engine.macenko_fit(dev[:8].contiguous(), params=engine.make_params(**PHASED))
     np.testing.assert_allclose(Mf[:8].cpu().numpy(), Mm.cpu().numpy(), rtol=0, atol=1e-12)
     np.testing.assert_allclose(mcf[:8].cpu().numpy(), mcm.cpu().numpy(), rtol=1e-12)
 
@@ -198,8 +200,8 @@ def test_full_size_fused_vs_per_phase_schedule_and_oracle():
     big = dev3[torch.arange(66, device="cuda") % 3].contiguous()              # 66 tiles -> fused kernel
     tgt = so.synth_tile(256, 256, 1001, so.M_TRUE_TGT)
     Mt, mct = _fit_oracle(tgt)
-    of, Mf, mcf, stf = engine.macenko_transform(big, Mt, mct)
-    om, Mm, mcm, stm = engine.macenko_transform(dev3, Mt, mct)                # 3 tiles -> per-phase kernels
+    of, Mf, mcf, stf = engine.macenko_transform(big, Mt, mct, params=engine.make_params(**FUSED))
+    om, Mm, mcm, stm = engine.macenko_transform(dev3, Mt, mct, params=engine.make_params(**PHASED))
     assert int(stf.sum()) == 0 and int(stm.sum()) == 0
     np.testing.assert_allclose(Mf[:3].cpu().numpy(), Mm.cpu().numpy(), rtol=0, atol=1e-12)
     np.testing.assert_allclose(mcf[:3].cpu().numpy(), mcm.cpu().numpy(), rtol=1e-12)
