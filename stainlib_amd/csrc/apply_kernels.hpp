@@ -8,6 +8,7 @@
 // Roofline: HBM.  Algorithmic traffic of k_apply is 3 B read + 3 B written per pixel.
 #pragma once
 #include "sl_device.hpp"
+#include <type_traits>
 
 namespace sl {
 
@@ -16,12 +17,25 @@ __device__ __forceinline__ Chunk load_chunk(const uint8_t* tile, size_t nbytes, 
     if (ALIGNED) {
         return reinterpret_cast<const Chunk*>(tile)[c];
     } else {
+        // ragged tail: clamped addresses instead of predicated loads (no divergent control flow in the sweeps);
+        // bytes past the tile read as the last byte and are never used (callers test the pixel index)
         uint32_t w[3] = {0, 0, 0};
-        const size_t base = (size_t)c * 12;
-        for (int i = 0; i < 12; ++i)
-            if (base + i < nbytes) w[i >> 2] |= (uint32_t)tile[base + i] << (8 * (i & 3));
+        const size_t base = (size_t)c * 12, lastb = nbytes - 1;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const size_t at = base + i < lastb ? base + i : lastb;
+            w[i >> 2] |= (uint32_t)tile[at] << (8 * (i & 3));
+        }
         return Chunk{w[0], w[1], w[2]};
     }
+}
+
+// Chunk c of [.., c1) for a sweep lane: lanes past the end re-read the last chunk (always a valid address, so the
+// load needs no predicate and the sweep body stays free of divergent regions); they mask their results with
+// `c < c1` themselves.  Requires c1 >= 1.
+template <bool ALIGNED>
+__device__ __forceinline__ Chunk load_chunk_clamped(const uint8_t* tile, size_t nbytes, int c, int c1) {
+    return load_chunk<ALIGNED>(tile, nbytes, c < c1 ? c : c1 - 1);
 }
 
 template <bool ALIGNED>
@@ -54,6 +68,87 @@ __device__ __forceinline__ void recon_px(const ReconK& R, float c1, float c2, fl
 // Truncating cast of normalizer.py:50 (`astype(np.uint8)`): toward zero, then modulo 256.
 __device__ __forceinline__ uint32_t trunc_u8(float t) { return ((uint32_t)t) & 0xffu; }
 
+// ---- the normalisation step shared by k_apply and sweep 4 of the fused kernel (bit-identical by construction) ----
+struct ApplyK {
+    LassoK L;            // source stain matrix; affine parts VGPR-resident
+    float q[2][3];       // -log2(e) * (maxC_tgt_i / maxC_src_i) * M_tgt[i][c], VGPR-resident
+    bool fast;           // wave-uniform: g12 >= 0 and every q <= 0, i.e. 0 <= 255*2^e <= 255 for every pixel
+};
+
+__device__ __forceinline__ void apply_consts(const double* M_src, const double* maxC_src, const double* M_tgt,
+                                             const double* maxC_tgt, double lam, ApplyK& K) {
+    lasso_consts(M_src, lam, K.L);
+    bool nonpos = true;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const double ratio = maxC_tgt[i] / maxC_src[i];                          // normalizer.py:48
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float q = (float)(-1.4426950408889634 * ratio * M_tgt[3 * i + c]);
+            nonpos = nonpos & (q <= 0.0f);
+            K.q[i][c] = in_vgpr(uni(q));
+        }
+    }
+    K.fast = (bool)__builtin_amdgcn_readfirstlane((int)(nonpos & (K.L.g12 >= 0.0f)));
+    vgpr(K.L);
+}
+
+// 255 * exp(-C @ M_tgt) of one pixel, before the cast
+template <bool FAST>
+__device__ __forceinline__ void apply_px(const ApplyK& K, float x, float y, float z, float (&t)[3]) {
+    float c1, c2;
+    if (FAST) {                                    // g12 >= 0: branch-free lasso (see lasso2)
+        float a1, a2;
+        lasso_interior(K.L, x, y, z, a1, a2);
+        const float s1 = fmaf(K.L.ws1[2], z, fmaf(K.L.ws1[1], y, fmaf(K.L.ws1[0], x, K.L.ks1)));
+        const float s2 = fmaf(K.L.ws2[2], z, fmaf(K.L.ws2[1], y, fmaf(K.L.ws2[0], x, K.L.ks2)));
+        c1 = fmaxf(fminf(a1, s1), 0.0f);
+        c2 = fmaxf(fminf(a2, s2), 0.0f);
+    } else {
+        lasso2(K.L, x, y, z, c1, c2);
+    }
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) t[ch] = 255.0f * __builtin_amdgcn_exp2f(fmaf(c1, K.q[0][ch], c2 * K.q[1][ch]));
+}
+
+// The truncating cast of normalizer.py:50 for 12 values in [0, 255] -> one chunk.  v_cvt_pk_u8_f32 converts,
+// saturates and inserts the byte in one instruction but rounds per MODE.fp_round, so the block switches the
+// binary32 rounding mode to toward-zero around the 12 conversions (measured: tools/ubench_issue.hip).
+__device__ __forceinline__ Chunk pack_trunc_fast(const float (&t)[12]) {
+    Chunk o;
+    asm volatile(
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+        "s_nop 0\n\t"
+        "v_cvt_pk_u8_f32 %0, %3, 0, 0\n\t"
+        "v_cvt_pk_u8_f32 %1, %7, 0, 0\n\t"
+        "v_cvt_pk_u8_f32 %2, %11, 0, 0\n\t"
+        "v_cvt_pk_u8_f32 %0, %4, 1, %0\n\t"
+        "v_cvt_pk_u8_f32 %1, %8, 1, %1\n\t"
+        "v_cvt_pk_u8_f32 %2, %12, 1, %2\n\t"
+        "v_cvt_pk_u8_f32 %0, %5, 2, %0\n\t"
+        "v_cvt_pk_u8_f32 %1, %9, 2, %1\n\t"
+        "v_cvt_pk_u8_f32 %2, %13, 2, %2\n\t"
+        "v_cvt_pk_u8_f32 %0, %6, 3, %0\n\t"
+        "v_cvt_pk_u8_f32 %1, %10, 3, %1\n\t"
+        "v_cvt_pk_u8_f32 %2, %14, 3, %2\n\t"
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+        : "=&v"(o.w0), "=&v"(o.w1), "=&v"(o.w2)
+        : "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]), "v"(t[4]), "v"(t[5]), "v"(t[6]), "v"(t[7]), "v"(t[8]), "v"(t[9]),
+          "v"(t[10]), "v"(t[11]));
+    return o;
+}
+// general case (a target matrix with negative entries can push values past 255): toward zero, then modulo 256
+__device__ __forceinline__ Chunk pack_trunc_general(const float (&t)[12]) {
+    uint32_t ob[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) ob[i] = trunc_u8(t[i]);
+    Chunk o;
+    o.w0 = ob[0] | (ob[1] << 8) | (ob[2] << 16) | (ob[3] << 24);
+    o.w1 = ob[4] | (ob[5] << 8) | (ob[6] << 16) | (ob[7] << 24);
+    o.w2 = ob[8] | (ob[9] << 8) | (ob[10] << 16) | (ob[11] << 24);
+    return o;
+}
+
 constexpr int kU = 4;       // chunks in flight per lane per trip (plain sweeps: 4 x 12 B loads issued back to back)
 constexpr int kUApply = 2;  // k_apply: 2 chunks per trip with the following trip prefetched
 
@@ -70,17 +165,9 @@ static __global__ __launch_bounds__(kWG) void k_apply(const uint8_t* __restrict_
     const int tid = threadIdx.x;
     const uint32_t lane32 = tid & (kRepl - 1);   // which LDS copy of the table this lane reads
 
-    // per-tile constants, computed redundantly in binary64 by every lane, then made scalar
-    LassoK L;
-    lasso_consts(M_src + 6 * (size_t)tile, lam, L);
-    uni(L);
-    ReconK R;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const double ratio = maxC_tgt[i] / maxC_src[2 * (size_t)tile + i];   // normalizer.py:48
-#pragma unroll
-        for (int c = 0; c < 3; ++c) R.q[i][c] = uni((float)(-1.4426950408889634 * ratio * M_tgt[3 * i + c]));
-    }
+    // per-tile constants, computed redundantly in binary64 by every lane
+    ApplyK K;
+    apply_consts(M_src + 6 * (size_t)tile, maxC_src + 2 * (size_t)tile, M_tgt, maxC_tgt, lam, K);
     __syncthreads();
 
     const size_t nbytes = (size_t)P * 3;
@@ -99,46 +186,45 @@ static __global__ __launch_bounds__(kWG) void k_apply(const uint8_t* __restrict_
     }
 
     // software pipeline: the next trip's chunks are requested before this trip's arithmetic (measured +5 %)
-    auto fetch = [&](int cc) { return cc < c1 ? load_chunk<ALIGNED>(src, nbytes, cc) : Chunk{0, 0, 0}; };
-    Chunk nxt[kUApply];
+    auto fetch = [&](int cc) { return load_chunk_clamped<ALIGNED>(src, nbytes, cc, c1); };
+    auto sweep = [&](auto fast_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        Chunk nxt[kUApply];
 #pragma unroll
-    for (int u = 0; u < kUApply; ++u) nxt[u] = fetch(c0 + tid + u * kWG);
-    for (int c = c0 + tid; c < c1; c += kWG * kUApply) {
-        Chunk in[kUApply];
+        for (int u = 0; u < kUApply; ++u) nxt[u] = fetch(c0 + tid + u * kWG);
+        for (int c = c0 + tid; c < c1; c += kWG * kUApply) {
+            Chunk in[kUApply];
 #pragma unroll
-        for (int u = 0; u < kUApply; ++u) {
-            in[u] = nxt[u];
-            nxt[u] = fetch(c + (kUApply + u) * kWG);
-        }
+            for (int u = 0; u < kUApply; ++u) {
+                in[u] = nxt[u];
+                nxt[u] = fetch(c + (kUApply + u) * kWG);
+            }
 #pragma unroll
-        for (int u = 0; u < kUApply; ++u) {
-            const int cc = c + u * kWG;
-            uint32_t ob[12];
+            for (int u = 0; u < kUApply; ++u) {
+                const int cc = c + u * kWG;
+                float t[12];
 #pragma unroll
-            for (int px = 0; px < 4; ++px) {
-                const float x = lut(s_od, chunk_byte(in[u], 3 * px + 0), lane32);
-                const float y = lut(s_od, chunk_byte(in[u], 3 * px + 1), lane32);
-                const float z = lut(s_od, chunk_byte(in[u], 3 * px + 2), lane32);
-                float a, b, v[3];
-                lasso2(L, x, y, z, a, b);
-                recon_px<false>(R, a, b, v);
-#pragma unroll
-                for (int ch = 0; ch < 3; ++ch) ob[3 * px + ch] = trunc_u8(v[ch]);
-                if (PREQ) {
-                    const size_t pix = (size_t)cc * 4 + px;
-                    if (cc < c1 && pix < (size_t)P) {
-                        float* pq = prequant + ((size_t)tile * P + pix) * 3;
-                        pq[0] = v[0]; pq[1] = v[1]; pq[2] = v[2];
+                for (int px = 0; px < 4; ++px) {
+                    const float x = lut(s_od, chunk_byte(in[u], 3 * px + 0), lane32);
+                    const float y = lut(s_od, chunk_byte(in[u], 3 * px + 1), lane32);
+                    const float z = lut(s_od, chunk_byte(in[u], 3 * px + 2), lane32);
+                    float v[3];
+                    apply_px<FAST>(K, x, y, z, v);
+                    t[3 * px] = v[0]; t[3 * px + 1] = v[1]; t[3 * px + 2] = v[2];
+                    if (PREQ) {
+                        const size_t pix = (size_t)cc * 4 + px;
+                        if (cc < c1 && pix < (size_t)P) {
+                            float* pq = prequant + ((size_t)tile * P + pix) * 3;
+                            pq[0] = v[0]; pq[1] = v[1]; pq[2] = v[2];
+                        }
                     }
                 }
+                const Chunk o = FAST ? pack_trunc_fast(t) : pack_trunc_general(t);
+                if (cc < c1) store_chunk<ALIGNED>(dst, nbytes, cc, o);
             }
-            Chunk o;
-            o.w0 = ob[0] | (ob[1] << 8) | (ob[2] << 16) | (ob[3] << 24);
-            o.w1 = ob[4] | (ob[5] << 8) | (ob[6] << 16) | (ob[7] << 24);
-            o.w2 = ob[8] | (ob[9] << 8) | (ob[10] << 16) | (ob[11] << 24);
-            if (cc < c1) store_chunk<ALIGNED>(dst, nbytes, cc, o);
         }
-    }
+    };
+    if (K.fast) sweep(std::true_type{}); else sweep(std::false_type{});
 }
 
 // StainAugmentor.pop: own stain matrix both ways, affine on the concentrations of tissue pixels

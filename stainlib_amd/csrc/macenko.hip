@@ -66,7 +66,7 @@ int run_stats_group(const uint8_t* rgb, int g0, int m, long P, const SlParams& p
     a.parts = L.parts;
     a.stride_log2 = L.stride_log2;
     a.n_sample = L.n_sample;
-    a.y_lim = y_limit_for_threshold(p.luminosity_threshold);
+    a.ylimf = (float)y_limit_for_threshold(p.luminosity_threshold) - 2048.0f;   // exact: y_lim < 2^24
     a.lam = p.lasso_lambda;
     a.pct = p.angular_percentile;
     a.partials = (double*)(ws + L.off_partials);
@@ -77,7 +77,7 @@ int run_stats_group(const uint8_t* rgb, int g0, int m, long P, const SlParams& p
     a.cand = (float*)(ws + L.off_list);
     a.state = (TileState*)(ws + L.off_state);
     const bool al = aligned4(a.rgb, P);
-    const dim3 gs((unsigned)((long)m * L.parts)), bs(kWG), gf((unsigned)m), bf(kFinishThreads);
+    const dim3 gs((unsigned)((long)m * L.parts)), bs(kSweepThreads), gf((unsigned)m), bf(kFinishThreads);
     SlProfile* prof = p.profile;
     {
         ProfScope ps(prof, SL_PROF_MOMENTS, m, s);
@@ -104,6 +104,7 @@ int run_stats_group(const uint8_t* rgb, int g0, int m, long P, const SlParams& p
 }
 
 long long* g_phase_clock = nullptr;   // development aid, see sl_debug_set_phase_clock
+int g_debug_stop = 0;
 
 // The persistent schedule: one launch for the whole batch (fit only when out == nullptr).
 int run_fused(int method, const uint8_t* rgb, uint8_t* out, int n, long P, const SlParams& p, const Layout& L, char* ws,
@@ -116,7 +117,7 @@ int run_fused(int method, const uint8_t* rgb, uint8_t* out, int n, long P, const
     a.P = (int)P;
     a.stride_log2 = L.stride_log2;
     a.n_sample = L.n_sample;
-    a.y_lim = y_limit_for_threshold(p.luminosity_threshold);
+    a.ylimf = (float)y_limit_for_threshold(p.luminosity_threshold) - 2048.0f;   // exact: y_lim < 2^24
     a.lam = p.lasso_lambda;
     a.pct = p.angular_percentile;
     a.M_tgt = M_tgt;
@@ -131,6 +132,7 @@ int run_fused(int method, const uint8_t* rgb, uint8_t* out, int n, long P, const
     a.status_out = status_all;
     a.diag_out = (int32_t*)(ws + L.off_diag);
     a.phase_clock = g_phase_clock;
+    a.debug_stop = g_debug_stop;
     a.dl_lambda = p.dl_lambda;
     a.dl_tol = p.dl_tol;
     a.dl_max_sweeps = p.dl_max_sweeps > 0 ? p.dl_max_sweeps : 1;
@@ -287,3 +289,4 @@ extern "C" int sl_debug_layout(int n, int h, int w, size_t* off_state, size_t* s
 }
 
 extern "C" void sl_debug_set_phase_clock(long long* device_buf) { g_phase_clock = device_buf; }
+extern "C" void sl_debug_set_stop(int phase) { g_debug_stop = phase; }

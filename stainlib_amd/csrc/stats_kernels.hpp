@@ -43,6 +43,7 @@ constexpr int kMinCapRaw = 65536;   // raw-pixel candidate capacity per tile and
 constexpr int kMinCapList = 16384;  // exact-key bracket members per list after the refine pass: max(this, P/40)
 constexpr int kFinishThreads = 1024;
 constexpr int kFusedThreads = 512;  // 2 resident workgroups per CU (<=128 VGPRs, <80 KB LDS each)
+constexpr int kSweepThreads = 512;  // sweep kernels of the one-launch-per-phase schedule (same occupancy: 64 KB table each)
 constexpr int kStageWave = 256;     // per-wave LDS staging entries for raw candidates (8 KB per 8 waves)
 constexpr float kBracketZ = 6.0f;   // bracket half-width in standard deviations of the sample rank
 constexpr float kAngleMargin = 2e-5f;  // safety margin of the cheap pseudo-angle test (keys carry ~1e-7)
@@ -71,7 +72,7 @@ struct StatsArgs {
     int parts;               // workgroups per tile (multi-kernel schedule)
     int stride_log2;         // sampling stride = 1 << stride_log2 (>= 6)
     int n_sample;            // ceil(P / stride)
-    uint32_t y_lim;
+    float ylimf;             // tissue test threshold: y_lim - 2048 (see is_tissue_f)
     double lam;
     double pct;              // angular percentile
     double* partials;        // [tile][part][10]          (multi-kernel)
@@ -83,65 +84,45 @@ struct StatsArgs {
 };
 
 
-// LDS lookup tables of the 256 byte values, bank-replicated: copy (lane & (R-1)) of entry v sits at
-// [v*R + copy], so the lanes a DS instruction services together hit distinct banks whatever bytes
-// they look up (R = 32: conflict-free ds_read_b32; smaller R trades LDS for a few conflicts).
-// The sweeps are LDS-gather bound with a single 1 KB table (measured), hence the replication.
-struct TabView {                    // this thread's copy of the tables, for the finish steps and key functors
-    const float* f; const uint32_t* g; int rf, rg, cf, cg;
-    __device__ __forceinline__ float odf(uint32_t v) const { return f[v * rf + cf]; }
-    __device__ __forceinline__ uint32_t gam(uint32_t v) const { return g[v * rg + cg]; }
+// Table access of the finish steps and key functors (few lookups, any layout): entry v of table f / g
+// sits at [v*stride + c].  The sweeps use TabReader (sl_device.hpp) on the same RowTab instead.
+struct TabView {
+    const float* f; const float* g; int stride, cf, cg;
+    __device__ __forceinline__ float odf(uint32_t v) const { return f[v * stride + cf]; }
+    __device__ __forceinline__ float gam(uint32_t v) const { return g[v * stride + cg]; }
 };
-template <int RF, int RG, int RD>
-struct Tabs {
-    float f[256 * RF];                       // max(-ln(v/255), 1e-6) in binary32
-    uint32_t g[256 * RG];                    // OpenCV inverse-sRGB-gamma table
-    double d[257 * (RD > 0 ? RD : 1)];       // OD in binary64 (moment sums only); entry 256 = 0.0 (masked-out pixel)
+__device__ __forceinline__ TabView view_of(const RowTab& t) {
+    const float* base = reinterpret_cast<const float*>(t.e);
+    const int c = 4 * (int)(threadIdx.x & (kTabCopies - 1));
+    return TabView{base, base, 4 * kTabCopies, c + 3, c + 2};
+}
+// the 2 KB version for kernels that only run finish steps
+struct SmallTab {
+    float f[256], g[256];
     __device__ __forceinline__ void fill() {
-        for (int i = threadIdx.x; i < 256 * RF; i += blockDim.x) f[i] = d_od_f32[i / RF];
-        for (int i = threadIdx.x; i < 256 * RG; i += blockDim.x) g[i] = d_gamma[i / RG];
-        if (RD > 0)
-            for (int i = threadIdx.x; i < 257 * RD; i += blockDim.x) d[i] = i < 256 * RD ? d_od_f64[i / RD] : 0.0;
-    }
-    __device__ __forceinline__ float odf(uint32_t v, uint32_t lane) const { return f[v * RF + (lane & (RF - 1))]; }
-    __device__ __forceinline__ uint32_t gam(uint32_t v, uint32_t lane) const { return g[v * RG + (lane & (RG - 1))]; }
-    __device__ __forceinline__ double od64(uint32_t v, uint32_t lane) const { return d[v * RD + (lane & (RD - 1))]; }
-    __device__ __forceinline__ void pair(uint32_t v, uint32_t lane, float& o, uint32_t& gm) const { o = odf(v, lane); gm = gam(v, lane); }
-    __device__ __forceinline__ TabView view() const {
-        return TabView{f, g, RF, RG, (int)(threadIdx.x & (RF - 1)), (int)(threadIdx.x & (RG - 1))};
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) { f[i] = d_od_f32[i]; g[i] = (float)d_gamma[i]; }
     }
 };
+__device__ __forceinline__ TabView view_of(const SmallTab& t) { return TabView{t.f, t.g, 1, 0, 0}; }
 
-// Fused-kernel variant: OD-f32 and gamma interleaved in one 8-byte entry, so the angle sweep gets both with
-// ONE ds_read_b64 per channel (3 LDS instructions + 3 address computations per pixel instead of 6 + 6).
-template <int R, int RD>
-struct TabsFG {
-    struct __attribute__((aligned(8))) FG { float o; uint32_t g; };
-    FG fg[256 * R];
-    double d[257 * RD];                      // entry 256 = 0.0 (masked-out pixel)
-    __device__ __forceinline__ void fill() {
-        for (int i = threadIdx.x; i < 256 * R; i += blockDim.x) { FG e; e.o = d_od_f32[i / R]; e.g = d_gamma[i / R]; fg[i] = e; }
-        for (int i = threadIdx.x; i < 257 * RD; i += blockDim.x) d[i] = i < 256 * RD ? d_od_f64[i / RD] : 0.0;
-    }
-    __device__ __forceinline__ float odf(uint32_t v, uint32_t lane) const { return fg[v * R + (lane & (R - 1))].o; }
-    __device__ __forceinline__ uint32_t gam(uint32_t v, uint32_t lane) const { return fg[v * R + (lane & (R - 1))].g; }
-    __device__ __forceinline__ double od64(uint32_t v, uint32_t lane) const { return d[v * RD + (lane & (RD - 1))]; }
-    __device__ __forceinline__ void pair(uint32_t v, uint32_t lane, float& o, uint32_t& gm) const {
-        const FG e = fg[v * R + (lane & (R - 1))];
-        o = e.o; gm = e.g;
-    }
-    __device__ __forceinline__ TabView view() const {
-        const int c = 2 * (int)(threadIdx.x & (R - 1));
-        return TabView{&fg[0].o, &fg[0].g, 2 * R, 2 * R, c, c};
-    }
-};
-
-// Which pixel of sampling block b is kept (same function in the sweep and in the finish steps).
-__device__ __forceinline__ uint32_t sample_offset(uint32_t b, int stride_log2) {
-    uint32_t h = b * 0x9E3779B1u;
+// ---- stratified sample: one pixel per block of 2^stride_log2 pixels (2^cps_log2 chunks, cps_log2 >= 4) ----
+// Which pixel is decided per HASH GROUP = the 64 chunks one wave covers with one load (or the whole block when
+// it is larger): every lane of a wave row then shares the draw, so the sweep computes it on the scalar unit and
+// pays one compare per chunk.  The draw picks a chunk of the block and pixel 0 or 3 of that chunk (the two a
+// single shift extracts).  The sample only steers the brackets; results never depend on it.
+__device__ __forceinline__ uint32_t sample_hash(uint32_t group) {
+    uint32_t h = group * 0x9E3779B1u;
     h ^= h >> 15;
     h *= 0x85EBCA77u;
-    return h >> (32 - stride_log2);
+    return h;
+}
+__device__ __forceinline__ int sample_group_shift(int cps_log2) { return cps_log2 > 6 ? cps_log2 : 6; }   // chunk index -> group
+// pixel index kept for block b (may lie beyond the tile for the last block: then the entry is absent)
+__device__ __forceinline__ long long sample_pixel(uint32_t b, int cps_log2) {
+    const uint32_t chunk0 = b << cps_log2;
+    const uint32_t h = sample_hash(chunk0 >> sample_group_shift(cps_log2));
+    const uint32_t chunk = chunk0 + ((h >> 8) & ((1u << cps_log2) - 1u));
+    return (long long)chunk * 4 + ((h >> 31) ? 3 : 0);
 }
 
 // Monotone surrogate of arctan2(y, x) on (-pi, pi]: y/(|x|+|y|) in [-1,1] for x >= 0, mirrored to
@@ -557,58 +538,70 @@ __device__ __forceinline__ void stain_matrix_from_angles(const double* Vd, const
 // ------------------------------------------------------------------------------------------
 struct Moments {
     double sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
-    uint32_t cnt = 0;
-    __device__ __forceinline__ void add(bool on, double x, double y, double z) {   // x = y = z = 0 when !on
-        cnt += on ? 1u : 0u;
+    __device__ __forceinline__ void add(double x, double y, double z) {
         sx += x; sy += y; sz += z;
         sxx = fma(x, x, sxx); sxy = fma(x, y, sxy); sxz = fma(x, z, sxz);
         syy = fma(y, y, syy); syz = fma(y, z, syz); szz = fma(z, z, szz);
     }
-    __device__ __forceinline__ void to_array(double* v) const {
-        v[0] = (double)cnt; v[1] = sx; v[2] = sy; v[3] = sz; v[4] = sxx; v[5] = sxy; v[6] = sxz;
+    // v[0] = pixel count: n_wave is the wave-uniform count, credited to lane 0 so that a wave sum yields it
+    __device__ __forceinline__ void to_array(double* v, uint32_t n_wave, int lane) const {
+        v[0] = lane == 0 ? (double)n_wave : 0.0; v[1] = sx; v[2] = sy; v[3] = sz; v[4] = sxx; v[5] = sxy; v[6] = sxz;
         v[7] = syy; v[8] = syz; v[9] = szz;
     }
 };
 
-// sweep 1 over chunks [c0, c1) with `nthreads` cooperating threads (thread index t)
-template <bool ALIGNED, class TABS, class SampleStore>
+
+// Sample bookkeeping of one chunk row (64 chunks starting at the wave-uniform, 64-aligned chunk `row0`): the lane
+// whose chunk the draw selects stores pixel 0 or 3 of it.  Scalar hash, ~6 vector instructions per chunk.
+template <bool ALIGNED>
+__device__ __forceinline__ void sample_row(const Chunk& ch, int row0, int cc, int c1, int P, int cps_log2, uint32_t* samp) {
+    const uint32_t h = sample_hash((uint32_t)row0 >> sample_group_shift(cps_log2));
+    const uint32_t cmask = (1u << cps_log2) - 1u;
+    const uint32_t sel = (h >> 8) & cmask;
+    const bool last = (h >> 31) != 0;                                  // uniform: pixel 3 instead of pixel 0
+    if ((cc < c1) & (((uint32_t)cc & cmask) == sel)) {
+        const uint32_t v = (last ? ch.w2 : ch.w0) >> (last ? 8 : 0);   // stray top byte for pixel 0: readers ignore it
+        if (ALIGNED || (size_t)cc * 4 + (last ? 3 : 0) < (size_t)P) samp[(uint32_t)cc >> cps_log2] = v;
+    }
+}
+
+// sweep 1 over chunks [c0, c1) with `nthreads` cooperating threads (thread index t); c0 must be a multiple of 64.
+// n_tissue is wave-uniform (a scalar popcount per pixel row).  ~13 slow-pipe + 3 fast-pipe instructions per pixel.
+template <bool ALIGNED>
 __device__ __forceinline__ void moments_sweep(const uint8_t* src, int P, int c0, int c1, int t, int nthreads,
-                                              const TABS& T, uint32_t y_lim, int stride_log2,
-                                              SampleStore store_sample, Moments& mo) {
+                                              const TabReader& T, float ylimf, int stride_log2, uint32_t* samp,
+                                              Moments& mo, uint32_t& n_tissue) {
     const size_t nbytes = (size_t)P * 3;
+    const int lane = t & 63;
     const int cps_log2 = stride_log2 - 2;          // chunks per sampling block
-    auto process = [&](const Chunk& ch, int cc) {
-        const bool live = cc < c1;
-        const uint32_t b = (uint32_t)cc >> cps_log2;        // stratified sample: block b keeps pixel b*stride+off
-        const uint32_t off = sample_offset(b, stride_log2);
-        const bool has_sample = live & ((off >> 2) == ((uint32_t)cc & ((1u << cps_log2) - 1)));
+    const int w0 = __builtin_amdgcn_readfirstlane(c0 + (t & ~63));
+    auto fetch = [&](int cc) { return load_chunk_clamped<ALIGNED>(src, nbytes, cc, c1); };   // dead lanes: see `live`
+    Chunk nx[2] = {fetch(w0 + lane), fetch(w0 + lane + nthreads)};
+    for (int cb = w0; cb < c1; cb += nthreads * 2) {
+        const Chunk in[2] = {nx[0], nx[1]};
+        nx[0] = fetch(cb + lane + 2 * nthreads);   // the next trip's chunks are in flight during this one
+        nx[1] = fetch(cb + lane + 3 * nthreads);
 #pragma unroll
-        for (int px = 0; px < 4; ++px) {
-            const uint32_t r = chunk_byte(ch, 3 * px), g = chunk_byte(ch, 3 * px + 1), bb = chunk_byte(ch, 3 * px + 2);
-            // branch-free: a non-tissue pixel reads table entry 256 (= 0.0) instead of being skipped, so the
-            // whole chunk stays one basic block and its LDS gathers issue back to back
-            const uint32_t gr = T.gam(r, t), gg = T.gam(g, t), gb = T.gam(bb, t);
-            const bool inb = live & (ALIGNED | ((size_t)cc * 4 + px < (size_t)P));
-            const bool tissue = inb & is_tissue(gr, gg, gb, y_lim);
-            const double ox = T.od64(tissue ? r : 256u, t), oy = T.od64(tissue ? g : 256u, t), oz = T.od64(tissue ? bb : 256u, t);
-            mo.add(tissue, ox, oy, oz);
-            if (has_sample & ((off & 3) == (uint32_t)px) & inb)
-                store_sample(b, r | (g << 8) | (bb << 16) | ((tissue ? 1u : 0u) << 24));
+        for (int u = 0; u < 2; ++u) {
+            const int row0 = cb + u * nthreads, cc = row0 + lane;
+            sample_row<ALIGNED>(in[u], row0, cc, c1, P, cps_log2, samp);
+            const bool live = cc < c1;
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                const TabEntry er = T.entry(T.addr(in[u], 3 * px)), eg = T.entry(T.addr(in[u], 3 * px + 1)),
+                               eb = T.entry(T.addr(in[u], 3 * px + 2));
+                bool tissue = live & is_tissue_f(er.gam, eg.gam, eb.gam, ylimf);
+                if (!ALIGNED) tissue = tissue & ((size_t)cc * 4 + px < (size_t)P);
+                n_tissue += (uint32_t)__popcll(__ballot(tissue));
+                if (tissue) mo.add(er.od, eg.od, eb.od);             // 9 binary64 ops under the exec mask, no select
+            }
         }
-    };
-    for (int c = c0 + t; c < c1; c += nthreads * 2) {
-        const int cA = c, cB = c + nthreads;
-        const Chunk inA = cA < c1 ? load_chunk<ALIGNED>(src, nbytes, cA) : Chunk{0xffffffffu, 0xffffffffu, 0xffffffffu};
-        const Chunk inB = cB < c1 ? load_chunk<ALIGNED>(src, nbytes, cB) : Chunk{0xffffffffu, 0xffffffffu, 0xffffffffu};
-        process(inA, cA);
-        __builtin_amdgcn_sched_barrier(0);   // keep the two chunks' 24 table reads from being hoisted together (spills)
-        process(inB, cB);
     }
 }
 
 enum { kStageAngle = 0, kStageConc = 1 };
 
-struct SelConsts {
+struct SelConsts {          // everything VGPR-resident (in_vgpr)
     float V[6];
     LassoK L;
     float lo0, hi0, lo1, hi1;
@@ -622,23 +615,24 @@ struct SelConsts {
 //     division as  y > (hi0+eps) d  and  y < (lo1-eps) d  with d = x + |y|, x > 0
 //   concentration stage (g12 >= 0): c_i <= max(0, a_i) exactly, so  a1 < lo0 and a2 < lo1  =>  both
 //     keys lie below their brackets (needs lo > 0; otherwise nothing is plain)
-template <int STAGE, bool ALIGNED, class TABS, class Sink>
+// n_plain is wave-uniform.  c0 must be a multiple of 64.
+template <int STAGE, bool ALIGNED, class Sink>
 __device__ __forceinline__ void select_sweep(const uint8_t* src, int P, int c0, int c1, int t, int nthreads,
-                                             const TABS& T, uint32_t y_lim, const SelConsts& K, Sink& sink,
+                                             const TabReader& T, float ylimf, const SelConsts& K, Sink& sink,
                                              uint32_t& n_plain) {
     const size_t nbytes = (size_t)P * 3;
     const int lane = t & 63;
-    // thresholds of the cheap tests (wave-uniform)
-    const float hi0m = K.hi0 + kAngleMargin, lo1m = K.lo1 - kAngleMargin;
+    // thresholds of the cheap tests
+    const float nhi0m = in_vgpr(-(K.hi0 + kAngleMargin)), nlo1m = in_vgpr(-(K.lo1 - kAngleMargin));
     const bool conc_ok = (K.L.g12 >= 0.0f) & (K.lo0 > 0.0f) & (K.lo1 > 0.0f);
     const float clo0 = conc_ok ? K.lo0 : -INFINITY, clo1 = conc_ok ? K.lo1 : -INFINITY;
-    for (int cb = c0 + (t & ~63); cb < c1; cb += nthreads * 2) {
-        Chunk in[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int cc = cb + lane + u * nthreads;
-            in[u] = cc < c1 ? load_chunk<ALIGNED>(src, nbytes, cc) : Chunk{0xffffffffu, 0xffffffffu, 0xffffffffu};
-        }
+    const int w0 = __builtin_amdgcn_readfirstlane(c0 + (t & ~63));
+    auto fetch = [&](int cc) { return load_chunk_clamped<ALIGNED>(src, nbytes, cc, c1); };   // dead lanes: see `live`
+    Chunk nx[2] = {fetch(w0 + lane), fetch(w0 + lane + nthreads)};
+    for (int cb = w0; cb < c1; cb += nthreads * 2) {
+        const Chunk in[2] = {nx[0], nx[1]};
+        nx[0] = fetch(cb + lane + 2 * nthreads);
+        nx[1] = fetch(cb + lane + 3 * nthreads);
         uint32_t raw[8];
         bool flag[8];
 #pragma unroll
@@ -648,29 +642,25 @@ __device__ __forceinline__ void select_sweep(const uint8_t* src, int P, int c0, 
 #pragma unroll
             for (int px = 0; px < 4; ++px) {
                 const int j = u * 4 + px;
-                const uint32_t r = chunk_byte(in[u], 3 * px), g = chunk_byte(in[u], 3 * px + 1),
-                               bb = chunk_byte(in[u], 3 * px + 2);
-                float ox, oy, oz;
-                uint32_t gr = 0, gg = 0, gb = 0;
-                if (STAGE == kStageAngle) { T.pair(r, t, ox, gr); T.pair(g, t, oy, gg); T.pair(bb, t, oz, gb); }
-                else { ox = T.odf(r, t); oy = T.odf(g, t); oz = T.odf(bb, t); }
-                const bool inb = live & (ALIGNED | ((size_t)cc * 4 + px < (size_t)P));
-                bool valid, plain;
+                const uint32_t ar = T.addr(in[u], 3 * px), ag = T.addr(in[u], 3 * px + 1), ab = T.addr(in[u], 3 * px + 2);
+                bool valid = live, plain;
+                if (!ALIGNED) valid = valid & ((size_t)cc * 4 + px < (size_t)P);
                 if (STAGE == kStageAngle) {
-                    valid = inb & is_tissue(gr, gg, gb, y_lim);
-                    const float x = fmaf(K.V[4], oz, fmaf(K.V[2], oy, K.V[0] * ox));
-                    const float y = fmaf(K.V[5], oz, fmaf(K.V[3], oy, K.V[1] * ox));
+                    const float2 er = T.gam_odf(ar), eg = T.gam_odf(ag), eb = T.gam_odf(ab);
+                    valid = valid & is_tissue_f(er.x, eg.x, eb.x, ylimf);
+                    const float x = fmaf(K.V[4], eb.y, fmaf(K.V[2], eg.y, K.V[0] * er.y));
+                    const float y = fmaf(K.V[5], eb.y, fmaf(K.V[3], eg.y, K.V[1] * er.y));
                     const float d = x + fabsf(y);
-                    plain = valid & (x > 0.0f) & (fmaf(-hi0m, d, y) > 0.0f) & (fmaf(-lo1m, d, y) < 0.0f);
+                    const float t0 = fmaf(nhi0m, d, y), t1 = fmaf(nlo1m, d, y);
+                    plain = valid & (x > 0.0f) & (t0 > 0.0f) & (t1 < 0.0f);
                 } else {
-                    valid = inb;
                     float a1, a2;
-                    lasso_interior(K.L, ox, oy, oz, a1, a2);
+                    lasso_interior(K.L, T.odf(ar), T.odf(ag), T.odf(ab), a1, a2);
                     plain = valid & (a1 < clo0) & (a2 < clo1);
                 }
-                n_plain += plain ? 1u : 0u;
+                n_plain += (uint32_t)__popcll(__ballot(plain));
                 flag[j] = valid & !plain;
-                raw[j] = r | (g << 8) | (bb << 16);
+                raw[j] = chunk_pixel(in[u], px);
             }
         }
         sink.commit(flag, raw, lane);
@@ -680,21 +670,20 @@ __device__ __forceinline__ void select_sweep(const uint8_t* src, int P, int c0, 
 // ---- key functors handed BY VALUE to the selection primitives ----
 // pseudo-angle of sample entry b (NaN: not tissue / beyond the tile)
 struct SampleAngleKey {
-    const uint32_t* sample; TabView tab; float V[6]; int stride_log2; int P;
+    const uint32_t* sample; TabView tab; float V[6]; int cps_log2; int P; float ylimf;
     __device__ __forceinline__ float operator()(int b) const {
-        const long long pix = ((long long)b << stride_log2) + sample_offset(b, stride_log2);
-        if (pix >= P) return nan_f();
+        if (sample_pixel((uint32_t)b, cps_log2) >= P) return nan_f();
         const uint32_t s = sample[b];
-        if (!(s >> 24)) return nan_f();
-        return angle_key(V, tab.odf(s & 255u), tab.odf((s >> 8) & 255u), tab.odf((s >> 16) & 255u));
+        const uint32_t r = s & 255u, g = (s >> 8) & 255u, bl = (s >> 16) & 255u;
+        if (!is_tissue_f(tab.gam(r), tab.gam(g), tab.gam(bl), ylimf)) return nan_f();
+        return angle_key(V, tab.odf(r), tab.odf(g), tab.odf(bl));
     }
 };
 // concentration `col` of sample entry b (all pixels, tissue or not)
 struct SampleConcKey {
-    const uint32_t* sample; TabView tab; LassoK L; int stride_log2; int P; int col;
+    const uint32_t* sample; TabView tab; LassoK L; int cps_log2; int P; int col;
     __device__ __forceinline__ float operator()(int b) const {
-        const long long pix = ((long long)b << stride_log2) + sample_offset(b, stride_log2);
-        if (pix >= P) return nan_f();
+        if (sample_pixel((uint32_t)b, cps_log2) >= P) return nan_f();
         const uint32_t s = sample[b];
         float c1, c2;
         lasso2(L, tab.odf(s & 255u), tab.odf((s >> 8) & 255u), tab.odf((s >> 16) & 255u), c1, c2);
@@ -703,10 +692,10 @@ struct SampleConcKey {
 };
 // keys of pixel p of a whole tile (exact fallback)
 struct AngleTileKey {
-    const uint8_t* src; TabView tab; float V[6]; uint32_t y_lim;
+    const uint8_t* src; TabView tab; float V[6]; float ylimf;
     __device__ __forceinline__ float operator()(int p) const {
         const uint32_t r = src[3 * (size_t)p], g = src[3 * (size_t)p + 1], b = src[3 * (size_t)p + 2];
-        if (!is_tissue(tab.gam(r), tab.gam(g), tab.gam(b), y_lim)) return nan_f();
+        if (!is_tissue_f(tab.gam(r), tab.gam(g), tab.gam(b), ylimf)) return nan_f();
         return angle_key(V, tab.odf(r), tab.odf(g), tab.odf(b));
     }
 };
@@ -912,36 +901,36 @@ struct ClsAcc {
     }
 };
 
-// classify every tissue pixel of chunks [c0,c1) under the dictionary L (binary32 lasso constants) and
-// accumulate the moments of classes both / only-1 / only-2; n_tissue counts all tissue pixels.
-template <bool ALIGNED, bool SAMPLE, class TABS, class SampleStore>
-__device__ __forceinline__ void dict_sweep(const uint8_t* src, int P, int c0, int c1, int t, int nthreads, const TABS& T,
-                                           uint32_t y_lim, int stride_log2, const LassoK64& L, SampleStore store_sample,
+// classify every tissue pixel of chunks [c0,c1) under the dictionary L and accumulate the moments of classes
+// both / only-1 / only-2; n_tissue (wave-uniform) counts all tissue pixels.  c0 must be a multiple of 64.
+template <bool ALIGNED, bool SAMPLE>
+__device__ __forceinline__ void dict_sweep(const uint8_t* src, int P, int c0, int c1, int t, int nthreads, const TabReader& T,
+                                           float ylimf, int stride_log2, const LassoK64& L, uint32_t* samp,
                                            ClsAcc (&acc)[3], uint32_t& n_tissue) {
     const size_t nbytes = (size_t)P * 3;
+    const int lane = t & 63;
     const int cps_log2 = stride_log2 - 2;
-    for (int c = c0 + t; c < c1; c += nthreads * 2) {
+    const int w0 = __builtin_amdgcn_readfirstlane(c0 + (t & ~63));
+    for (int cb = w0; cb < c1; cb += nthreads * 2) {
         Chunk in[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int cc = c + u * nthreads;
-            in[u] = cc < c1 ? load_chunk<ALIGNED>(src, nbytes, cc) : Chunk{0xffffffffu, 0xffffffffu, 0xffffffffu};
+            const int cc = cb + lane + u * nthreads;
+            in[u] = load_chunk_clamped<ALIGNED>(src, nbytes, cc, c1);
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int cc = c + u * nthreads;
+            const int row0 = cb + u * nthreads, cc = row0 + lane;
+            if (SAMPLE) sample_row<ALIGNED>(in[u], row0, cc, c1, P, cps_log2, samp);
             const bool live = cc < c1;
-            const uint32_t b = (uint32_t)cc >> cps_log2;
-            const uint32_t off = SAMPLE ? sample_offset(b, stride_log2) : 0u;
-            const bool has_sample = SAMPLE & live & ((off >> 2) == ((uint32_t)cc & ((1u << cps_log2) - 1)));
 #pragma unroll
             for (int px = 0; px < 4; ++px) {
-                const uint32_t r = chunk_byte(in[u], 3 * px), g = chunk_byte(in[u], 3 * px + 1),
-                               bb = chunk_byte(in[u], 3 * px + 2);
-                const uint32_t gr = T.gam(r, t), gg = T.gam(g, t), gb = T.gam(bb, t);
-                const double ox = T.od64(r, t), oy = T.od64(g, t), oz = T.od64(bb, t);
-                const bool inb = live & (ALIGNED | ((size_t)cc * 4 + px < (size_t)P));
-                const bool tissue = inb & is_tissue(gr, gg, gb, y_lim);
+                const TabEntry er = T.entry(T.addr(in[u], 3 * px)), eg = T.entry(T.addr(in[u], 3 * px + 1)),
+                               eb = T.entry(T.addr(in[u], 3 * px + 2));
+                bool tissue = live & is_tissue_f(er.gam, eg.gam, eb.gam, ylimf);
+                if (!ALIGNED) tissue = tissue & ((size_t)cc * 4 + px < (size_t)P);
+                n_tissue += (uint32_t)__popcll(__ballot(tissue));
+                const double ox = er.od, oy = eg.od, oz = eb.od;
                 // active set of the exact code (same quantities as lasso2, in binary64)
                 const double a1 = fma(L.wa1[2], oz, fma(L.wa1[1], oy, fma(L.wa1[0], ox, L.ka1)));
                 const double a2 = fma(L.wa2[2], oz, fma(L.wa2[1], oy, fma(L.wa2[0], ox, L.ka2)));
@@ -950,14 +939,9 @@ __device__ __forceinline__ void dict_sweep(const uint8_t* src, int P, int c0, in
                 const bool both = (a1 >= 0.0) & (a2 >= 0.0);
                 const bool only1 = !both & (s1 > 0.0) & (fma(-L.g12, s1, L.g22 * s2) <= 0.0);
                 const bool only2 = !both & !only1 & (s2 > 0.0);
-                n_tissue += tissue ? 1u : 0u;
                 if (tissue & both) acc[0].add(ox, oy, oz);
                 if (tissue & only1) acc[1].add(ox, oy, oz);
                 if (tissue & only2) acc[2].add(ox, oy, oz);
-                if (SAMPLE) {
-                    if (has_sample & ((off & 3) == (uint32_t)px) & inb)
-                        store_sample(b, r | (g << 8) | (bb << 16) | ((tissue ? 1u : 0u) << 24));
-                }
             }
         }
     }
@@ -965,16 +949,19 @@ __device__ __forceinline__ void dict_sweep(const uint8_t* src, int P, int c0, in
 
 // the same classification + accumulation over the tile's stratified SAMPLE (tissue entries only): a
 // 1/64-cost stand-in for a full sweep, used to bring D close to its fixed point before touching the tile again
-template <class TABS>
 __device__ __forceinline__ void dict_sweep_sample(const uint32_t* samp, int n_sample, int stride_log2, int P, int t,
-                                                  int nthreads, const TABS& T, const LassoK64& L, ClsAcc (&acc)[3],
-                                                  uint32_t& n_tissue) {
-    for (int b = t; b < n_sample; b += nthreads) {
-        const long long pix = ((long long)b << stride_log2) + sample_offset(b, stride_log2);
-        if (pix >= P) continue;
-        const uint32_t s = samp[b];
-        if (!(s >> 24)) continue;
-        const double ox = T.od64(s & 255u, t), oy = T.od64((s >> 8) & 255u, t), oz = T.od64((s >> 16) & 255u, t);
+                                                  int nthreads, const TabReader& T, float ylimf, const LassoK64& L,
+                                                  ClsAcc (&acc)[3], uint32_t& n_tissue) {
+    const int lane = t & 63;
+    const int cps_log2 = stride_log2 - 2;
+    for (int b0 = t & ~63; b0 < n_sample; b0 += nthreads) {
+        const int b = b0 + lane;
+        const bool have = b < n_sample && sample_pixel((uint32_t)b, cps_log2) < P;
+        const uint32_t s = samp[have ? b : 0];                      // unconditional load (n_sample >= 1); `have` masks the result
+        const TabEntry er = T.entry(T.addr(s, 0)), eg = T.entry(T.addr(s, 1)), eb = T.entry(T.addr(s, 2));
+        const bool tissue = have & is_tissue_f(er.gam, eg.gam, eb.gam, ylimf);
+        n_tissue += (uint32_t)__popcll(__ballot(tissue));
+        const double ox = er.od, oy = eg.od, oz = eb.od;
         const double a1 = fma(L.wa1[2], oz, fma(L.wa1[1], oy, fma(L.wa1[0], ox, L.ka1)));
         const double a2 = fma(L.wa2[2], oz, fma(L.wa2[1], oy, fma(L.wa2[0], ox, L.ka2)));
         const double s1 = fma(L.ws1[2], oz, fma(L.ws1[1], oy, fma(L.ws1[0], ox, L.ks1)));
@@ -982,10 +969,9 @@ __device__ __forceinline__ void dict_sweep_sample(const uint32_t* samp, int n_sa
         const bool both = (a1 >= 0.0) & (a2 >= 0.0);
         const bool only1 = !both & (s1 > 0.0) & (fma(-L.g12, s1, L.g22 * s2) <= 0.0);
         const bool only2 = !both & !only1 & (s2 > 0.0);
-        n_tissue += 1u;
-        if (both) acc[0].add(ox, oy, oz);
-        if (only1) acc[1].add(ox, oy, oz);
-        if (only2) acc[2].add(ox, oy, oz);
+        if (tissue & both) acc[0].add(ox, oy, oz);
+        if (tissue & only1) acc[1].add(ox, oy, oz);
+        if (tissue & only2) acc[2].add(ox, oy, oz);
     }
 }
 
@@ -1079,32 +1065,39 @@ __device__ __forceinline__ double dict_inner_solve(const double* mom, double (&D
 // ------------------------------------------------------------------------------------------
 // multi-kernel schedule
 // ------------------------------------------------------------------------------------------
+// chunk range of part `part` of a tile: spans are multiples of 64 chunks so that every wave row is 64-aligned
+__device__ __forceinline__ void part_range(int nch, int parts, int part, int& c0, int& c1) {
+    const int span = (((nch + parts - 1) / parts) + 63) & ~63;
+    c0 = min(nch, part * span);
+    c1 = min(nch, c0 + span);
+}
+
 template <bool ALIGNED>
-static __global__ __launch_bounds__(kWG) void k_moments(StatsArgs a) {
-    __shared__ Tabs<1, 8, 4> s_tab;
-    __shared__ double s_red[kWG / 64][10];
+static __global__ __launch_bounds__(kSweepThreads, 4) void k_moments(StatsArgs a) {
+    __shared__ RowTab s_tab;
+    __shared__ double s_red[kSweepThreads / 64][10];
     s_tab.fill();
     __syncthreads();
+    const TabReader T = TabReader::make(s_tab);
     const int tile = blockIdx.x / a.parts, part = blockIdx.x % a.parts;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     const uint8_t* src = a.rgb + (size_t)tile * a.P * 3;
     uint32_t* samp = a.sample + (size_t)tile * a.n_sample;
-    const int nch = (a.P + 3) >> 2;
-    const int span = (nch + a.parts - 1) / a.parts;
-    const int c0 = part * span, c1 = min(nch, c0 + span);
+    int c0, c1;
+    part_range((a.P + 3) >> 2, a.parts, part, c0, c1);
     Moments mo;
-    auto store = [&](uint32_t b, uint32_t v) { samp[b] = v; };
-    moments_sweep<ALIGNED>(src, a.P, c0, c1, tid, kWG, s_tab, a.y_lim, a.stride_log2, store, mo);
+    uint32_t n_tissue = 0;
+    moments_sweep<ALIGNED>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, a.stride_log2, samp, mo, n_tissue);
     double v[10];
-    mo.to_array(v);
+    mo.to_array(v, n_tissue, lane);
 #pragma unroll
     for (int i = 0; i < 10; ++i) v[i] = wave_sum(v[i]);
-    if ((tid & 63) == 0)
+    if (lane == 0)
         for (int i = 0; i < 10; ++i) s_red[tid >> 6][i] = v[i];
     __syncthreads();
     if (tid < 10) {
         double t = 0;
-        for (int w = 0; w < kWG / 64; ++w) t += s_red[w][tid];
+        for (int w = 0; w < kSweepThreads / 64; ++w) t += s_red[w][tid];
         a.partials[((size_t)tile * a.parts + part) * 10 + tid] = t;
     }
 }
@@ -1125,7 +1118,7 @@ __device__ __forceinline__ void conc_brackets(SampleConcKey key, int n_sample, f
 }
 
 static __global__ __launch_bounds__(kFinishThreads) void k_finish_moments(StatsArgs a) {
-    __shared__ Tabs<1, 1, 0> s_tab;
+    __shared__ SmallTab s_tab;
     __shared__ SelScratch S;
     __shared__ double s_sum[10];
     __shared__ float s_V[6];
@@ -1150,48 +1143,48 @@ static __global__ __launch_bounds__(kFinishThreads) void k_finish_moments(StatsA
     __syncthreads();
     SampleAngleKey key;
     key.sample = a.sample + (size_t)tile * a.n_sample;
-    key.tab = s_tab.view();
+    key.tab = view_of(s_tab);
     for (int i = 0; i < 6; ++i) key.V[i] = s_V[i];
-    key.stride_log2 = a.stride_log2;
+    key.cps_log2 = a.stride_log2 - 2;
     key.P = a.P;
+    key.ylimf = a.ylimf;
     float lo[2], hi[2];
     angle_brackets(key, a.n_sample, a.pct, lo, hi, S);
     if (tid == 0) { st.lo[0] = lo[0]; st.hi[0] = hi[0]; st.lo[1] = lo[1]; st.hi[1] = hi[1]; }
 }
 
 template <int STAGE, bool ALIGNED>
-static __global__ __launch_bounds__(kWG) void k_select(StatsArgs a) {
-    __shared__ Tabs<8, 8, 0> s_tab;
-    __shared__ uint32_t s_stage[kWG / 64][kStageWave];
-    s_tab.fill();
+static __global__ __launch_bounds__(kSweepThreads, 4) void k_select(StatsArgs a) {
+    __shared__ RowTab s_tab;
+    __shared__ uint32_t s_stage[kSweepThreads / 64][kStageWave];
     const int tile = blockIdx.x / a.parts, part = blockIdx.x % a.parts;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     TileState& st = a.state[tile];
     if (st.status != SL_TILE_OK) return;                                   // block-uniform
+    s_tab.fill();
+    const TabReader T = TabReader::make(s_tab);
     SelConsts K;
     if (STAGE == kStageAngle) {
-        for (int i = 0; i < 6; ++i) K.V[i] = uni(st.Vf[i]);
+        for (int i = 0; i < 6; ++i) K.V[i] = in_vgpr(st.Vf[i]);
         K.L.g12 = 0.0f;
     } else {
         lasso_consts(st.M, a.lam, K.L);
-        uni(K.L);
+        vgpr(K.L);
     }
     K.lo0 = uni(st.lo[0]); K.hi0 = uni(st.hi[0]); K.lo1 = uni(st.lo[1]); K.hi1 = uni(st.hi[1]);
     __syncthreads();
     const uint8_t* src = a.rgb + (size_t)tile * a.P * 3;
-    const int nch = (a.P + 3) >> 2;
-    const int span = (nch + a.parts - 1) / a.parts;
-    const int c0 = part * span, c1 = min(nch, c0 + span);
+    int c0, c1;
+    part_range((a.P + 3) >> 2, a.parts, part, c0, c1);
     RawSink sink{s_stage[wave], 0u, a.raw + (size_t)tile * a.cap_raw, &st.n_raw, &st.overflow, (uint32_t)a.cap_raw};
     uint32_t n_plain = 0;
-    select_sweep<STAGE, ALIGNED>(src, a.P, c0, c1, tid, kWG, s_tab, a.y_lim, K, sink, n_plain);
+    select_sweep<STAGE, ALIGNED>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, K, sink, n_plain);
     sink.flush(lane);
-    for (int o = 32; o > 0; o >>= 1) n_plain += __shfl_xor((int)n_plain, o, 64);
     if (lane == 0 && n_plain) atomicAdd(&st.n_plain, n_plain);
 }
 
 static __global__ __launch_bounds__(kFinishThreads) void k_finish_angle(StatsArgs a) {
-    __shared__ Tabs<1, 1, 0> s_tab;
+    __shared__ SmallTab s_tab;
     __shared__ SelScratch S;
     __shared__ float s_res[4];
     __shared__ LassoK s_L;
@@ -1205,9 +1198,9 @@ static __global__ __launch_bounds__(kFinishThreads) void k_finish_angle(StatsArg
     __syncthreads();
     const uint8_t* src = a.rgb + (size_t)tile * a.P * 3;
     AngleTileKey tkey;
-    tkey.src = src; tkey.tab = s_tab.view(); tkey.y_lim = a.y_lim;
+    tkey.src = src; tkey.tab = view_of(s_tab); tkey.ylimf = a.ylimf;
     RawAngleKey2 rkey;
-    rkey.raw = a.raw + (size_t)tile * a.cap_raw; rkey.tab = s_tab.view();
+    rkey.raw = a.raw + (size_t)tile * a.cap_raw; rkey.tab = view_of(s_tab);
     for (int i = 0; i < 6; ++i) { tkey.V[i] = st.Vf[i]; rkey.V[i] = st.Vf[i]; }
     const uint32_t T = (uint32_t)st.n_tissue;
     long long k[2];
@@ -1243,9 +1236,9 @@ static __global__ __launch_bounds__(kFinishThreads) void k_finish_angle(StatsArg
     __syncthreads();
     SampleConcKey ckey;
     ckey.sample = a.sample + (size_t)tile * a.n_sample;
-    ckey.tab = s_tab.view();
+    ckey.tab = view_of(s_tab);
     ckey.L = s_L;
-    ckey.stride_log2 = a.stride_log2;
+    ckey.cps_log2 = a.stride_log2 - 2;
     ckey.P = a.P;
     ckey.col = 0;
     float lo[2], hi[2];
@@ -1255,7 +1248,7 @@ static __global__ __launch_bounds__(kFinishThreads) void k_finish_angle(StatsArg
 
 static __global__ __launch_bounds__(kFinishThreads) void k_finish_conc(StatsArgs a, double* M_out, double* maxC_out,
                                                                        int32_t* status_out, int tile0) {
-    __shared__ Tabs<1, 1, 0> s_tab;
+    __shared__ SmallTab s_tab;
     __shared__ SelScratch S;
     __shared__ float s_res[4];
     __shared__ LassoK s_L;
@@ -1272,10 +1265,10 @@ static __global__ __launch_bounds__(kFinishThreads) void k_finish_conc(StatsArgs
         int fallbacks = 0;
         ConcTileKey tkey;
         tkey.src = a.rgb + (size_t)tile * a.P * 3;
-        tkey.tab = s_tab.view();
+        tkey.tab = view_of(s_tab);
         tkey.L = s_L;
         RawConcKey2 rkey;
-        rkey.raw = a.raw + (size_t)tile * a.cap_raw; rkey.tab = s_tab.view(); rkey.L = s_L;
+        rkey.raw = a.raw + (size_t)tile * a.cap_raw; rkey.tab = view_of(s_tab); rkey.L = s_L;
         const bool complete = st.n_raw <= (uint32_t)a.cap_raw && st.overflow == 0;
         const uint32_t n_raw = st.n_raw < (uint32_t)a.cap_raw ? st.n_raw : (uint32_t)a.cap_raw;
         float* cand0 = a.cand + ((size_t)tile * 2 + 0) * a.cap_list;
@@ -1316,7 +1309,7 @@ struct FusedArgs {
     int P;
     int stride_log2;
     int n_sample;
-    uint32_t y_lim;
+    float ylimf;
     double lam;
     double pct;
     const double* M_tgt;     // transform only
@@ -1330,6 +1323,7 @@ struct FusedArgs {
     int32_t* status_out;     // [n_tiles]
     int32_t* diag_out;       // [n_tiles] fallbacks (may be NULL)
     long long* phase_clock;  // [n_tiles][8] wall_clock64() at phase boundaries (development aid, may be NULL)
+    int debug_stop;          // development aid: leave the tile after phase marker debug_stop-1 (0 = run everything)
     // Vahadane
     double dl_lambda;
     double dl_tol;
@@ -1338,8 +1332,8 @@ struct FusedArgs {
 };
 
 struct FusedShared {
-    TabsFG<16, 4> tab;       // 32 + 8 KB
-    uint32_t stage[kFusedThreads / 64][kStageWave];     // 16 KB
+    RowTab tab;              // 64 KB, first member: LDS offset 0
+    uint32_t stage[kFusedThreads / 64][kStageWave];     // 8 KB
     unsigned int n_plain, n_raw, overflow;
     SelScratch S;
     double red[kFusedThreads / 64][32];
@@ -1366,6 +1360,7 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     sh.tab.fill();
     __syncthreads();
+    const TabReader T = TabReader::make(sh.tab);
     const int nch = (a.P + 3) >> 2;
     uint32_t* samp = a.sample + (size_t)blockIdx.x * a.n_sample;
     uint32_t* rawl = a.raw + (size_t)blockIdx.x * a.cap_raw;
@@ -1378,9 +1373,8 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
         K.lo0 = uni(sh.lo[0]); K.hi0 = uni(sh.hi[0]); K.lo1 = uni(sh.lo[1]); K.hi1 = uni(sh.hi[1]);
         RawSink sink{sh.stage[wave], 0u, rawl, &sh.n_raw, &sh.overflow, (uint32_t)a.cap_raw};
         uint32_t n_plain = 0;
-        select_sweep<STAGE, ALIGNED>(src, a.P, 0, nch, tid, kFusedThreads, sh.tab, a.y_lim, K, sink, n_plain);
+        select_sweep<STAGE, ALIGNED>(src, a.P, 0, nch, tid, kFusedThreads, T, a.ylimf, K, sink, n_plain);
         sink.flush(lane);
-        for (int o = 32; o > 0; o >>= 1) n_plain += __shfl_xor((int)n_plain, o, 64);
         if (lane == 0 && n_plain) atomicAdd(&sh.n_plain, n_plain);
         __threadfence_block();
         __syncthreads();
@@ -1391,17 +1385,17 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
         const uint8_t* src = a.rgb + (size_t)tile * nbytes;
         int fallbacks = 0;
         int sweeps_used = 0;
-#define SL_PHASE(i) do { if (a.phase_clock && tid == 0) a.phase_clock[(size_t)tile * 8 + (i)] = wall_clock64(); } while (0)
+#define SL_PHASE(i) { if (a.phase_clock && tid == 0) a.phase_clock[(size_t)tile * 8 + (i)] = wall_clock64(); if (a.debug_stop == (i) + 1) { __syncthreads(); continue; } }
         SL_PHASE(0);
-        auto store = [&](uint32_t b, uint32_t v) { samp[b] = v; };
 
         if (METHOD == kMethodMacenko) {
             // ---------------- sweep 1: moments + sample
             {
                 Moments mo;
-                moments_sweep<ALIGNED>(src, a.P, 0, nch, tid, kFusedThreads, sh.tab, a.y_lim, a.stride_log2, store, mo);
+                uint32_t n_tissue = 0;
+                moments_sweep<ALIGNED>(src, a.P, 0, nch, tid, kFusedThreads, T, a.ylimf, a.stride_log2, samp, mo, n_tissue);
                 double v[10];
-                mo.to_array(v);
+                mo.to_array(v, n_tissue, lane);
 #pragma unroll
                 for (int i = 0; i < 10; ++i) v[i] = wave_sum(v[i]);
                 if (lane == 0)
@@ -1427,7 +1421,7 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
             if (sh.status == SL_TILE_OK) {                                    // block-uniform
                 {
                     SampleAngleKey key;
-                    key.sample = samp; key.tab = sh.tab.view(); key.stride_log2 = a.stride_log2; key.P = a.P;
+                    key.sample = samp; key.tab = view_of(sh.tab); key.cps_log2 = a.stride_log2 - 2; key.P = a.P; key.ylimf = a.ylimf;
                     for (int i = 0; i < 6; ++i) key.V[i] = sh.Vf[i];
                     float lo[2], hi[2];
                     angle_brackets(key, a.n_sample, a.pct, lo, hi, sh.S);
@@ -1438,7 +1432,7 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
                 // ---------------- sweep 2: angle select
                 {
                     SelConsts K;
-                    for (int i = 0; i < 6; ++i) K.V[i] = uni(sh.Vf[i]);
+                    for (int i = 0; i < 6; ++i) K.V[i] = in_vgpr(sh.Vf[i]);
                     K.L.g12 = 0.0f;
                     run_select(std::integral_constant<int, kStageAngle>{}, src, K);
                 }
@@ -1450,9 +1444,9 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
                 percentile_pos((double)T, 100.0 - a.pct, k[0], gfrac[0]);
                 percentile_pos((double)T, a.pct, k[1], gfrac[1]);
                 AngleTileKey tkey;
-                tkey.src = src; tkey.tab = sh.tab.view(); tkey.y_lim = a.y_lim;
+                tkey.src = src; tkey.tab = view_of(sh.tab); tkey.ylimf = a.ylimf;
                 RawAngleKey2 rkey;
-                rkey.raw = rawl; rkey.tab = sh.tab.view();
+                rkey.raw = rawl; rkey.tab = view_of(sh.tab);
                 for (int i = 0; i < 6; ++i) { tkey.V[i] = sh.Vf[i]; rkey.V[i] = sh.Vf[i]; }
                 const bool complete = sh.n_raw <= (uint32_t)a.cap_raw && sh.overflow == 0;
                 const uint32_t n_raw = sh.n_raw < (uint32_t)a.cap_raw ? sh.n_raw : (uint32_t)a.cap_raw;
@@ -1499,14 +1493,14 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
                 ClsAcc acc[3];
                 uint32_t n_tissue = 0;
                 if (stage == 0)
-                    dict_sweep<ALIGNED, true>(src, a.P, 0, nch, tid, kFusedThreads, sh.tab, a.y_lim, a.stride_log2, Ld, store, acc, n_tissue);
+                    dict_sweep<ALIGNED, true>(src, a.P, 0, nch, tid, kFusedThreads, T, a.ylimf, a.stride_log2, Ld, samp, acc, n_tissue);
                 else if (stage == 1)
-                    dict_sweep_sample(samp, a.n_sample, a.stride_log2, a.P, tid, kFusedThreads, sh.tab, Ld, acc, n_tissue);
+                    dict_sweep_sample(samp, a.n_sample, a.stride_log2, a.P, tid, kFusedThreads, T, a.ylimf, Ld, acc, n_tissue);
                 else
-                    dict_sweep<ALIGNED, false>(src, a.P, 0, nch, tid, kFusedThreads, sh.tab, a.y_lim, a.stride_log2, Ld, store, acc, n_tissue);
+                    dict_sweep<ALIGNED, false>(src, a.P, 0, nch, tid, kFusedThreads, T, a.ylimf, a.stride_log2, Ld, samp, acc, n_tissue);
                 double v[31];
                 acc[0].to_array(v); acc[1].to_array(v + 10); acc[2].to_array(v + 20);
-                v[30] = (double)n_tissue;
+                v[30] = lane == 0 ? (double)n_tissue : 0.0;      // n_tissue is wave-uniform
 #pragma unroll
                 for (int i = 0; i < 31; ++i) v[i] = wave_sum(v[i]);
                 __syncthreads();                                             // previous iteration's readers of sh.red are done
@@ -1586,7 +1580,7 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
             // ---------------- concentration brackets from the sample
             {
                 SampleConcKey ckey;
-                ckey.sample = samp; ckey.tab = sh.tab.view(); ckey.L = sh.L; ckey.stride_log2 = a.stride_log2;
+                ckey.sample = samp; ckey.tab = view_of(sh.tab); ckey.L = sh.L; ckey.cps_log2 = a.stride_log2 - 2;
                 ckey.P = a.P; ckey.col = 0;
                 float lo[2], hi[2];
                 conc_brackets(ckey, a.n_sample, lo, hi, sh.S);
@@ -1598,7 +1592,7 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
             {
                 SelConsts K;
                 K.L = sh.L;
-                uni(K.L);
+                vgpr(K.L);
                 run_select(std::integral_constant<int, kStageConc>{}, src, K);
             }
             SL_PHASE(5);
@@ -1608,9 +1602,9 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
                 double gfrac;
                 percentile_pos((double)a.P, 99.0, k, gfrac);
                 ConcTileKey tkey;
-                tkey.src = src; tkey.tab = sh.tab.view(); tkey.L = sh.L;
+                tkey.src = src; tkey.tab = view_of(sh.tab); tkey.L = sh.L;
                 RawConcKey2 rkey;
-                rkey.raw = rawl; rkey.tab = sh.tab.view(); rkey.L = sh.L;
+                rkey.raw = rawl; rkey.tab = view_of(sh.tab); rkey.L = sh.L;
                 const bool complete = sh.n_raw <= (uint32_t)a.cap_raw && sh.overflow == 0;
                 const uint32_t n_raw = sh.n_raw < (uint32_t)a.cap_raw ? sh.n_raw : (uint32_t)a.cap_raw;
                 const float los[2] = {sh.lo[0], sh.lo[1]}, his[2] = {sh.hi[0], sh.hi[1]};
@@ -1649,44 +1643,35 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
             if (bad) {
                 for (int c = tid; c < nch; c += kFusedThreads) store_chunk<ALIGNED>(dst, nbytes, c, load_chunk<ALIGNED>(src, nbytes, c));
             } else {
-                LassoK L = sh.L;
-                uni(L);
-                ReconK R;
+                ApplyK K;
+                apply_consts(sh.M, sh.maxC, a.M_tgt, a.maxC_tgt, a.lam, K);
+                auto sweep = [&](auto fast_tag) {
+                    constexpr bool FAST = decltype(fast_tag)::value;
+                    for (int c = tid; c < nch; c += kFusedThreads * kU) {
+                        Chunk in[kU];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const double ratio = a.maxC_tgt[i] / sh.maxC[i];                       // normalizer.py:48
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) R.q[i][c] = uni((float)(-1.4426950408889634 * ratio * a.M_tgt[3 * i + c]));
-                }
-                for (int c = tid; c < nch; c += kFusedThreads * kU) {
-                    Chunk in[kU];
-#pragma unroll
-                    for (int u = 0; u < kU; ++u) {
-                        const int cc = c + u * kFusedThreads;
-                        in[u] = cc < nch ? load_chunk<ALIGNED>(src, nbytes, cc) : Chunk{0, 0, 0};
-                    }
-#pragma unroll
-                    for (int u = 0; u < kU; ++u) {
-                        const int cc = c + u * kFusedThreads;
-                        uint32_t ob[12];
-#pragma unroll
-                        for (int px = 0; px < 4; ++px) {
-                            const float x = sh.tab.odf(chunk_byte(in[u], 3 * px + 0), tid);
-                            const float y = sh.tab.odf(chunk_byte(in[u], 3 * px + 1), tid);
-                            const float z = sh.tab.odf(chunk_byte(in[u], 3 * px + 2), tid);
-                            float c1, c2, v[3];
-                            lasso2(L, x, y, z, c1, c2);
-                            recon_px<false>(R, c1, c2, v);
-#pragma unroll
-                            for (int ch = 0; ch < 3; ++ch) ob[3 * px + ch] = trunc_u8(v[ch]);
+                        for (int u = 0; u < kU; ++u) {
+                            const int cc = c + u * kFusedThreads;
+                            in[u] = load_chunk_clamped<ALIGNED>(src, nbytes, cc, nch);
                         }
-                        Chunk o;
-                        o.w0 = ob[0] | (ob[1] << 8) | (ob[2] << 16) | (ob[3] << 24);
-                        o.w1 = ob[4] | (ob[5] << 8) | (ob[6] << 16) | (ob[7] << 24);
-                        o.w2 = ob[8] | (ob[9] << 8) | (ob[10] << 16) | (ob[11] << 24);
-                        if (cc < nch) store_chunk<ALIGNED>(dst, nbytes, cc, o);
+#pragma unroll
+                        for (int u = 0; u < kU; ++u) {
+                            const int cc = c + u * kFusedThreads;
+                            float t[12];
+#pragma unroll
+                            for (int px = 0; px < 4; ++px) {
+                                const float x = T.odf(T.addr(in[u], 3 * px)), y = T.odf(T.addr(in[u], 3 * px + 1)),
+                                            z = T.odf(T.addr(in[u], 3 * px + 2));
+                                float v[3];
+                                apply_px<FAST>(K, x, y, z, v);
+                                t[3 * px] = v[0]; t[3 * px + 1] = v[1]; t[3 * px + 2] = v[2];
+                            }
+                            const Chunk o = FAST ? pack_trunc_fast(t) : pack_trunc_general(t);
+                            if (cc < nch) store_chunk<ALIGNED>(dst, nbytes, cc, o);
+                        }
                     }
-                }
+                };
+                if (K.fast) sweep(std::true_type{}); else sweep(std::false_type{});
             }
         }
         __syncthreads();     // sh.* is reused by the next tile
