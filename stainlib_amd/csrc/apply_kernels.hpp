@@ -149,6 +149,55 @@ __device__ __forceinline__ Chunk pack_trunc_general(const float (&t)[12]) {
     return o;
 }
 
+// The apply sweep over chunks [c0, c1) of one tile with `nthreads` cooperating threads, table values from the
+// row table.  Two chunks per trip; the next trip's chunks are in flight during the current one and the 12 table
+// gathers of a chunk are issued one chunk ahead of its arithmetic.
+template <bool ALIGNED, bool FAST>
+__device__ __forceinline__ void apply_sweep(const uint8_t* src, uint8_t* dst, int P, int c0, int c1, int t, int nthreads,
+                                            const TabReader& T, const ApplyK& K) {
+    const size_t nbytes = (size_t)P * 3;
+    struct G { float v[12]; };
+    auto fetch = [&](int cc) { return load_chunk_clamped<ALIGNED>(src, nbytes, cc, c1); };
+    auto gather = [&](const Chunk& ch) {
+        G g;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) g.v[i] = T.odf(T.addr(ch, i));
+        return g;
+    };
+    auto compute = [&](const G& g, int cc) {
+        float tv[12];
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            float v[3];
+            apply_px<FAST>(K, g.v[3 * px], g.v[3 * px + 1], g.v[3 * px + 2], v);
+            tv[3 * px] = v[0]; tv[3 * px + 1] = v[1]; tv[3 * px + 2] = v[2];
+        }
+        const Chunk o = FAST ? pack_trunc_fast(tv) : pack_trunc_general(tv);
+        if (cc < c1) store_chunk<ALIGNED>(dst, nbytes, cc, o);
+    };
+    constexpr int N = 4;                                       // chunks per lane and trip; the next trip is in flight
+    Chunk cur[N], nx[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) { cur[k] = fetch(c0 + t + k * nthreads); nx[k] = fetch(c0 + t + (N + k) * nthreads); }
+    G g[2];
+    g[0] = gather(cur[0]);
+    for (int c = c0 + t; c < c1; c += N * nthreads) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            if (k + 1 < N) {
+                g[(k + 1) & 1] = gather(cur[k + 1]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < N; ++j) { cur[j] = nx[j]; nx[j] = fetch(c + (2 * N + j) * nthreads); }
+                g[0] = gather(cur[0]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            compute(g[k & 1], c + k * nthreads);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 constexpr int kU = 4;       // chunks in flight per lane per trip (plain sweeps: 4 x 12 B loads issued back to back)
 constexpr int kUApply = 2;  // k_apply: 2 chunks per trip with the following trip prefetched
 

@@ -13,7 +13,7 @@ namespace {
 
 constexpr size_t kGroupBytes = 96u << 20;   // uint8 bytes of one tile group (fits the 256 MiB MALL with output + slack)
 
-constexpr int kFusedMinTiles = 160;         // measured crossover (tools/crossover.py): below it one launch per phase wins
+constexpr int kFusedMinTiles = 144;         // measured crossover (tools/crossover.py): below it one launch per phase wins
 constexpr int kFusedMaxGrid = 512;          // 2 resident 1024-thread workgroups per CU x 256 CUs
 
 struct Layout {

@@ -44,6 +44,8 @@ constexpr int kMinCapList = 16384;  // exact-key bracket members per list after 
 constexpr int kFinishThreads = 1024;
 constexpr int kFusedThreads = 512;  // 2 resident workgroups per CU (<=128 VGPRs, <80 KB LDS each)
 constexpr int kSweepThreads = 512;  // sweep kernels of the one-launch-per-phase schedule (same occupancy: 64 KB table each)
+constexpr int kFusedTrip = 4;       // chunks per lane and sweep trip in the fused kernel (even)
+constexpr int kPhaseTrip = 2;       // ... in the one-sweep kernels (32 Ki-pixel parts: 8 chunks per lane)
 constexpr int kStageWave = 256;     // per-wave LDS staging entries for raw candidates (8 KB per 8 waves)
 constexpr float kBracketZ = 6.0f;   // bracket half-width in standard deviations of the sample rank
 constexpr float kAngleMargin = 2e-5f;  // safety margin of the cheap pseudo-angle test (keys carry ~1e-7)
@@ -54,7 +56,7 @@ struct TileState {
     double Vd[6];            // V[c][k], c = channel, k = 0 (largest eigenvalue), 1 (second)
     float Vf[6];
     float lo[2], hi[2];      // brackets of the current selection stage
-    unsigned int n_plain;    // pixels the sweep classified without collecting them
+    unsigned int pad0_;
     unsigned int n_raw;      // raw candidates appended (may exceed cap_raw => overflow)
     unsigned int overflow;   // a wave's staging buffer overflowed: the collected list is incomplete
     unsigned int pad_;
@@ -565,38 +567,76 @@ __device__ __forceinline__ void sample_row(const Chunk& ch, int row0, int cc, in
     }
 }
 
+// Table values of two pixels (sweep 1 works in half chunks: 6 x ds_read_b128 = 24 VGPRs per stage)
+struct HalfGather { TabEntry e[6]; };
+
 // sweep 1 over chunks [c0, c1) with `nthreads` cooperating threads (thread index t); c0 must be a multiple of 64.
-// n_tissue is wave-uniform (a scalar popcount per pixel row).  ~13 slow-pipe + 3 fast-pipe instructions per pixel.
-template <bool ALIGNED>
+// n_tissue is wave-uniform (a scalar popcount per pixel row).  Per pixel: 4 slow-pipe + 9 binary64 + 3 fast-pipe
+// instructions.  The LDS gathers run one stage (two pixels) ahead of the arithmetic: a wave has only three
+// partners on its SIMD to hide the ~100-cycle gather latency, so it must overlap its own.
+template <bool ALIGNED, int kTrip, class TR>
 __device__ __forceinline__ void moments_sweep(const uint8_t* src, int P, int c0, int c1, int t, int nthreads,
-                                              const TabReader& T, float ylimf, int stride_log2, uint32_t* samp,
+                                              const TR& T, float ylimf, int stride_log2, uint32_t* samp,
                                               Moments& mo, uint32_t& n_tissue) {
     const size_t nbytes = (size_t)P * 3;
     const int lane = t & 63;
     const int cps_log2 = stride_log2 - 2;          // chunks per sampling block
     const int w0 = __builtin_amdgcn_readfirstlane(c0 + (t & ~63));
     auto fetch = [&](int cc) { return load_chunk_clamped<ALIGNED>(src, nbytes, cc, c1); };   // dead lanes: see `live`
-    Chunk nx[2] = {fetch(w0 + lane), fetch(w0 + lane + nthreads)};
-    for (int cb = w0; cb < c1; cb += nthreads * 2) {
-        const Chunk in[2] = {nx[0], nx[1]};
-        nx[0] = fetch(cb + lane + 2 * nthreads);   // the next trip's chunks are in flight during this one
-        nx[1] = fetch(cb + lane + 3 * nthreads);
+    auto gather = [&](const Chunk& ch, int half) {
+        HalfGather g;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int row0 = cb + u * nthreads, cc = row0 + lane;
-            sample_row<ALIGNED>(in[u], row0, cc, c1, P, cps_log2, samp);
-            const bool live = cc < c1;
+        for (int i = 0; i < 6; ++i) g.e[i] = T.entry(T.addr(ch, 6 * half + i));
+        return g;
+    };
+    // TAIL = false: every lane of the trip holds a chunk of in-range pixels, so the tissue predicate is the bare
+    // compare (a ballot of an AND of predicates costs two extra vector instructions, see tools/ubench notes)
+    auto compute = [&](auto tail_tag, const HalfGather& g, int cc, int half) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
 #pragma unroll
-            for (int px = 0; px < 4; ++px) {
-                const TabEntry er = T.entry(T.addr(in[u], 3 * px)), eg = T.entry(T.addr(in[u], 3 * px + 1)),
-                               eb = T.entry(T.addr(in[u], 3 * px + 2));
-                bool tissue = live & is_tissue_f(er.gam, eg.gam, eb.gam, ylimf);
-                if (!ALIGNED) tissue = tissue & ((size_t)cc * 4 + px < (size_t)P);
-                n_tissue += (uint32_t)__popcll(__ballot(tissue));
-                if (tissue) mo.add(er.od, eg.od, eb.od);             // 9 binary64 ops under the exec mask, no select
+        for (int p = 0; p < 2; ++p) {
+            const TabEntry &er = g.e[3 * p], &eg = g.e[3 * p + 1], &eb = g.e[3 * p + 2];
+            const bool tc = is_tissue_f(er.gam, eg.gam, eb.gam, ylimf);
+            if (!TAIL) {
+                n_tissue += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(tc));
+                if (tc) mo.add(er.od, eg.od, eb.od);             // 9 binary64 ops under the exec mask, no select
+            } else {
+                const bool inb = (cc < c1) & (ALIGNED | ((size_t)cc * 4 + 2 * half + p < (size_t)P));
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(tc) & __builtin_amdgcn_ballot_w64(inb);
+                n_tissue += (uint32_t)__popcll(m);
+                if (tc & inb) mo.add(er.od, eg.od, eb.od);
             }
         }
-    }
+    };
+    // kTrip chunks per lane and trip, the next trip's chunks already requested: 2 x kTrip x 12 B in flight per
+    // lane -- with 16 waves per CU it takes that much to cover the HBM latency at full rate (measured)
+    Chunk cur[kTrip], nx[kTrip];
+#pragma unroll
+    for (int k = 0; k < kTrip; ++k) { cur[k] = fetch(w0 + lane + k * nthreads); nx[k] = fetch(w0 + lane + (kTrip + k) * nthreads); }
+    HalfGather g[2];
+    g[0] = gather(cur[0], 0);
+    auto trip = [&](auto tail_tag, int cb) {
+#pragma unroll
+        for (int k = 0; k < kTrip; ++k) sample_row<ALIGNED>(cur[k], cb + k * nthreads, cb + k * nthreads + lane, c1, P, cps_log2, samp);
+#pragma unroll
+        for (int st = 0; st < 2 * kTrip; ++st) {             // stage = half chunk; gathers run one stage ahead
+            const int k = st >> 1, half = st & 1;
+            if (st + 1 < 2 * kTrip) {
+                g[(st + 1) & 1] = gather(cur[(st + 1) >> 1], (st + 1) & 1);
+            } else {
+#pragma unroll
+                for (int j = 0; j < kTrip; ++j) { cur[j] = nx[j]; nx[j] = fetch(cb + lane + (2 * kTrip + j) * nthreads); }
+                g[0] = gather(cur[0], 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            compute(tail_tag, g[st & 1], cb + k * nthreads + lane, half);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    const int lim = ALIGNED ? c1 : min(c1, P >> 2);          // chunks made of in-range pixels only
+    int cb = w0;
+    for (; cb + (kTrip - 1) * nthreads + 64 <= lim; cb += nthreads * kTrip) trip(std::false_type{}, cb);
+    if (cb < c1) trip(std::true_type{}, cb);                    // at most one ragged trip per wave
 }
 
 enum { kStageAngle = 0, kStageConc = 1 };
@@ -615,11 +655,15 @@ struct SelConsts {          // everything VGPR-resident (in_vgpr)
 //     division as  y > (hi0+eps) d  and  y < (lo1-eps) d  with d = x + |y|, x > 0
 //   concentration stage (g12 >= 0): c_i <= max(0, a_i) exactly, so  a1 < lo0 and a2 < lo1  =>  both
 //     keys lie below their brackets (needs lo > 0; otherwise nothing is plain)
-// n_plain is wave-uniform.  c0 must be a multiple of 64.
-template <int STAGE, bool ALIGNED, class Sink>
+// The plain pixels are not even counted: their number is (valid pixels of the stage) - (raw candidates).
+// c0 must be a multiple of 64.  The LDS gathers of a chunk are issued one chunk ahead of its arithmetic.
+template <int STAGE> struct SelGather;
+template <> struct SelGather<kStageAngle> { float2 v[12]; };      // {gamma, od32} per byte
+template <> struct SelGather<kStageConc> { float v[12]; };        // od32 per byte
+
+template <int STAGE, bool ALIGNED, int kTrip, class TR, class Sink>
 __device__ __forceinline__ void select_sweep(const uint8_t* src, int P, int c0, int c1, int t, int nthreads,
-                                             const TabReader& T, float ylimf, const SelConsts& K, Sink& sink,
-                                             uint32_t& n_plain) {
+                                             const TR& T, float ylimf, const SelConsts& K, Sink& sink) {
     const size_t nbytes = (size_t)P * 3;
     const int lane = t & 63;
     // thresholds of the cheap tests
@@ -628,43 +672,72 @@ __device__ __forceinline__ void select_sweep(const uint8_t* src, int P, int c0, 
     const float clo0 = conc_ok ? K.lo0 : -INFINITY, clo1 = conc_ok ? K.lo1 : -INFINITY;
     const int w0 = __builtin_amdgcn_readfirstlane(c0 + (t & ~63));
     auto fetch = [&](int cc) { return load_chunk_clamped<ALIGNED>(src, nbytes, cc, c1); };   // dead lanes: see `live`
-    Chunk nx[2] = {fetch(w0 + lane), fetch(w0 + lane + nthreads)};
-    for (int cb = w0; cb < c1; cb += nthreads * 2) {
-        const Chunk in[2] = {nx[0], nx[1]};
-        nx[0] = fetch(cb + lane + 2 * nthreads);
-        nx[1] = fetch(cb + lane + 3 * nthreads);
-        uint32_t raw[8];
-        bool flag[8];
+    auto gather = [&](const Chunk& ch) {
+        SelGather<STAGE> g;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int cc = cb + lane + u * nthreads;
-            const bool live = cc < c1;
-#pragma unroll
-            for (int px = 0; px < 4; ++px) {
-                const int j = u * 4 + px;
-                const uint32_t ar = T.addr(in[u], 3 * px), ag = T.addr(in[u], 3 * px + 1), ab = T.addr(in[u], 3 * px + 2);
-                bool valid = live, plain;
-                if (!ALIGNED) valid = valid & ((size_t)cc * 4 + px < (size_t)P);
-                if (STAGE == kStageAngle) {
-                    const float2 er = T.gam_odf(ar), eg = T.gam_odf(ag), eb = T.gam_odf(ab);
-                    valid = valid & is_tissue_f(er.x, eg.x, eb.x, ylimf);
-                    const float x = fmaf(K.V[4], eb.y, fmaf(K.V[2], eg.y, K.V[0] * er.y));
-                    const float y = fmaf(K.V[5], eb.y, fmaf(K.V[3], eg.y, K.V[1] * er.y));
-                    const float d = x + fabsf(y);
-                    const float t0 = fmaf(nhi0m, d, y), t1 = fmaf(nlo1m, d, y);
-                    plain = valid & (x > 0.0f) & (t0 > 0.0f) & (t1 < 0.0f);
-                } else {
-                    float a1, a2;
-                    lasso_interior(K.L, T.odf(ar), T.odf(ag), T.odf(ab), a1, a2);
-                    plain = valid & (a1 < clo0) & (a2 < clo1);
-                }
-                n_plain += (uint32_t)__popcll(__ballot(plain));
-                flag[j] = valid & !plain;
-                raw[j] = chunk_pixel(in[u], px);
-            }
+        for (int i = 0; i < 12; ++i) {
+            if constexpr (STAGE == kStageAngle) g.v[i] = T.gam_odf(T.addr(ch, i));
+            else g.v[i] = T.odf(T.addr(ch, i));
         }
-        sink.commit(flag, raw, lane);
-    }
+        return g;
+    };
+    auto compute = [&](auto tail_tag, const Chunk& ch, const SelGather<STAGE>& g, int cc) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            // flagged = valid and not provably plain.  The lane mask is assembled from ballots of BARE compares.
+            unsigned long long m;
+            bool mine;
+            if constexpr (STAGE == kStageAngle) {
+                const float2 er = g.v[3 * px], eg = g.v[3 * px + 1], eb = g.v[3 * px + 2];
+                const bool tc = is_tissue_f(er.x, eg.x, eb.x, ylimf);
+                const float x = fmaf(K.V[4], eb.y, fmaf(K.V[2], eg.y, K.V[0] * er.y));
+                const float y = fmaf(K.V[5], eb.y, fmaf(K.V[3], eg.y, K.V[1] * er.y));
+                const float d = x + fabsf(y);
+                const float t0 = fmaf(nhi0m, d, y), t1 = fmaf(nlo1m, d, y);
+                const bool pp = fminf(fminf(x, t0), -t1) > 0.0f;             // x > 0, y > hi0m d, y < lo1m d
+                m = __builtin_amdgcn_ballot_w64(tc) & ~__builtin_amdgcn_ballot_w64(pp);
+                mine = tc & !pp;
+            } else {
+                float a1, a2;
+                lasso_interior(K.L, g.v[3 * px], g.v[3 * px + 1], g.v[3 * px + 2], a1, a2);
+                const bool g1 = a1 >= clo0, g2 = a2 >= clo1;
+                m = __builtin_amdgcn_ballot_w64(g1) | __builtin_amdgcn_ballot_w64(g2);
+                mine = g1 | g2;
+            }
+            if (TAIL) {
+                const bool inb = (cc < c1) & (ALIGNED | ((size_t)cc * 4 + px < (size_t)P));
+                m &= __builtin_amdgcn_ballot_w64(inb);
+                mine = mine & inb;
+            }
+            sink.put(m, mine, ch, px, lane);
+        }
+    };
+    Chunk cur[kTrip], nx[kTrip];                             // see moments_sweep
+#pragma unroll
+    for (int k = 0; k < kTrip; ++k) { cur[k] = fetch(w0 + lane + k * nthreads); nx[k] = fetch(w0 + lane + (kTrip + k) * nthreads); }
+    SelGather<STAGE> g[2];
+    g[0] = gather(cur[0]);
+    auto trip = [&](auto tail_tag, int cb) {
+#pragma unroll
+        for (int k = 0; k < kTrip; ++k) {
+            const Chunk ch = cur[k];
+            if (k + 1 < kTrip) {
+                g[(k + 1) & 1] = gather(cur[k + 1]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < kTrip; ++j) { cur[j] = nx[j]; nx[j] = fetch(cb + lane + (2 * kTrip + j) * nthreads); }
+                g[0] = gather(cur[0]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            compute(tail_tag, ch, g[k & 1], cb + k * nthreads + lane);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    const int lim = ALIGNED ? c1 : min(c1, P >> 2);          // chunks made of in-range pixels only
+    int cb = w0;
+    for (; cb + (kTrip - 1) * nthreads + 64 <= lim; cb += nthreads * kTrip) trip(std::false_type{}, cb);
+    if (cb < c1) trip(std::true_type{}, cb);                    // at most one ragged trip per wave
 }
 
 // ---- key functors handed BY VALUE to the selection primitives ----
@@ -804,41 +877,39 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
 }
 
 // Raw candidates are staged per wave in LDS and written out in dense bursts; the tile's list head is
-// touched once per burst.  Positions come from a DPP prefix sum of the per-lane counts: no atomics, no
-// LDS round trip, the fill level stays in an SGPR.
+// touched once per burst.  Positions come from v_mbcnt on the row's lane mask: no atomics, no LDS round
+// trip, the fill level stays in an SGPR.
+// burst of a wave's staged candidates to the tile's list (cold: once per ~130 pixel rows; kept out of line so
+// that the eight call sites of a trip stay small)
+__device__ __noinline__ void raw_flush(const uint32_t* buf, uint32_t n, uint32_t* dst, unsigned int* head, uint32_t cap) {
+    const int lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(head, n);
+    base = __builtin_amdgcn_readfirstlane(base);
+    for (uint32_t i = lane; i < n; i += 64)
+        if (base + i < cap) dst[base + i] = buf[i];
+}
+
 struct RawSink {
     uint32_t* buf;              // LDS, this wave's kStageWave entries
     uint32_t n;                 // wave-uniform fill
     uint32_t* dst;              // global raw list of the tile
     unsigned int* head;         // list head (LDS in the fused kernel, global otherwise)
-    unsigned int* overflow;     // set when entries were lost (list incomplete => exact slow path)
+    unsigned int* overflow;     // (unused by this sink: an over-full list shows as head > cap)
     uint32_t cap;               // capacity of dst
-    __device__ __forceinline__ void flush(int lane) {
+    __device__ __forceinline__ void flush(int) {
         if (n == 0) return;
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(head, n);
-        base = __builtin_amdgcn_readfirstlane(base);
-        for (uint32_t i = lane; i < n; i += 64)
-            if (base + i < cap) dst[base + i] = buf[i];
+        raw_flush(buf, n, dst, head, cap);
         n = 0;
     }
-    __device__ __forceinline__ void commit(const bool (&f)[8], const uint32_t (&raw)[8], int lane) {
-        uint32_t cnt = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) cnt += f[j] ? 1u : 0u;
-        const uint32_t inc = wave_inclusive_scan(cnt);
-        const uint32_t total = __builtin_amdgcn_readlane(inc, 63);
-        if (total == 0) return;                                     // wave-uniform
-        if (n + total > (uint32_t)kStageWave) flush(lane);
-        if (total > (uint32_t)kStageWave) {                         // pathological trip: more than the buffer holds
-            if (lane == 0) *overflow = 1u;
-            return;
-        }
-        uint32_t pos = n + inc - cnt;
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (f[j]) buf[pos++] = raw[j];
-        n += total;
+    // one pixel row of the wave: m = lane mask of the flagged lanes (a wave-uniform value), mine = this lane's bit
+    __device__ __forceinline__ void put(unsigned long long m, bool mine, const Chunk& ch, int px, int lane) {
+        if (m == 0) return;                                         // wave-uniform: ~1 row in 7 has no candidate
+        const uint32_t cnt = (uint32_t)__popcll(m);
+        if (n + cnt > (uint32_t)kStageWave) flush(lane);            // a row holds <= 64 entries: always fits afterwards
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+        if (mine) buf[n + rank] = chunk_pixel(ch, px) & 0xffffffu;
+        n += cnt;
     }
 };
 
@@ -1087,7 +1158,7 @@ static __global__ __launch_bounds__(kSweepThreads, 4) void k_moments(StatsArgs a
     part_range((a.P + 3) >> 2, a.parts, part, c0, c1);
     Moments mo;
     uint32_t n_tissue = 0;
-    moments_sweep<ALIGNED>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, a.stride_log2, samp, mo, n_tissue);
+    moments_sweep<ALIGNED, kPhaseTrip>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, a.stride_log2, samp, mo, n_tissue);
     double v[10];
     mo.to_array(v, n_tissue, lane);
 #pragma unroll
@@ -1138,7 +1209,7 @@ static __global__ __launch_bounds__(kFinishThreads) void k_finish_moments(StatsA
         for (int i = 0; i < 6; ++i) { st.Vd[i] = Vd[i]; st.Vf[i] = Vf[i]; s_V[i] = Vf[i]; }
         st.n_tissue = s_sum[0];
         st.fallbacks = 0;
-        st.n_plain = 0; st.n_raw = 0; st.overflow = 0;
+        st.n_raw = 0; st.overflow = 0;
     }
     __syncthreads();
     SampleAngleKey key;
@@ -1177,10 +1248,8 @@ static __global__ __launch_bounds__(kSweepThreads, 4) void k_select(StatsArgs a)
     int c0, c1;
     part_range((a.P + 3) >> 2, a.parts, part, c0, c1);
     RawSink sink{s_stage[wave], 0u, a.raw + (size_t)tile * a.cap_raw, &st.n_raw, &st.overflow, (uint32_t)a.cap_raw};
-    uint32_t n_plain = 0;
-    select_sweep<STAGE, ALIGNED>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, K, sink, n_plain);
+    select_sweep<STAGE, ALIGNED, kPhaseTrip>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, K, sink);
     sink.flush(lane);
-    if (lane == 0 && n_plain) atomicAdd(&st.n_plain, n_plain);
 }
 
 static __global__ __launch_bounds__(kFinishThreads) void k_finish_angle(StatsArgs a) {
@@ -1214,7 +1283,8 @@ static __global__ __launch_bounds__(kFinishThreads) void k_finish_angle(StatsArg
     const float los[2] = {st.lo[0], st.lo[1]}, his[2] = {st.hi[0], st.hi[1]};
     uint32_t n_lt[2], n_in[2];
     wg_refine((int)n_raw, rkey, los, his, cand0, cand1, (uint32_t)a.cap_list, n_lt, n_in, S);
-    const long long base[2] = {0, (long long)st.n_plain};        // plain pixels sit between the two brackets
+    // plain pixels (tissue pixels that were not collected) sit between the two brackets
+    const long long base[2] = {0, (long long)T - (long long)st.n_raw};
     int fallbacks = 0;
     for (int li = 0; li < 2; ++li) {
         float xa, xb;
@@ -1231,7 +1301,7 @@ static __global__ __launch_bounds__(kFinishThreads) void k_finish_angle(StatsArg
         LassoK L;
         lasso_consts(M, a.lam, L);
         s_L = L;
-        st.n_plain = 0; st.n_raw = 0; st.overflow = 0;
+        st.n_raw = 0; st.overflow = 0;
     }
     __syncthreads();
     SampleConcKey ckey;
@@ -1279,7 +1349,7 @@ static __global__ __launch_bounds__(kFinishThreads) void k_finish_conc(StatsArgs
         for (int col = 0; col < 2; ++col) {
             tkey.col = col;
             float xa, xb;
-            stage_order_stats(col ? cand1 : cand0, n_in[col], (uint32_t)a.cap_list, complete, los[col], his[col], (long long)st.n_plain + n_lt[col],
+            stage_order_stats(col ? cand1 : cand0, n_in[col], (uint32_t)a.cap_list, complete, los[col], his[col], (long long)a.P - (long long)st.n_raw + n_lt[col],
                               a.P, tkey, (uint32_t)a.P, k, xa, xb, fallbacks, S);
             if (tid == 0) { s_res[2 * col] = xa; s_res[2 * col + 1] = xb; }
             __syncthreads();
@@ -1334,7 +1404,7 @@ struct FusedArgs {
 struct FusedShared {
     RowTab tab;              // 64 KB, first member: LDS offset 0
     uint32_t stage[kFusedThreads / 64][kStageWave];     // 8 KB
-    unsigned int n_plain, n_raw, overflow;
+    unsigned int n_raw, overflow;
     SelScratch S;
     double red[kFusedThreads / 64][32];
     double sum[32];
@@ -1372,10 +1442,8 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
         constexpr int STAGE = decltype(stage_tag)::value;
         K.lo0 = uni(sh.lo[0]); K.hi0 = uni(sh.hi[0]); K.lo1 = uni(sh.lo[1]); K.hi1 = uni(sh.hi[1]);
         RawSink sink{sh.stage[wave], 0u, rawl, &sh.n_raw, &sh.overflow, (uint32_t)a.cap_raw};
-        uint32_t n_plain = 0;
-        select_sweep<STAGE, ALIGNED>(src, a.P, 0, nch, tid, kFusedThreads, T, a.ylimf, K, sink, n_plain);
+        select_sweep<STAGE, ALIGNED, kFusedTrip>(src, a.P, 0, nch, tid, kFusedThreads, T, a.ylimf, K, sink);
         sink.flush(lane);
-        if (lane == 0 && n_plain) atomicAdd(&sh.n_plain, n_plain);
         __threadfence_block();
         __syncthreads();
     };
@@ -1393,7 +1461,7 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
             {
                 Moments mo;
                 uint32_t n_tissue = 0;
-                moments_sweep<ALIGNED>(src, a.P, 0, nch, tid, kFusedThreads, T, a.ylimf, a.stride_log2, samp, mo, n_tissue);
+                moments_sweep<ALIGNED, kFusedTrip>(src, a.P, 0, nch, tid, kFusedThreads, T, a.ylimf, a.stride_log2, samp, mo, n_tissue);
                 double v[10];
                 mo.to_array(v, n_tissue, lane);
 #pragma unroll
@@ -1415,7 +1483,7 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
                 float Vf[6];
                 sh.status = eigvecs_from_moments(sh.sum, Vd, Vf);
                 for (int i = 0; i < 6; ++i) { sh.Vd[i] = Vd[i]; sh.Vf[i] = Vf[i]; }
-                sh.n_plain = 0; sh.n_raw = 0; sh.overflow = 0;
+                sh.n_raw = 0; sh.overflow = 0;
             }
             __syncthreads();
             if (sh.status == SL_TILE_OK) {                                    // block-uniform
@@ -1451,7 +1519,7 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
                 const bool complete = sh.n_raw <= (uint32_t)a.cap_raw && sh.overflow == 0;
                 const uint32_t n_raw = sh.n_raw < (uint32_t)a.cap_raw ? sh.n_raw : (uint32_t)a.cap_raw;
                 const float los[2] = {sh.lo[0], sh.lo[1]}, his[2] = {sh.hi[0], sh.hi[1]};
-                const long long base[2] = {0, (long long)sh.n_plain};
+                const long long base[2] = {0, (long long)T - (long long)sh.n_raw};   // plain = tissue pixels not collected
                 uint32_t n_lt[2], n_in[2];
                 wg_refine((int)n_raw, rkey, los, his, cand0, cand1, (uint32_t)a.cap_list, n_lt, n_in, sh.S);
                 for (int li = 0; li < 2; ++li) {
@@ -1476,7 +1544,7 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
                 for (int k = 0; k < 3; ++k) { sh.D[k] = h[k] / nh; sh.D[3 + k] = e[k] / ne; }
                 sh.status = SL_TILE_OK;
                 sh.delta = 1.0;
-                sh.n_plain = 0; sh.n_raw = 0; sh.overflow = 0;
+                sh.n_raw = 0; sh.overflow = 0;
                 for (int k = 0; k < 6; ++k) sh.Dprev[k] = 1e300;
                 sh.inner_cap = 500;
             }
@@ -1574,7 +1642,7 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
                 LassoK L;
                 lasso_consts(sh.M, a.lam, L);
                 sh.L = L;
-                sh.n_plain = 0; sh.n_raw = 0; sh.overflow = 0;
+                sh.n_raw = 0; sh.overflow = 0;
             }
             __syncthreads();
             // ---------------- concentration brackets from the sample
@@ -1608,7 +1676,7 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
                 const bool complete = sh.n_raw <= (uint32_t)a.cap_raw && sh.overflow == 0;
                 const uint32_t n_raw = sh.n_raw < (uint32_t)a.cap_raw ? sh.n_raw : (uint32_t)a.cap_raw;
                 const float los[2] = {sh.lo[0], sh.lo[1]}, his[2] = {sh.hi[0], sh.hi[1]};
-                const long long n_plain = sh.n_plain;
+                const long long n_plain = (long long)a.P - (long long)sh.n_raw;        // plain = pixels not collected
                 uint32_t n_lt[2], n_in[2];
                 wg_refine((int)n_raw, rkey, los, his, cand0, cand1, (uint32_t)a.cap_list, n_lt, n_in, sh.S);
                 for (int col = 0; col < 2; ++col) {
@@ -1645,33 +1713,8 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
             } else {
                 ApplyK K;
                 apply_consts(sh.M, sh.maxC, a.M_tgt, a.maxC_tgt, a.lam, K);
-                auto sweep = [&](auto fast_tag) {
-                    constexpr bool FAST = decltype(fast_tag)::value;
-                    for (int c = tid; c < nch; c += kFusedThreads * kU) {
-                        Chunk in[kU];
-#pragma unroll
-                        for (int u = 0; u < kU; ++u) {
-                            const int cc = c + u * kFusedThreads;
-                            in[u] = load_chunk_clamped<ALIGNED>(src, nbytes, cc, nch);
-                        }
-#pragma unroll
-                        for (int u = 0; u < kU; ++u) {
-                            const int cc = c + u * kFusedThreads;
-                            float t[12];
-#pragma unroll
-                            for (int px = 0; px < 4; ++px) {
-                                const float x = T.odf(T.addr(in[u], 3 * px)), y = T.odf(T.addr(in[u], 3 * px + 1)),
-                                            z = T.odf(T.addr(in[u], 3 * px + 2));
-                                float v[3];
-                                apply_px<FAST>(K, x, y, z, v);
-                                t[3 * px] = v[0]; t[3 * px + 1] = v[1]; t[3 * px + 2] = v[2];
-                            }
-                            const Chunk o = FAST ? pack_trunc_fast(t) : pack_trunc_general(t);
-                            if (cc < nch) store_chunk<ALIGNED>(dst, nbytes, cc, o);
-                        }
-                    }
-                };
-                if (K.fast) sweep(std::true_type{}); else sweep(std::false_type{});
+                if (K.fast) apply_sweep<ALIGNED, true>(src, dst, a.P, 0, nch, tid, kFusedThreads, T, K);
+                else apply_sweep<ALIGNED, false>(src, dst, a.P, 0, nch, tid, kFusedThreads, T, K);
             }
         }
         __syncthreads();     // sh.* is reused by the next tile

@@ -14,7 +14,7 @@
         __syncthreads();                                                                           \
         uint32_t la = (threadIdx.x & 63) * 16u;                                                    \
         for (int it = 0; it < iters; ++it) {                                                       \
-            REP8(asm volatile(BODY : "+" CONSTR(r0), "+" CONSTR(r1), "+" CONSTR(r2), "+" CONSTR(r3) : "v"(la) : "vcc", "scc", "s20", "s21", "s22", "s23", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107");)     \
+            REP8(asm volatile(BODY : "+" CONSTR(r0), "+" CONSTR(r1), "+" CONSTR(r2), "+" CONSTR(r3) : "v"(la) : "vcc", "scc", "s20", "s21", "s22", "s23", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118");)     \
         }                                                                                          \
         float r = (float)r0 + (float)r1 + (float)r2 + (float)r3;                                   \
         if (r == 123.456f) out[0] = r;                                                             \
@@ -89,6 +89,9 @@ KERNEL(k_mix_f64_perm, double, "v", "v_fma_f64 %0, %0, %1, %0\n v_perm_b32 v100,
 KERNEL(k_mix_exp_perm, float, "v", "v_exp_f32 %0, %1\n v_perm_b32 v100, v101, v102, v103\n v_exp_f32 %2, %3\n v_perm_b32 v100, v101, v102, v103\n v_exp_f32 %0, %1\n v_perm_b32 v100, v101, v102, v103\n v_exp_f32 %2, %3\n v_perm_b32 v100, v101, v102, v103\n ")
 KERNEL(k_mix_exp_2fma, float, "v", "v_exp_f32 %0, %1\n v_fmac_f32 v100, v101, v102\n v_fmac_f32 v104, v101, v102\n v_perm_b32 v105, v101, v102, v103\n v_exp_f32 %0, %1\n v_fmac_f32 v100, v101, v102\n v_fmac_f32 v104, v101, v102\n v_perm_b32 v105, v101, v102, v103\n ")
 KERNEL(k_mix_f64_fma, double, "v", "v_fma_f64 %0, %0, %1, %0\n v_fmac_f32 v100, v101, v102\n v_perm_b32 v105, v101, v102, v103\n v_fmac_f32 v104, v101, v102\n v_fma_f64 %0, %0, %1, %0\n v_fmac_f32 v100, v101, v102\n v_perm_b32 v105, v101, v102, v103\n v_fmac_f32 v104, v101, v102\n ")
+KERNEL(k_mfma4, float, "v", "v_mfma_f32_4x4x1_16b_f32 v[100:103], %0, %1, v[100:103]\n v_mfma_f32_4x4x1_16b_f32 v[104:107], %1, %2, v[104:107]\n v_mfma_f32_4x4x1_16b_f32 v[108:111], %2, %3, v[108:111]\n v_mfma_f32_4x4x1_16b_f32 v[112:115], %3, %0, v[112:115]\n v_mfma_f32_4x4x1_16b_f32 v[100:103], %0, %1, v[100:103]\n v_mfma_f32_4x4x1_16b_f32 v[104:107], %1, %2, v[104:107]\n v_mfma_f32_4x4x1_16b_f32 v[108:111], %2, %3, v[108:111]\n v_mfma_f32_4x4x1_16b_f32 v[112:115], %3, %0, v[112:115]\n")
+KERNEL(k_mfma4_perm, uint32_t, "v", "v_mfma_f32_4x4x1_16b_f32 v[100:103], %0, %1, v[100:103]\n v_perm_b32 v116, %1, %2, %3\n v_perm_b32 v117, %1, %2, %3\n v_perm_b32 v118, %1, %2, %3\n v_mfma_f32_4x4x1_16b_f32 v[104:107], %1, %2, v[104:107]\n v_perm_b32 v116, %1, %2, %3\n v_perm_b32 v117, %1, %2, %3\n v_perm_b32 v118, %1, %2, %3\n")
+KERNEL(k_mfma4_fma, float, "v", "v_mfma_f32_4x4x1_16b_f32 v[100:103], %0, %1, v[100:103]\n v_fmac_f32 v116, %1, %2\n v_fmac_f32 v117, %1, %2\n v_fmac_f32 v118, %1, %2\n v_mfma_f32_4x4x1_16b_f32 v[104:107], %1, %2, v[104:107]\n v_fmac_f32 v116, %1, %2\n v_fmac_f32 v117, %1, %2\n v_fmac_f32 v118, %1, %2\n")
 typedef void (*kern_t)(float*, int, float);
 static void run(const char* name, kern_t kf, int instr_per_rep, float* d_out) {
     const int iters = 2048;
@@ -113,6 +116,7 @@ int main() {
     setvbuf(stdout, nullptr, _IONBF, 0);
     float* d_out; hipMalloc(&d_out, 1024);
 #define RUN(k, n) run(#k, k, n, d_out)
+    RUN(k_mfma4,8);RUN(k_mfma4_perm,8);RUN(k_mfma4_fma,8);
     RUN(k_perm_ssel,8);RUN(k_fmac_lit,8);RUN(k_mul_lit,8);RUN(k_and_lit,8);RUN(k_cmp_sgpr,8);RUN(k_cmp_zero,8);RUN(k_alignbit,8);RUN(k_mbcnt,8);RUN(k_addc,8);RUN(k_readlane,8);RUN(k_mix_f64_perm,8);RUN(k_mix_exp_perm,8);RUN(k_mix_exp_2fma,8);RUN(k_mix_f64_fma,8);
     RUN(k_fmac_sgpr,8);RUN(k_mul_sgpr,8);RUN(k_fma_lit,8);RUN(k_fma_neg,8);RUN(k_add_abs,8);RUN(k_mul_u24,8);RUN(k_or_b32,8);RUN(k_xor_b32,8);RUN(k_sub_u32,8);RUN(k_lshl_add,8);RUN(k_and_or,8);RUN(k_add3,8);RUN(k_cnd_indep,8);RUN(k_cnd_sgpr,8);RUN(k_max_u32,8);RUN(k_ldexp,8);RUN(k_mix_fma_cmp,8);RUN(k_mix_fma_bfe,8);RUN(k_mix_3fma_perm,8);RUN(k_mix_fma_exp,8);RUN(k_exp,8);
     RUN(k_add_f32, 8); RUN(k_mul_f32, 8); RUN(k_fmac_f32, 8); RUN(k_fma_sgpr, 8); RUN(k_min_f32, 8); RUN(k_min3_f32, 8);
