@@ -86,17 +86,28 @@ struct StatsArgs {
 };
 
 
-// Table access of the finish steps and key functors (few lookups, any layout): entry v of table f / g
-// sits at [v*stride + c].  The sweeps use TabReader (sl_device.hpp) on the same RowTab instead.
+// Table access of the finish steps and key functors (few lookups, any layout): entry v of table f / g sits at LDS
+// byte address base + v*stride + off_f / off_g (DS reads; a generic pointer would go the slower flat path).
 struct TabView {
-    const float* f; const float* g; int stride, cf, cg;
-    __device__ __forceinline__ float odf(uint32_t v) const { return f[v * stride + cf]; }
-    __device__ __forceinline__ float gam(uint32_t v) const { return g[v * stride + cg]; }
+    uint32_t base; uint32_t stride, off_f, off_g;
+#if defined(__HIP_DEVICE_COMPILE__)
+    __device__ __forceinline__ float odf(uint32_t v) const { return *(SL_LDS const float*)(base + v * stride + off_f); }
+    __device__ __forceinline__ float gam(uint32_t v) const { return *(SL_LDS const float*)(base + v * stride + off_g); }
+#else
+    float odf(uint32_t) const { return 0.0f; }
+    float gam(uint32_t) const { return 0.0f; }
+#endif
 };
+__device__ __forceinline__ uint32_t lds_address(const void* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)(uintptr_t)(SL_LDS const void*)p;
+#else
+    return 0;
+#endif
+}
 __device__ __forceinline__ TabView view_of(const RowTab& t) {
-    const float* base = reinterpret_cast<const float*>(t.e);
-    const int c = 4 * (int)(threadIdx.x & (kTabCopies - 1));
-    return TabView{base, base, 4 * kTabCopies, c + 3, c + 2};
+    const uint32_t c = (uint32_t)sizeof(TabEntry) * (threadIdx.x & (kTabCopies - 1));
+    return TabView{lds_address(&t), (uint32_t)sizeof(TabEntry) * kTabCopies, c + 12u, c + 8u};
 }
 // the 2 KB version for kernels that only run finish steps
 struct SmallTab {
@@ -105,7 +116,7 @@ struct SmallTab {
         for (int i = threadIdx.x; i < 256; i += blockDim.x) { f[i] = d_od_f32[i]; g[i] = (float)d_gamma[i]; }
     }
 };
-__device__ __forceinline__ TabView view_of(const SmallTab& t) { return TabView{t.f, t.g, 1, 0, 0}; }
+__device__ __forceinline__ TabView view_of(const SmallTab& t) { return TabView{lds_address(&t), 4u, 0u, 1024u}; }
 
 // ---- stratified sample: one pixel per block of 2^stride_log2 pixels (2^cps_log2 chunks, cps_log2 >= 4) ----
 // Which pixel is decided per HASH GROUP = the 64 chunks one wave covers with one load (or the whole block when
@@ -325,71 +336,122 @@ __device__ __forceinline__ void wg_minmax(int n, const KeyAt& key_at, uint32_t& 
     __syncthreads();
 }
 
-// Two brackets (for percentiles pctA and pctB of the FULL population) from the sample keys, in
-// three passes over the sample: min/max, one shared 1024-bin histogram, one 4x256-bin refinement.
-// Each end is a bin edge on the safe side of the exact sample order statistic at rank -/+ z sigma
-// (so the bracket is a hair wider than with exact sample quantiles, never narrower); an end opens
-// to -inf/+inf when its rank leaves the sample.
-template <class KeyAt>
-__device__ __forceinline__ void wg_sample_brackets(int n, const KeyAt& key_at, int nbr, const double* pct, float* lo,
-                                                   float* hi, SelScratch& S) {
-    uint32_t omin, omax, nv;
-    wg_minmax(n, key_at, omin, omax, nv, S);
-    uint32_t rank[4];
-    bool open[4];
-    for (int i = 0; i < 2 * nbr; ++i) { rank[i] = 0; open[i] = true; }
-    if (nv > 0) {
-        for (int b = 0; b < nbr; ++b) {
+// Two brackets (for percentiles of the FULL population) from the sample keys, in three passes: min/max, one
+// shared 1024-bin histogram, one 4x256-bin refinement.  Each end is a bin edge on the safe side of the exact sample
+// order statistic at rank -/+ z sigma (so the bracket is a hair wider than with exact sample quantiles, never
+// narrower); an end opens to -inf/+inf when its rank leaves the sample.
+// The keys sit in REGISTERS: thread t holds sample entries t, t + blockDim, ... of NSETS key sets as ordered
+// integers (kAbsent = no key).  Bracket b is the pct[b]-th percentile of key set set_of[b].  The passes touch no
+// memory but the LDS histogram: the sample is read and its keys are evaluated once.
+constexpr uint32_t kAbsent = 0xffffffffu;
+template <int NSETS, int KPT, int NBR>
+__device__ __forceinline__ void wg_brackets_regs(const uint32_t (&ord)[NSETS][KPT], const int (&set_of)[NBR],
+                                                 const double (&pct)[NBR], float* lo, float* hi, SelScratch& S) {
+    static_assert(2 * NBR <= 4, "four 256-bin refinement windows");
+    uint32_t omin[NSETS], omax[NSETS], nv[NSETS];
+#pragma unroll
+    for (int s = 0; s < NSETS; ++s) {
+        if (threadIdx.x == 0) { S.misc[4] = 0xffffffffu; S.misc[5] = 0; S.misc[6] = 0; }
+        __syncthreads();
+        uint32_t mn = 0xffffffffu, mx = 0, cnt = 0;
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const uint32_t o = ord[s][j];
+            if (o != kAbsent) { mn = min(mn, o); mx = max(mx, o); ++cnt; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
+            mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+            cnt += __shfl_xor((int)cnt, o, 64);
+        }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&S.misc[4], mn); atomicMax(&S.misc[5], mx); atomicAdd(&S.misc[6], cnt); }
+        __syncthreads();
+        omin[s] = S.misc[4]; omax[s] = S.misc[5]; nv[s] = S.misc[6];
+        __syncthreads();
+    }
+    uint32_t rank[2 * NBR], wlo[2 * NBR], whi[2 * NBR], below[2 * NBR];
+    bool open[2 * NBR];
+#pragma unroll
+    for (int b = 0; b < NBR; ++b) {
+        const uint32_t n = nv[set_of[b]];
+        rank[2 * b] = rank[2 * b + 1] = 0; open[2 * b] = open[2 * b + 1] = true;
+        wlo[2 * b] = wlo[2 * b + 1] = whi[2 * b] = whi[2 * b + 1] = below[2 * b] = below[2 * b + 1] = 0;
+        if (n > 0) {
             const double q = pct[b] / 100.0;
-            const double r = q * ((double)nv - 1.0);
-            const double sd = sqrt(fmax(q * (1.0 - q) * (double)nv, 0.0));
+            const double r = q * ((double)n - 1.0);
+            const double sd = sqrt(fmax(q * (1.0 - q) * (double)n, 0.0));
             const long long rlo = (long long)floor(r - kBracketZ * sd) - 1;
             const long long rhi = (long long)ceil(r + kBracketZ * sd) + 1;
             open[2 * b] = rlo < 0;
-            open[2 * b + 1] = rhi > (long long)nv - 1;
+            open[2 * b + 1] = rhi > (long long)n - 1;
             rank[2 * b] = open[2 * b] ? 0u : (uint32_t)rlo;
-            rank[2 * b + 1] = open[2 * b + 1] ? nv - 1 : (uint32_t)rhi;
+            rank[2 * b + 1] = open[2 * b + 1] ? n - 1 : (uint32_t)rhi;
         }
     }
-    uint32_t wlo[4], whi[4], below[4];
-    const uint32_t R = omax - omin;
-    const int s1 = (nv == 0 || R < 1024u) ? 0 : (32 - __clz(R) - 10);
-    if (nv > 0) {
-        const int nb1 = (int)(R >> s1) + 1;
+    int s1[NSETS];
+#pragma unroll
+    for (int s = 0; s < NSETS; ++s) {                       // coarse pass per key set
+        const uint32_t R = omax[s] - omin[s];
+        s1[s] = (nv[s] == 0 || R < 1024u) ? 0 : (32 - __clz(R) - 10);
+        if (nv[s] == 0) continue;                            // block-uniform
+        const int nb1 = (int)(R >> s1[s]) + 1;
         for (int i = threadIdx.x; i < nb1; i += blockDim.x) S.hist[i] = 0;
         __syncthreads();
-        wg_for_each_key(n, key_at, [&](uint32_t o) { atomicAdd(&S.hist[(o - omin) >> s1], 1u); });
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const uint32_t o = ord[s][j];
+            if (o != kAbsent) atomicAdd(&S.hist[(o - omin[s]) >> s1[s]], 1u);
+        }
         __syncthreads();
-        for (int i = 0; i < 2 * nbr; ++i) {
+#pragma unroll
+        for (int i = 0; i < 2 * NBR; ++i) {
+            if (set_of[i >> 1] != s) continue;
             wg_locate(S.hist, nb1, rank[i], S.misc);
-            wlo[i] = omin + (S.misc[0] << s1);
-            const uint32_t span = s1 ? ((1u << s1) - 1u) : 0u;
-            whi[i] = (omax - wlo[i]) < span ? omax : wlo[i] + span;
+            wlo[i] = omin[s] + (S.misc[0] << s1[s]);
+            const uint32_t span = s1[s] ? ((1u << s1[s]) - 1u) : 0u;
+            whi[i] = (omax[s] - wlo[i]) < span ? omax[s] : wlo[i] + span;
             below[i] = S.misc[1];
             __syncthreads();
         }
-        if (s1 > 0) {            // refine every window into 256 bins (segments of the same LDS histogram)
-            const int s2 = s1 > 8 ? s1 - 8 : 0;
-            for (int i = threadIdx.x; i < 1024; i += blockDim.x) S.hist[i] = 0;
-            __syncthreads();
-            wg_for_each_key(n, key_at, [&](uint32_t o) {
-                for (int i = 0; i < 2 * nbr; ++i)
-                    if (o >= wlo[i] && o <= whi[i]) atomicAdd(&S.hist[i * 256 + ((o - wlo[i]) >> s2)], 1u);
-            });
-            __syncthreads();
-            for (int i = 0; i < 2 * nbr; ++i) {
-                wg_locate(S.hist + i * 256, 256, rank[i] - below[i], S.misc);
-                const uint32_t nlo = wlo[i] + (S.misc[0] << s2);
-                const uint32_t span = s2 ? ((1u << s2) - 1u) : 0u;
-                whi[i] = (whi[i] - nlo) < span ? whi[i] : nlo + span;
-                wlo[i] = nlo;
-                __syncthreads();
+    }
+    bool any_refine = false;
+#pragma unroll
+    for (int s = 0; s < NSETS; ++s) any_refine = any_refine | (nv[s] > 0 && s1[s] > 0);
+    if (any_refine) {                                        // every window into 256 bins (segments of the LDS histogram)
+        for (int i = threadIdx.x; i < 1024; i += blockDim.x) S.hist[i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < NSETS; ++s) {
+            if (!(nv[s] > 0 && s1[s] > 0)) continue;
+            const int s2 = s1[s] > 8 ? s1[s] - 8 : 0;
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) {
+                const uint32_t o = ord[s][j];
+                if (o == kAbsent) continue;
+#pragma unroll
+                for (int i = 0; i < 2 * NBR; ++i)
+                    if (set_of[i >> 1] == s && o >= wlo[i] && o <= whi[i]) atomicAdd(&S.hist[i * 256 + ((o - wlo[i]) >> s2)], 1u);
             }
         }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2 * NBR; ++i) {
+            const int s = set_of[i >> 1];
+            if (!(nv[s] > 0 && s1[s] > 0)) continue;
+            const int s2 = s1[s] > 8 ? s1[s] - 8 : 0;
+            wg_locate(S.hist + i * 256, 256, rank[i] - below[i], S.misc);
+            const uint32_t nlo = wlo[i] + (S.misc[0] << s2);
+            const uint32_t span = s2 ? ((1u << s2) - 1u) : 0u;
+            whi[i] = (whi[i] - nlo) < span ? whi[i] : nlo + span;
+            wlo[i] = nlo;
+            __syncthreads();
+        }
     }
-    for (int b = 0; b < nbr; ++b) {
-        lo[b] = (nv == 0 || open[2 * b]) ? -INFINITY : ord2f(wlo[2 * b]);
-        hi[b] = (nv == 0 || open[2 * b + 1]) ? INFINITY : ord2f(whi[2 * b + 1]);
+#pragma unroll
+    for (int b = 0; b < NBR; ++b) {
+        const bool none = nv[set_of[b]] == 0;
+        lo[b] = (none || open[2 * b]) ? -INFINITY : ord2f(wlo[2 * b]);
+        hi[b] = (none || open[2 * b + 1]) ? INFINITY : ord2f(whi[2 * b + 1]);
     }
 }
 
@@ -755,11 +817,14 @@ struct SampleAngleKey {
 // concentration `col` of sample entry b (all pixels, tissue or not)
 struct SampleConcKey {
     const uint32_t* sample; TabView tab; LassoK L; int cps_log2; int P; int col;
-    __device__ __forceinline__ float operator()(int b) const {
-        if (sample_pixel((uint32_t)b, cps_log2) >= P) return nan_f();
+    __device__ __forceinline__ void both(int b, float& c1, float& c2) const {      // NaN, NaN: entry absent
+        if (sample_pixel((uint32_t)b, cps_log2) >= P) { c1 = c2 = nan_f(); return; }
         const uint32_t s = sample[b];
-        float c1, c2;
         lasso2(L, tab.odf(s & 255u), tab.odf((s >> 8) & 255u), tab.odf((s >> 16) & 255u), c1, c2);
+    }
+    __device__ __forceinline__ float operator()(int b) const {
+        float c1, c2;
+        both(b, c1, c2);
         return col == 0 ? c1 : c2;
     }
 };
@@ -812,28 +877,48 @@ __device__ __forceinline__ void wg_refine(int n_raw, const Key2& key2, const flo
     __syncthreads();
     const int lane = threadIdx.x & 63;
     uint32_t lt0 = 0, lt1 = 0;
-    const int bd = blockDim.x;
-    for (int i0 = threadIdx.x - lane; i0 < n_raw; i0 += bd) {      // wave-uniform trip count
-        const int i = i0 + lane;
-        float k0 = nan_f(), k1 = nan_f();
-        if (i < n_raw) key2(i, k0, k1);
-        lt0 += k0 < lo[0] ? 1u : 0u;
-        lt1 += k1 < lo[1] ? 1u : 0u;
-        const bool in0 = (k0 >= lo[0]) & (k0 <= hi[0]), in1 = (k1 >= lo[1]) & (k1 <= hi[1]);
-        const unsigned long long m0 = __ballot(in0), m1 = __ballot(in1);
-        if (m0) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&S.misc[14], (uint32_t)__popcll(m0));
-            base = __builtin_amdgcn_readfirstlane(base);
-            const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0));
-            if (in0 && pos < cap_list) cand0[pos] = k0;
+    constexpr int U = 4;                                            // entries per lane and trip: one list-head update per trip
+    const int step = (int)blockDim.x * U;
+    for (int i0 = (int)(threadIdx.x - lane) * U; i0 < n_raw; i0 += step) {      // wave-uniform trip count
+        float k0[U], k1[U];
+        unsigned long long m0[U], m1[U];
+        uint32_t tot0 = 0, tot1 = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * 64 + lane;
+            k0[u] = k1[u] = nan_f();
+            if (i < n_raw) key2(i, k0[u], k1[u]);
         }
-        if (m1) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            lt0 += k0[u] < lo[0] ? 1u : 0u;
+            lt1 += k1[u] < lo[1] ? 1u : 0u;
+            m0[u] = __ballot((k0[u] >= lo[0]) & (k0[u] <= hi[0]));
+            m1[u] = __ballot((k1[u] >= lo[1]) & (k1[u] <= hi[1]));
+            tot0 += (uint32_t)__popcll(m0[u]);
+            tot1 += (uint32_t)__popcll(m1[u]);
+        }
+        if (tot0) {
             uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&S.misc[15], (uint32_t)__popcll(m1));
+            if (lane == 0) base = atomicAdd(&S.misc[14], tot0);
             base = __builtin_amdgcn_readfirstlane(base);
-            const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0));
-            if (in1 && pos < cap_list) cand1[pos] = k1;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0[u], 0));
+                if (((m0[u] >> lane) & 1ull) && pos < cap_list) cand0[pos] = k0[u];
+                base += (uint32_t)__popcll(m0[u]);
+            }
+        }
+        if (tot1) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&S.misc[15], tot1);
+            base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1[u], 0));
+                if (((m1[u] >> lane) & 1ull) && pos < cap_list) cand1[pos] = k1[u];
+                base += (uint32_t)__popcll(m1[u]);
+            }
         }
     }
     for (int o = 32; o > 0; o >>= 1) { lt0 += __shfl_xor((int)lt0, o, 64); lt1 += __shfl_xor((int)lt1, o, 64); }
@@ -1173,19 +1258,38 @@ static __global__ __launch_bounds__(kSweepThreads, 4) void k_moments(StatsArgs a
     }
 }
 
-// brackets of both angular quantiles from the sample
+// brackets of both angular quantiles from the sample (THREADS = blockDim.x)
+template <int THREADS>
 __device__ __forceinline__ void angle_brackets(const SampleAngleKey& key, int n_sample, double pct, float* lo, float* hi,
                                                SelScratch& S) {
+    constexpr int KPT = kMaxSample / THREADS;
+    uint32_t ord[1][KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        const int b = j * THREADS + (int)threadIdx.x;
+        const float k = b < n_sample ? key(b) : nan_f();
+        ord[0][j] = k == k ? f2ord(k) : kAbsent;
+    }
+    const int set_of[2] = {0, 0};
     const double p2[2] = {100.0 - pct, pct};          // minPhi, maxPhi (macenko_stain_extractor.py:33-34)
-    wg_sample_brackets(n_sample, key, 2, p2, lo, hi, S);
+    wg_brackets_regs<1, KPT, 2>(ord, set_of, p2, lo, hi, S);
 }
 // brackets of the 99th percentile of both concentration columns from the sample (normalizer.py:36,47)
-__device__ __forceinline__ void conc_brackets(SampleConcKey key, int n_sample, float* lo, float* hi, SelScratch& S) {
-    const double p1[1] = {99.0};
-    for (int col = 0; col < 2; ++col) {
-        key.col = col;
-        wg_sample_brackets(n_sample, key, 1, p1, lo + col, hi + col, S);
+template <int THREADS>
+__device__ __forceinline__ void conc_brackets(const SampleConcKey& key, int n_sample, float* lo, float* hi, SelScratch& S) {
+    constexpr int KPT = kMaxSample / THREADS;
+    uint32_t ord[2][KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        const int b = j * THREADS + (int)threadIdx.x;
+        float c1 = nan_f(), c2 = nan_f();
+        if (b < n_sample) key.both(b, c1, c2);
+        ord[0][j] = c1 == c1 ? f2ord(c1) : kAbsent;
+        ord[1][j] = c2 == c2 ? f2ord(c2) : kAbsent;
     }
+    const int set_of[2] = {0, 1};
+    const double p2[2] = {99.0, 99.0};
+    wg_brackets_regs<2, KPT, 2>(ord, set_of, p2, lo, hi, S);
 }
 
 static __global__ __launch_bounds__(kFinishThreads) void k_finish_moments(StatsArgs a) {
@@ -1220,7 +1324,7 @@ static __global__ __launch_bounds__(kFinishThreads) void k_finish_moments(StatsA
     key.P = a.P;
     key.ylimf = a.ylimf;
     float lo[2], hi[2];
-    angle_brackets(key, a.n_sample, a.pct, lo, hi, S);
+    angle_brackets<kFinishThreads>(key, a.n_sample, a.pct, lo, hi, S);
     if (tid == 0) { st.lo[0] = lo[0]; st.hi[0] = hi[0]; st.lo[1] = lo[1]; st.hi[1] = hi[1]; }
 }
 
@@ -1312,7 +1416,7 @@ static __global__ __launch_bounds__(kFinishThreads) void k_finish_angle(StatsArg
     ckey.P = a.P;
     ckey.col = 0;
     float lo[2], hi[2];
-    conc_brackets(ckey, a.n_sample, lo, hi, S);
+    conc_brackets<kFinishThreads>(ckey, a.n_sample, lo, hi, S);
     if (tid == 0) { st.lo[0] = lo[0]; st.hi[0] = hi[0]; st.lo[1] = lo[1]; st.hi[1] = hi[1]; }
 }
 
@@ -1492,7 +1596,7 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
                     key.sample = samp; key.tab = view_of(sh.tab); key.cps_log2 = a.stride_log2 - 2; key.P = a.P; key.ylimf = a.ylimf;
                     for (int i = 0; i < 6; ++i) key.V[i] = sh.Vf[i];
                     float lo[2], hi[2];
-                    angle_brackets(key, a.n_sample, a.pct, lo, hi, sh.S);
+                    angle_brackets<kFusedThreads>(key, a.n_sample, a.pct, lo, hi, sh.S);
                     if (tid == 0) { sh.lo[0] = lo[0]; sh.hi[0] = hi[0]; sh.lo[1] = lo[1]; sh.hi[1] = hi[1]; }
                     __syncthreads();
                 }
@@ -1651,7 +1755,7 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
                 ckey.sample = samp; ckey.tab = view_of(sh.tab); ckey.L = sh.L; ckey.cps_log2 = a.stride_log2 - 2;
                 ckey.P = a.P; ckey.col = 0;
                 float lo[2], hi[2];
-                conc_brackets(ckey, a.n_sample, lo, hi, sh.S);
+                conc_brackets<kFusedThreads>(ckey, a.n_sample, lo, hi, sh.S);
                 if (tid == 0) { sh.lo[0] = lo[0]; sh.hi[0] = hi[0]; sh.lo[1] = lo[1]; sh.hi[1] = hi[1]; }
                 __syncthreads();
             }
