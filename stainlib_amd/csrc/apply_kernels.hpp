@@ -283,23 +283,22 @@ static __global__ __launch_bounds__(kWG) void k_stain_augment(const uint8_t* __r
                                                        int P, int parts, const double* __restrict__ M,
                                                        const float* __restrict__ alpha_beta, int augment_background,
                                                        uint32_t y_lim, double lam) {
-    __shared__ float s_od[256 * kRepl];
-    __shared__ uint32_t s_g[256 * kRepl];
-    fill_od_lut(s_od);
-    fill_gamma_lut(s_g);
+    __shared__ float2 s_t[256];                  // {od32, gamma} per byte value: one ds_read_b64 per channel
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_t[i] = make_float2(d_od_f32[i], (float)d_gamma[i]);
     const int tile = blockIdx.x / parts, part = blockIdx.x % parts;
     const int tid = threadIdx.x;
-    const uint32_t lane32 = tid & (kRepl - 1);   // which LDS copy of the table this lane reads
+    // per-tile constants live in VGPRs (a VALU op with an SGPR operand issues at half rate on gfx950)
     LassoK L;
     lasso_consts(M + 6 * (size_t)tile, lam, L);
-    uni(L);
+    vgpr(L);
     ReconK R;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) R.q[i][c] = uni((float)(-1.4426950408889634 * M[6 * (size_t)tile + 3 * i + c]));
-    const float al0 = uni(alpha_beta[4 * (size_t)tile + 0]), be0 = uni(alpha_beta[4 * (size_t)tile + 1]);
-    const float al1 = uni(alpha_beta[4 * (size_t)tile + 2]), be1 = uni(alpha_beta[4 * (size_t)tile + 3]);
+        for (int c = 0; c < 3; ++c) R.q[i][c] = in_vgpr((float)(-1.4426950408889634 * M[6 * (size_t)tile + 3 * i + c]));
+    const float al0 = in_vgpr(alpha_beta[4 * (size_t)tile + 0]), be0 = in_vgpr(alpha_beta[4 * (size_t)tile + 1]);
+    const float al1 = in_vgpr(alpha_beta[4 * (size_t)tile + 2]), be1 = in_vgpr(alpha_beta[4 * (size_t)tile + 3]);
+    const float ylimf = (float)y_lim - 2048.0f;
     __syncthreads();
 
     const size_t nbytes = (size_t)P * 3;
@@ -310,33 +309,25 @@ static __global__ __launch_bounds__(kWG) void k_stain_augment(const uint8_t* __r
     const int c0 = part * span;
     const int c1 = min(nch, c0 + span);
     auto process = [&](const Chunk& in, int c) {
-        uint32_t ob[12];
+        float t[12];
 #pragma unroll
         for (int px = 0; px < 4; ++px) {
-            const uint32_t r = chunk_byte(in, 3 * px), g = chunk_byte(in, 3 * px + 1), b = chunk_byte(in, 3 * px + 2);
-            const bool tissue = augment_background ||
-                                is_tissue(lut(s_g, r, lane32), lut(s_g, g, lane32), lut(s_g, b, lane32), y_lim);
+            const float2 er = s_t[chunk_byte(in, 3 * px)], eg = s_t[chunk_byte(in, 3 * px + 1)], eb = s_t[chunk_byte(in, 3 * px + 2)];
+            const bool tissue = augment_background || is_tissue_f(er.y, eg.y, eb.y, ylimf);
             float a1, a2, v[3];
-            lasso2(L, lut(s_od, r, lane32), lut(s_od, g, lane32), lut(s_od, b, lane32), a1, a2);
+            lasso2(L, er.x, eg.x, eb.x, a1, a2);
             a1 = tissue ? fmaf(a1, al0, be0) : a1;
             a2 = tissue ? fmaf(a2, al1, be1) : a2;
-            recon_px<true>(R, a1, a2, v);
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) ob[3 * px + ch] = trunc_u8(v[ch]);
+            recon_px<false>(R, a1, a2, v);         // the clip to 255 (augmenter.py:447) is the saturation of the pack below
+            t[3 * px] = v[0]; t[3 * px + 1] = v[1]; t[3 * px + 2] = v[2];
         }
-        Chunk o;
-        o.w0 = ob[0] | (ob[1] << 8) | (ob[2] << 16) | (ob[3] << 24);
-        o.w1 = ob[4] | (ob[5] << 8) | (ob[6] << 16) | (ob[7] << 24);
-        o.w2 = ob[8] | (ob[9] << 8) | (ob[10] << 16) | (ob[11] << 24);
+        const Chunk o = pack_trunc_fast(t);         // values are >= 0; > 255 saturates = np.clip(.., 0, 255)
         if (c < c1) store_chunk<ALIGNED>(dst, nbytes, c, o);
     };
     for (int c = c0 + tid; c < c1; c += kWG * kU) {
         Chunk in[kU];
 #pragma unroll
-        for (int u = 0; u < kU; ++u) {
-            const int cc = c + u * kWG;
-            in[u] = cc < c1 ? load_chunk<ALIGNED>(src, nbytes, cc) : Chunk{0, 0, 0};
-        }
+        for (int u = 0; u < kU; ++u) in[u] = load_chunk_clamped<ALIGNED>(src, nbytes, c + u * kWG, c1);
 #pragma unroll
         for (int u = 0; u < kU; ++u) process(in[u], c + u * kWG);
     }

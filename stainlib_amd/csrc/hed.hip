@@ -30,7 +30,7 @@ static __global__ __launch_bounds__(kWG) void k_hed(const uint8_t* __restrict__ 
         s_x[tid] = (float)log(v);
     }
     if (tid == 0) s_sum = 0;
-    // per-tile constants in binary64, then binary32 scalars
+    // per-tile constants in binary64, then binary32 in VGPRs (a VALU op with an SGPR operand issues at half rate)
     float A[3][3], b[3], Hs[3][3], Rs[3][3], sc[3], bi[3];
     const double* sg = sigma + 3 * (size_t)tile;
     const double* bs = bias + 3 * (size_t)tile;
@@ -42,24 +42,24 @@ static __global__ __launch_bounds__(kWG) void k_hed(const uint8_t* __restrict__ 
             for (int c = 0; c < 3; ++c) {
                 double acc = 0;
                 for (int j = 0; j < 3; ++j) acc += hc.H[3 * k + j] * (1.0 + sg[j]) * hc.R[3 * j + c];
-                A[k][c] = uni((float)(acc * kL2E));
+                A[k][c] = in_vgpr((float)(acc * kL2E));
             }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             double acc = 0;
             for (int j = 0; j < 3; ++j) acc += bs[j] * hc.R[3 * j + c];
-            b[c] = uni((float)(Ladj * acc * kL2E));
+            b[c] = in_vgpr((float)(Ladj * acc * kL2E));
         }
     } else {
 #pragma unroll
         for (int k = 0; k < 3; ++k)
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                Hs[k][c] = uni((float)(hc.H[3 * k + c] / Ladj));           // stains = ln(rgb)/ln(1e-6) @ H
-                Rs[k][c] = uni((float)(hc.R[3 * k + c] * Ladj * kL2E));    // log2 rgb = ln(1e-6) * stains @ R * log2(e)
+                Hs[k][c] = in_vgpr((float)(hc.H[3 * k + c] / Ladj));           // stains = ln(rgb)/ln(1e-6) @ H
+                Rs[k][c] = in_vgpr((float)(hc.R[3 * k + c] * Ladj * kL2E));    // log2 rgb = ln(1e-6) * stains @ R * log2(e)
             }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { sc[c] = uni((float)(1.0 + sg[c])); bi[c] = uni((float)bs[c]); }
+        for (int c = 0; c < 3; ++c) { sc[c] = in_vgpr((float)(1.0 + sg[c])); bi[c] = in_vgpr((float)bs[c]); }
     }
     __syncthreads();
 
@@ -75,7 +75,7 @@ static __global__ __launch_bounds__(kWG) void k_hed(const uint8_t* __restrict__ 
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
             const int cc = c + u * kWG;
-            in[u] = cc < c1 ? load_chunk<ALIGNED>(src, nbytes, cc) : Chunk{0, 0, 0};
+            in[u] = cc < c1 ? load_chunk<ALIGNED>(src, nbytes, cc) : Chunk{0, 0, 0};      // zeros: keeps the byte sum exact
         }
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
@@ -83,7 +83,7 @@ static __global__ __launch_bounds__(kWG) void k_hed(const uint8_t* __restrict__ 
             bsum = __builtin_amdgcn_udot4(in[u].w0, 0x01010101u, bsum, false);
             bsum = __builtin_amdgcn_udot4(in[u].w1, 0x01010101u, bsum, false);
             bsum = __builtin_amdgcn_udot4(in[u].w2, 0x01010101u, bsum, false);
-            uint32_t ob[12];
+            float tv[12];
 #pragma unroll
             for (int px = 0; px < 4; ++px) {
                 const float x0 = s_x[chunk_byte(in[u], 3 * px)], x1 = s_x[chunk_byte(in[u], 3 * px + 1)],
@@ -104,15 +104,10 @@ static __global__ __launch_bounds__(kWG) void k_hed(const uint8_t* __restrict__ 
                     for (int ch = 0; ch < 3; ++ch) l[ch] = fmaf(st[2], Rs[2][ch], fmaf(st[1], Rs[1][ch], st[0] * Rs[0][ch]));
                 }
 #pragma unroll
-                for (int ch = 0; ch < 3; ++ch) {
-                    const float v = 255.0f * fminf(__builtin_amdgcn_exp2f(l[ch]), 1.0f);   // clip [0,1], *255 (:320-324)
-                    ob[3 * px + ch] = trunc_u8(v);                                        // astype(uint8) (:325)
-                }
+                for (int ch = 0; ch < 3; ++ch) tv[3 * px + ch] = 255.0f * __builtin_amdgcn_exp2f(l[ch]);
             }
-            Chunk o;
-            o.w0 = ob[0] | (ob[1] << 8) | (ob[2] << 16) | (ob[3] << 24);
-            o.w1 = ob[4] | (ob[5] << 8) | (ob[6] << 16) | (ob[7] << 24);
-            o.w2 = ob[8] | (ob[9] << 8) | (ob[10] << 16) | (ob[11] << 24);
+            // clip [0,1], *255, astype(uint8) (augmenter.py:320-325): min(255 x, 255) truncated = the saturating pack
+            const Chunk o = pack_trunc_fast(tv);
             if (cc < c1) store_chunk<ALIGNED>(dst, nbytes, cc, o);
         }
     }
