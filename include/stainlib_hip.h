@@ -52,6 +52,12 @@ extern "C" {
 #define SL_OP_VAHADANE_TRANSFORM 4
 #define SL_OP_HED_AUGMENT 5
 #define SL_OP_STAIN_AUGMENT 6
+#define SL_OP_TILE_MOMENTS 7
+
+/* selection keys of the pooled slide-level mode (sl_slide_key_*) */
+#define SL_KEY_ANGLE 0 /* pseudo-angle of the projected OD, tissue pixels only (macenko_stain_extractor.py:29-34) */
+#define SL_KEY_CONC0 1 /* lasso concentration of stain 0, all pixels (normalizer.py:36,47) */
+#define SL_KEY_CONC1 2
 
 /* skimage semantics selector for sl_hed_augment */
 #define SL_HED_SKIMAGE_018 0 /* ln(max(rgb,1e-6))/ln(1e-6) @ hed_from_rgb  (golden-pinned) */
@@ -181,6 +187,27 @@ int sl_tissue_mask(const uint8_t* rgb, int n, int h, int w, double luminosity_th
 /* get_concentrations (utils/stain_utils.py:69-78) materialised: C_out n x P x 2 float. */
 int sl_concentrations(const uint8_t* rgb, int n, int h, int w, const double* M,
                       double lasso_lambda, float* C_out, void* stream);
+
+/* ---- pooled slide-level mode (BASELINE.json configs[4]; an extension: the reference has no notion of a slide).
+ * Every tile of a slide gets the statistics the reference would compute from the vertical concatenation of all
+ * the tiles.  Each call reduces THIS process's tiles; the host sums / all-reduces the small results over ranks
+ * (stainlib_amd/distributed.py: PooledSlideStatistics).
+ *
+ * sl_tile_moments: per tile {n, sum od[3], sum od od^T [xx,xy,xz,yy,yz,zz]} over the tissue pixels, binary64,
+ * run-to-run identical.  workspace: sl_workspace_bytes(SL_OP_TILE_MOMENTS, n, h, w). */
+int sl_tile_moments(const uint8_t* rgb, int n, int h, int w, const SlParams* params,
+                    double* moments_out /* n x 10 */, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Keys are compared as order-preserving uint32 images of their binary32 value: ord(f) = bits(f) ^ 0x80000000 for
+ * f >= 0, ~bits(f) for f < 0.  `basis` is a HOST pointer to 6 doubles: V (3x2, V[c*2+k]) for SL_KEY_ANGLE, the
+ * stain matrix M (2x3) for SL_KEY_CONC*.  hist[256] (device, uint64) is ACCUMULATED into: bin = the 8 key bits
+ * below the top `prefix_bits` bits, over the keys whose top `prefix_bits` (0, 8, 16 or 24) bits equal `prefix`. */
+int sl_slide_key_histogram(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int key,
+                           const double* basis, uint32_t prefix, int prefix_bits, unsigned long long* hist,
+                           void* stream);
+/* *min_out (device uint32, set to 0xffffffff by the caller) = min(*min_out, smallest key > key_ord). */
+int sl_slide_key_next_above(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int key,
+                            const double* basis, uint32_t key_ord, uint32_t* min_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -176,6 +176,8 @@ extern "C" size_t sl_workspace_bytes(int op, int n_tiles, int h, int w) {
             return make_layout(n_tiles, (long)h * w, true).total;
         case SL_OP_HED_AUGMENT:
             return (sizeof(unsigned long long) * (size_t)n_tiles + 255) & ~(size_t)255;
+        case SL_OP_TILE_MOMENTS:
+            return (sizeof(double) * 10 * (size_t)parts_for((long)h * w) * (size_t)n_tiles + 255) & ~(size_t)255;
         default:
             return 0;
     }

@@ -623,7 +623,7 @@ __device__ __forceinline__ void sample_row(const Chunk& ch, int row0, int cc, in
     const uint32_t cmask = (1u << cps_log2) - 1u;
     const uint32_t sel = (h >> 8) & cmask;
     const bool last = (h >> 31) != 0;                                  // uniform: pixel 3 instead of pixel 0
-    if ((cc < c1) & (((uint32_t)cc & cmask) == sel)) {
+    if (samp && ((cc < c1) & (((uint32_t)cc & cmask) == sel))) {
         const uint32_t v = (last ? ch.w2 : ch.w0) >> (last ? 8 : 0);   // stray top byte for pixel 0: readers ignore it
         if (ALIGNED || (size_t)cc * 4 + (last ? 3 : 0) < (size_t)P) samp[(uint32_t)cc >> cps_log2] = v;
     }

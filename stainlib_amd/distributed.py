@@ -13,6 +13,14 @@ The only exchange is small and optional:
     (RCCL over xGMI on GPUs, gloo in the CPU tests; latency-bound: 36 B/tile), every rank reduces the
     same gathered table to the same slide statistics, and the apply pass runs locally.
 This is an extension (the reference has no notion of a slide); its check is the same recipe run on one process.
+
+  * POOLED slide-level mode (``SlideNormalizer(..., mode="pooled")``): the slide statistics are
+    exactly those the reference computes from the vertical concatenation of ALL tiles as one tall image --
+    covariance over every tissue pixel of the slide, 1st/99th angular percentiles over those pixels, 99th
+    percentile of each concentration over every pixel.  Sums and order statistics decompose over tiles and
+    ranks: per-tile moment sums are all-reduced (10 doubles), and each exact order statistic of the binary32
+    key is pinned by a 4-round radix select whose 256-bin histograms are all-reduced (2 KiB per round).  All
+    collectives are tiny and latency-bound.  Oracle: the reference restatement on the concatenated image.
 """
 from __future__ import annotations
 
@@ -69,16 +77,150 @@ def slide_statistics(M_all: torch.Tensor, maxC_all: torch.Tensor, status_all: to
     return M, maxC
 
 
-class SlideNormalizer:
-    """Slide-level Macenko/Vahadane normalisation over a sharded set of tiles (see module docstring)."""
+# ---- exact order statistics of a key that is spread over tiles and ranks ------------------------------------------
+def ord_to_float(o: int) -> float:
+    """Inverse of the order-preserving uint32 image of a binary32 value (include/stainlib_hip.h)."""
+    import struct
+    bits = (o & 0x7fffffff) if (o & 0x80000000) else (~o & 0xffffffff)
+    return struct.unpack("<f", struct.pack("<I", bits))[0]
 
-    def __init__(self, normalizer, group=None):
+
+def percentile_position(n: int, pct: float):
+    """numpy.percentile(method='linear'): 0-based rank k and interpolation weight g between ranks k and k+1."""
+    import math
+    vi = min(max((pct / 100.0) * (n - 1), 0.0), float(n - 1))
+    k = math.floor(vi)
+    return int(k), vi - k
+
+
+def np_lerp(a: float, b: float, t: float) -> float:
+    d = b - a
+    return b - d * (1.0 - t) if t >= 0.5 else a + d * t
+
+
+def exact_rank_pair(hist_fn, next_above_fn, k: int, group=None):
+    """Keys of ranks k and min(k+1, N-1) (0-based, ascending) of the union of every rank's keys, as ordered uint32.
+
+    hist_fn(prefix, prefix_bits) -> int64[256] tensor with THIS rank's histogram of the next 8 key bits among its
+    keys whose top prefix_bits bits equal prefix; next_above_fn(key) -> this rank's smallest key > key (0xffffffff
+    if none).  Four all-reduced histogram rounds pin the k-th key exactly; returns (key_k, key_k1, N)."""
+    _, world = _world(group)
+    prefix, below, total, in_bin = 0, 0, None, 0
+    for bits in (0, 8, 16, 24):
+        h = hist_fn(prefix, bits)
+        if world > 1:
+            dist.all_reduce(h, group=group)
+        hc = h.detach().cpu().tolist()
+        if total is None:
+            total = int(sum(hc))
+            if total == 0:
+                raise ValueError("no pixel carries this key")
+            k = min(max(int(k), 0), total - 1)
+        acc = below
+        for b in range(256):
+            if k < acc + hc[b]:
+                prefix, below, in_bin = (prefix << 8) | b, acc, int(hc[b])
+                break
+            acc += hc[b]
+    key_k = prefix
+    if k + 1 < below + in_bin or k + 1 >= total:
+        return key_k, key_k, total
+    nxt = next_above_fn(key_k)
+    if world > 1:
+        t = torch.tensor([nxt], dtype=torch.int64, device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        nxt = int(t.item())
+    return key_k, (nxt if nxt != 0xffffffff else key_k), total
+
+
+class PooledSlideStatistics:
+    """Stain matrix and 99th-percentile concentrations of the tall image made of every tile on every rank."""
+
+    def __init__(self, group=None, luminosity_threshold=0.8, angular_percentile=99.0, lasso_lambda=0.01):
+        self.group = group
+        self.thr, self.pct, self.lam = luminosity_threshold, angular_percentile, lasso_lambda
+
+    def __call__(self, tiles_local: torch.Tensor):
+        import math
+        import numpy as np
+        from . import engine, _ffi
+        from .utils.excepts import TissueMaskException
+        params = engine.make_params(luminosity_threshold=self.thr, angular_percentile=self.pct, lasso_lambda=self.lam)
+        _, world = _world(self.group)
+        n_local, h, w, _ = tiles_local.shape
+        # ---- covariance of the optical density over every tissue pixel (macenko_stain_extractor.py:18-27)
+        mom = engine.tile_moments(tiles_local, params=params).sum(dim=0)
+        npx = torch.tensor([float(n_local * h * w)], dtype=torch.float64, device=mom.device)
+        if world > 1:
+            dist.all_reduce(mom, group=self.group)
+            dist.all_reduce(npx, group=self.group)
+        m = mom.cpu().numpy()
+        T, n_pixels = int(round(m[0])), int(round(float(npx.item())))
+        if T < 1:
+            raise TissueMaskException("Empty tissue mask computed")
+        mean = m[1:4] / T
+        S2 = np.array([[m[4], m[5], m[6]], [m[5], m[7], m[8]], [m[6], m[8], m[9]]])
+        cov = (S2 - T * np.outer(mean, mean)) / (T - 1.0)
+        _, V = np.linalg.eigh(cov)
+        V = V[:, [2, 1]].copy()
+        for i in range(2):
+            if V[0, i] < 0:
+                V[:, i] *= -1.0
+        Vf = V.astype(np.float32).astype(np.float64)                # the keys are evaluated in binary32
+        # ---- exact angular percentiles over those pixels (:29-34)
+        def pair(key, basis, k):
+            a, b, _ = exact_rank_pair(lambda pre, bits: engine.slide_key_histogram(tiles_local, key, basis, pre, bits, params=params),
+                                      lambda o: engine.slide_key_next_above(tiles_local, key, basis, o, params=params), k, self.group)
+            return ord_to_float(a), ord_to_float(b)
+
+        def angle_of_pseudo(p):
+            if abs(p) <= 1.0:
+                return math.atan2(p, 1.0 - abs(p))
+            pp = 2.0 - p if p > 0 else -2.0 - p
+            return math.atan2(pp, -(1.0 - abs(pp)))
+        phis = []
+        for pct in (100.0 - self.pct, self.pct):
+            k, g = percentile_position(T, pct)
+            xa, xb = pair(_ffi.KEY_ANGLE, Vf.reshape(6), k)
+            phis.append(np_lerp(angle_of_pseudo(xa), angle_of_pseudo(xb), g))
+        v1 = V @ np.array([math.cos(phis[0]), math.sin(phis[0])])          # :36-37
+        v2 = V @ np.array([math.cos(phis[1]), math.sin(phis[1])])
+        M = np.array([v1, v2]) if v1[0] > v2[0] else np.array([v2, v1])     # :40-43
+        M = M / np.linalg.norm(M, axis=1, keepdims=True)                    # :44
+        # ---- 99th percentile of each concentration over every pixel (normalizer.py:36,47)
+        k, g = percentile_position(n_pixels, 99.0)
+        maxC = []
+        for key in (_ffi.KEY_CONC0, _ffi.KEY_CONC1):
+            xa, xb = pair(key, M.reshape(6), k)
+            maxC.append(np_lerp(float(xa), float(xb), g))
+        return M, np.asarray(maxC, dtype=np.float64)
+
+
+class SlideNormalizer:
+    """Slide-level Macenko/Vahadane normalisation over a sharded set of tiles (see module docstring).
+
+    mode="median" (default): per-tile fits, all-gather, element-wise median.  mode="pooled": the exact statistics
+    of the concatenated slide (Macenko only)."""
+
+    def __init__(self, normalizer, group=None, mode="median"):
+        if mode not in ("median", "pooled"):
+            raise ValueError("mode must be 'median' or 'pooled'")
         self.normalizer = normalizer          # a fitted stainlib_amd ExtractiveStainNormalizer
         self.group = group
+        self.mode = mode
 
     def transform_shard(self, tiles_local: torch.Tensor, out: Optional[torch.Tensor] = None):
         """tiles_local: this rank's (n_local,H,W,3) uint8 device tensor.  Returns (out, M_slide, maxC_slide, status_local)."""
         from . import engine
+        if self.mode == "pooled":
+            M_np, maxC_np = PooledSlideStatistics(self.group)(tiles_local)
+            dev = tiles_local.device
+            n = tiles_local.shape[0]
+            M_s = torch.as_tensor(M_np, dtype=torch.float64, device=dev)
+            maxC_s = torch.as_tensor(maxC_np, dtype=torch.float64, device=dev)
+            out = engine.normalize_apply(tiles_local, M_s.expand(n, 2, 3).contiguous(), maxC_s.expand(n, 2).contiguous(),
+                                         self.normalizer.stain_matrix_target, self.normalizer.maxC_target.reshape(2), out=out)
+            return out, M_s, maxC_s, torch.zeros((n,), dtype=torch.int32, device=dev)
         M, maxC, status = self.normalizer.fit_batch_targets(tiles_local)
         M_all, maxC_all, st_all = gather_tile_stats(M, maxC, status, self.group)
         M_s, maxC_s = slide_statistics(M_all, maxC_all, st_all)

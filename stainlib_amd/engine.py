@@ -235,3 +235,44 @@ def synth_tiles(n, h, w, seed=0, device="cuda", M_true=None, chunk=32):
         del u, Cc, bg, od, rgb
     _ = math
     return out
+
+
+# ---- pooled slide-level mode: per-process reductions (combined over ranks in stainlib_amd.distributed) -------------
+def tile_moments(rgb, params=None, ws=None):
+    """(n, 10) float64 per tile: tissue count, sum od[3], sum od od^T [xx, xy, xz, yy, yz, zz]  (sl_tile_moments)."""
+    n, h, w = _check_tiles(rgb)
+    p = params if params is not None else _ffi.default_params()
+    out = torch.empty((n, 10), dtype=torch.float64, device=rgb.device)
+    wsb = (ws or _default_ws).get(_ffi.OP_TILE_MOMENTS, n, h, w, rgb.device)
+    _ffi.check(_ffi.lib().sl_tile_moments(_ptr(rgb), n, h, w, C.byref(p), _ptr(out), _ptr(wsb), wsb.numel(), _stream()),
+               "sl_tile_moments")
+    return out
+
+
+def _basis6(basis):
+    import numpy as np
+    b = np.ascontiguousarray(np.asarray(basis, dtype=np.float64).reshape(6))
+    return b, b.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def slide_key_histogram(rgb, key, basis, prefix, prefix_bits, hist=None, params=None):
+    """Accumulate into hist (256 int64, device) the next 8 key bits of this process's pixels whose key starts with `prefix`."""
+    n, h, w = _check_tiles(rgb)
+    p = params if params is not None else _ffi.default_params()
+    if hist is None:
+        hist = torch.zeros((256,), dtype=torch.int64, device=rgb.device)
+    keep, bp = _basis6(basis)
+    _ffi.check(_ffi.lib().sl_slide_key_histogram(_ptr(rgb), n, h, w, C.byref(p), int(key), bp, int(prefix) & 0xffffffff,
+                                                 int(prefix_bits), _ptr(hist), _stream()), "sl_slide_key_histogram")
+    return hist
+
+
+def slide_key_next_above(rgb, key, basis, key_ord, params=None):
+    """Smallest key (ordered uint32, as a Python int) above key_ord among this process's pixels; 0xffffffff if none."""
+    n, h, w = _check_tiles(rgb)
+    p = params if params is not None else _ffi.default_params()
+    mn = torch.full((1,), -1, dtype=torch.int32, device=rgb.device)        # 0xffffffff
+    keep, bp = _basis6(basis)
+    _ffi.check(_ffi.lib().sl_slide_key_next_above(_ptr(rgb), n, h, w, C.byref(p), int(key), bp, int(key_ord) & 0xffffffff,
+                                                  _ptr(mn), _stream()), "sl_slide_key_next_above")
+    return int(mn.item()) & 0xffffffff

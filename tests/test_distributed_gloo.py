@@ -81,3 +81,71 @@ def test_single_process_passthrough_and_errors():
     assert torch.equal(Ma, M) and torch.equal(ca, maxC) and torch.equal(sa, status)
     with pytest.raises(ValueError):
         sd.slide_statistics(M, maxC, torch.ones(5, dtype=torch.int32))
+
+
+# ---- pooled slide-level mode: the distributed exact order statistic (radix select over all-reduced histograms) ----
+def _f2ord(a):
+    u = np.asarray(a, np.float32).view(np.uint32)
+    return np.where(u & 0x80000000, ~u, u | 0x80000000).astype(np.uint32)
+
+
+def _keys(rank, world, n=5000, seed=3):
+    rng = np.random.RandomState(seed)
+    allk = np.concatenate([rng.randn(n).astype(np.float32), np.zeros(400, np.float32), np.float32([1.5] * 7)])  # ties + zeros
+    rng.shuffle(allk)
+    lo, hi = sd.shard_range(len(allk), rank, world)
+    return allk, allk[lo:hi]
+
+
+def _rank_pair_with_numpy_histograms(mine, k):
+    """Stand-in for the device kernels: histograms / next-above of THIS rank's keys with numpy."""
+    o = _f2ord(mine).astype(np.uint64)
+
+    def hist_fn(prefix, bits):
+        sel = o if bits == 0 else o[(o >> np.uint64(32 - bits)) == np.uint64(prefix)]
+        b = (sel >> np.uint64(24 - bits)) & np.uint64(255)
+        return torch.from_numpy(np.bincount(b.astype(np.int64), minlength=256).astype(np.int64))
+
+    def next_above_fn(key):
+        g = o[o > np.uint64(key)]
+        return int(g.min()) if len(g) else 0xffffffff
+    return sd.exact_rank_pair(hist_fn, next_above_fn, k)
+
+
+def _worker_rank_pair(rank, world, port, ks, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _, mine = _keys(rank, world)
+    q.put((rank, [_rank_pair_with_numpy_histograms(mine, k) for k in ks]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exact_rank_pair_world2_matches_sorted_union():
+    ks = [0, 53, 2500, 2699, 5399, 5406, 10 ** 9]          # incl. inside the block of ties and beyond the end
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_rank_pair, args=(r, 2, port, ks, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    allk, _ = _keys(0, 1)
+    srt = np.sort(allk)
+    assert res[0][1] == res[1][1]                            # identical on every rank
+    for k, (a, b, total) in zip(ks, res[0][1]):
+        kk = min(k, len(srt) - 1)
+        assert total == len(srt)
+        assert sd.ord_to_float(a) == srt[kk] and sd.ord_to_float(b) == srt[min(kk + 1, len(srt) - 1)]
+
+
+def test_percentile_position_and_lerp_follow_numpy():
+    rng = np.random.RandomState(0)
+    x = np.sort(rng.rand(1001))
+    for pct in (1.0, 99.0, 50.0, 0.0, 100.0):
+        k, g = sd.percentile_position(len(x), pct)
+        assert sd.np_lerp(x[k], x[min(k + 1, len(x) - 1)], g) == np.percentile(x, pct)

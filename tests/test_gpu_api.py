@@ -171,3 +171,25 @@ def test_tile_pipeline_matches_direct_transform():
     for b, o in zip(batches, outs):
         direct = n.transform_batch(to_dev(b))[0].cpu().numpy()
         assert np.array_equal(o, direct)
+
+
+def test_pooled_slide_mode_matches_reference_on_concatenated_tiles():
+    """the pooled slide statistics are the reference's statistics of the vertical concatenation."""
+    import stainlib_amd as sl
+    from stainlib_amd.distributed import SlideNormalizer, PooledSlideStatistics
+    tiles = [so.synth_tile(96, 128, 70 + s) for s in range(5)] + [np.full((96, 128, 3), 255, np.uint8)]
+    tall = np.concatenate(tiles, axis=0)                                  # (576, 128, 3)
+    M_want = so.macenko_stain_matrix(tall)
+    maxC_want = np.percentile(so.get_concentrations(tall, M_want), 99, axis=0)
+    dev = to_dev(tiles)
+    M_got, maxC_got = PooledSlideStatistics()(dev)
+    np.testing.assert_allclose(M_got, M_want, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(maxC_got, maxC_want, rtol=2e-6)
+    tgt = so.synth_tile(128, 128, 1001, so.M_TRUE_TGT)
+    n = sl.MacenkoNormalizer()
+    n.fit(tgt)
+    out, M_s, mc_s, status = SlideNormalizer(n, mode="pooled").transform_shard(dev)
+    on = so.ExtractiveStainNormalizer("macenko")
+    on.fit(tgt)
+    want = on.transform(tall)                                             # the reference recipe on the tall image
+    u8_parity(out.cpu().numpy().reshape(tall.shape), want, max_rate=4e-4)
