@@ -156,7 +156,9 @@ def _fused_batch(h, w, n=66):
     return tiles
 
 
-@pytest.mark.parametrize("h,w", [(64, 64), (96, 130), (33, 47)])
+# (32,32) and (24,40): fewer chunks than threads, i.e. whole waves of the workgroup hold no pixel (aligned path);
+# (33,47): the same on the byte-wise path; (1,517): a one-row tile
+@pytest.mark.parametrize("h,w", [(64, 64), (96, 130), (33, 47), (32, 32), (24, 40), (1, 517)])
 def test_fused_schedule_vs_oracle(h, w):
     from stainlib_amd import engine
     tiles = _fused_batch(h, w)

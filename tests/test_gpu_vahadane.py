@@ -19,7 +19,7 @@ def _oracle_fit(I):
     return M, np.percentile(C, 99, axis=0), info
 
 
-@pytest.mark.parametrize("h,w", [(96, 96), (128, 160), (33, 47)])
+@pytest.mark.parametrize("h,w", [(96, 96), (128, 160), (33, 47), (32, 40)])   # (32,40): waves without pixels
 def test_vahadane_fit_vs_converged_oracle(h, w):
     from stainlib_amd import engine
     tiles = [so.synth_tile(h, w, s) for s in (2, 3, 4)]
