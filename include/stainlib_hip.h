@@ -188,6 +188,11 @@ int sl_tissue_mask(const uint8_t* rgb, int n, int h, int w, double luminosity_th
 int sl_concentrations(const uint8_t* rgb, int n, int h, int w, const double* M,
                       double lasso_lambda, float* C_out, void* stream);
 
+/* GrayscaleAugmentor.pop (augmentation/augmenter.py:390-401): out = 3 x uint8(255 * clip(rgb2gray * alpha +
+ * beta, 0, 1)), binary64 arithmetic like the reference.  alpha_beta: n x 2 doubles (device). */
+int sl_grayscale_augment(const uint8_t* rgb, uint8_t* out, int n, int h, int w, const double* alpha_beta,
+                         void* stream);
+
 /* ---- pooled slide-level mode (BASELINE.json configs[4]; an extension: the reference has no notion of a slide).
  * Every tile of a slide gets the statistics the reference would compute from the vertical concatenation of all
  * the tiles.  Each call reduces THIS process's tiles; the host sums / all-reduces the small results over ranks

@@ -408,6 +408,35 @@ class StainAugmentor:
 
 
 # --------------------------------------------------------------------------
+# GrayscaleAugmentor  (augmentation/augmenter.py:374-401)
+# --------------------------------------------------------------------------
+def rgb2gray(I: np.ndarray) -> np.ndarray:
+    """skimage 0.18 color.rgb2gray on a uint8 image: img_as_float (x * (1/255), binary64) @ [0.2125, 0.7154, 0.0721]."""
+    rgb = np.multiply(I[..., :3], 1.0 / 255, dtype=np.float64)
+    return rgb @ np.array([0.2125, 0.7154, 0.0721], dtype=np.float64)
+
+
+class GrayscaleAugmentor:
+    def __init__(self, sigma1=0.2, sigma2=0.2, augment_background=False):
+        self.sigma1, self.sigma2, self.augment_background = sigma1, sigma2, augment_background   # :376-378 (unused by pop)
+
+    def fit(self, I):
+        self.image_shape = I.shape                                               # :386
+        self.tissue_mask = tissue_mask(I).ravel()                                # :387 (raises on an empty mask)
+        self.image = I
+
+    def pop_with(self, alpha, beta):
+        g = np.clip(rgb2gray(self.image) * alpha + beta, 0, 1)                   # :396-397
+        g3 = np.stack([g, g, g], axis=2)                                         # :398
+        return np.clip(g3 * 255, 0, 255).astype(np.uint8)                        # :399
+
+    def pop(self):
+        alpha = np.random.uniform(1 - 0.2, 1 + 0.2)                              # :394 (literal 0.2, not sigma1)
+        beta = np.random.uniform(-0.2, 0.2)                                      # :395
+        return self.pop_with(alpha, beta)
+
+
+# --------------------------------------------------------------------------
 # Synthetic H&E tiles (SURVEY.md section 8d) -- shared by tests and bench
 # --------------------------------------------------------------------------
 M_TRUE_SRC = np.array([[0.65, 0.70, 0.29], [0.07, 0.99, 0.11]])

@@ -71,6 +71,7 @@ _SIGNATURES = {
     "sl_stain_augment": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.POINTER(SlParams), _P]),
     "sl_tissue_mask": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_double, _P, _P, _P]),
     "sl_concentrations": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_double, _P, _P]),
+    "sl_grayscale_augment": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "sl_tile_moments": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(SlParams), _P, _P, C.c_size_t, _P]),
     "sl_slide_key_histogram": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(SlParams), C.c_int, C.POINTER(C.c_double),
                                           C.c_uint32, C.c_int, _P, _P]),

@@ -200,3 +200,32 @@ class StainAugmentor(object):
         from .. import engine
         out = engine.stain_augment(self._dev, self.stain_matrix[None], [alpha_beta], self.augment_background)
         return out[0].cpu().numpy()
+
+
+class GrayscaleAugmentor(object):
+    """Grayscale intensity augmentation of a fitted image (augmenter.py:374-401)."""
+
+    def __init__(self, sigma1=0.2, sigma2=0.2, augment_background=False):
+        self.sigma1 = sigma1
+        self.sigma2 = sigma2
+        self.augment_background = augment_background
+        self._dev = None
+
+    def fit(self, I):
+        """augmenter.py:380-388 (the tissue mask is computed there too, so an all-background image raises here)."""
+        self.image_shape = I.shape
+        self.tissue_mask = LuminosityThresholdTissueLocator.get_tissue_mask(I).ravel()
+        self.image = I
+        self._dev = _to_device(I)
+
+    def pop(self):
+        """One augmented version; alpha ~ U(0.8, 1.2), beta ~ U(-0.2, 0.2) from the global numpy stream -- the reference
+        uses the literal 0.2 here, not sigma1 / sigma2 (augmenter.py:394-395)."""
+        alpha = np.random.uniform(1 - 0.2, 1 + 0.2)
+        beta = np.random.uniform(-0.2, 0.2)
+        return self.pop_with(alpha, beta)
+
+    def pop_with(self, alpha, beta):
+        from .. import engine
+        return engine.grayscale_augment(self._dev, [[alpha, beta]])[0].cpu().numpy()
+

@@ -45,6 +45,19 @@ extern "C" int sl_stain_augment(const uint8_t* rgb, uint8_t* out, int n, int h, 
     return launch_status();
 }
 
+extern "C" int sl_grayscale_augment(const uint8_t* rgb, uint8_t* out, int n, int h, int w, const double* alpha_beta,
+                                   void* stream) {
+    if (!rgb || !out || !alpha_beta || n <= 0 || h <= 0 || w <= 0) return SL_ERR_BADARG;
+    const long P = (long)h * w;
+    if (P > (1L << 30)) return SL_ERR_BADARG;
+    const int parts = parts_for(P);
+    const dim3 grid((unsigned)((long)n * parts)), block(kWG);
+    hipStream_t s = (hipStream_t)stream;
+    if (aligned4(rgb, P) && aligned4(out, P)) hipLaunchKernelGGL((k_grayscale<true>), grid, block, 0, s, rgb, out, (int)P, parts, alpha_beta);
+    else hipLaunchKernelGGL((k_grayscale<false>), grid, block, 0, s, rgb, out, (int)P, parts, alpha_beta);
+    return launch_status();
+}
+
 extern "C" int sl_concentrations(const uint8_t* rgb, int n, int h, int w, const double* M, double lasso_lambda,
                                  float* C_out, void* stream) {
     if (!rgb || !M || !C_out || n <= 0 || h <= 0 || w <= 0) return SL_ERR_BADARG;

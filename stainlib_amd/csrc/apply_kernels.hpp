@@ -333,6 +333,41 @@ static __global__ __launch_bounds__(kWG) void k_stain_augment(const uint8_t* __r
     }
 }
 
+// GrayscaleAugmentor.pop (augmenter.py:390-401): skimage rgb2gray on the uint8 image (x * (1/255) in binary64, weights
+// 0.2125 / 0.7154 / 0.0721), * alpha + beta, clip [0,1], * 255, truncate, replicated on three channels.  Binary64
+// like the reference (the pass is HBM bound: 6 B/px against ~10 binary64 ops), so the truncation sees the same value.
+template <bool ALIGNED>
+static __global__ __launch_bounds__(kWG) void k_grayscale(const uint8_t* __restrict__ rgb, uint8_t* __restrict__ out, int P,
+                                                          int parts, const double* __restrict__ alpha_beta) {
+    const int tile = blockIdx.x / parts, part = blockIdx.x % parts;
+    const double alpha = alpha_beta[2 * (size_t)tile], beta = alpha_beta[2 * (size_t)tile + 1];
+    const size_t nbytes = (size_t)P * 3;
+    const uint8_t* src = rgb + (size_t)tile * nbytes;
+    uint8_t* dst = out + (size_t)tile * nbytes;
+    const int nch = (P + 3) >> 2;
+    const int span = (nch + parts - 1) / parts;
+    const int c0 = part * span, c1 = min(nch, c0 + span);
+    const double k = 1.0 / 255;
+    for (int c = c0 + (int)threadIdx.x; c < c1; c += kWG) {
+        const Chunk in = load_chunk<ALIGNED>(src, nbytes, c);
+        uint32_t v[4];
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            const double r = (double)chunk_byte(in, 3 * px) * k, g = (double)chunk_byte(in, 3 * px + 1) * k,
+                         b = (double)chunk_byte(in, 3 * px + 2) * k;
+            double y = __dadd_rn(__dadd_rn(__dmul_rn(r, 0.2125), __dmul_rn(g, 0.7154)), __dmul_rn(b, 0.0721));   // no contraction
+            y = __dadd_rn(__dmul_rn(y, alpha), beta);
+            y = fmin(fmax(y, 0.0), 1.0);
+            v[px] = (uint32_t)fmin(fmax(y * 255.0, 0.0), 255.0);
+        }
+        Chunk o;
+        o.w0 = v[0] * 0x010101u | (v[1] << 24);
+        o.w1 = (v[1] * 0x0101u) | (v[2] * 0x01010000u);
+        o.w2 = v[2] | (v[3] * 0x01010100u);
+        store_chunk<ALIGNED>(dst, nbytes, c, o);
+    }
+}
+
 static __global__ __launch_bounds__(kWG) void k_concentrations(const uint8_t* __restrict__ rgb, int P, int parts,
                                                         const double* __restrict__ M, double lam,
                                                         float* __restrict__ C_out) {

@@ -190,6 +190,16 @@ def stain_augment(rgb, M, alpha_beta, augment_background=False, params=None, out
     return out
 
 
+def grayscale_augment(rgb, alpha_beta, out=None):
+    """GrayscaleAugmentor.pop on a batch: alpha_beta (n, 2) -> (n, H, W, 3) uint8 with three equal channels."""
+    n, h, w = _check_tiles(rgb)
+    ab = _f64(alpha_beta, (n, 2), rgb.device)
+    if out is None:
+        out = torch.empty_like(rgb)
+    _ffi.check(_ffi.lib().sl_grayscale_augment(_ptr(rgb), _ptr(out), n, h, w, _ptr(ab), _stream()), "sl_grayscale_augment")
+    return out
+
+
 def tissue_mask(rgb, luminosity_threshold=0.8, want_mask=True):
     """(mask (N,H,W) uint8 or None, counts (N,) int64)."""
     n, h, w = _check_tiles(rgb)

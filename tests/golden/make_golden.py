@@ -173,6 +173,21 @@ def stainaug_case(size, seed, npseed, background):
     return rec
 
 
+def grayscale_case(size, seed, npseed):
+    from stainlib.augmentation.augmenter import GrayscaleAugmentor
+    I = so.synth_tile(size, size, seed)
+    aug = GrayscaleAugmentor()
+    aug.fit(I)
+    rec = {"size": size, "seed": seed, "npseed": npseed, "input_sha": sha(I)}
+    np.random.seed(npseed)
+    st = np.random.get_state()
+    rec["out0"] = aug.pop()
+    rec["out1"] = aug.pop()
+    np.random.set_state(st)
+    rec["draws0"] = np.array([np.random.uniform(0.8, 1.2), np.random.uniform(-0.2, 0.2)])   # alpha, beta of out0
+    return rec
+
+
 def errors_case():
     rec = {}
     try:
@@ -211,6 +226,7 @@ def main():
     save("hed_128_s3_np123", hed_case(128, 3, 123))
     save("stainaug_128_s2_np7", stainaug_case(128, 2, 7, False))
     save("stainaug_128_s3_np7_bg", stainaug_case(128, 3, 7, True))
+    save("grayscale_128_s2_np11", grayscale_case(128, 2, 11))
     save("errors", errors_case())
 
 

@@ -135,3 +135,14 @@ def test_lab_threshold_index():
     assert np.array_equal(so.lab_l8(I) / 255.0 < 0.8, so.lab_y_index(I) <= 1146)
     assert so.lab_l8(np.full((1, 1, 3), 255, np.uint8))[0, 0] == 255
     assert so.lab_l8(np.zeros((1, 1, 3), np.uint8))[0, 0] == 0
+
+
+def test_grayscale_augmentor_golden():
+    g = np.load(os.path.join(GOLDEN, "grayscale_128_s2_np11.npz"))
+    I = so.synth_tile(128, 128, int(g["seed"]))
+    a = so.GrayscaleAugmentor()
+    a.fit(I)
+    np.random.seed(int(g["npseed"]))
+    assert np.array_equal(a.pop(), g["out0"]) and np.array_equal(a.pop(), g["out1"])
+    assert np.array_equal(a.pop_with(*g["draws0"]), g["out0"])
+
