@@ -749,7 +749,6 @@ __device__ __forceinline__ void select_sweep(const uint8_t* src, int P, int c0, 
         for (int px = 0; px < 4; ++px) {
             // flagged = valid and not provably plain.  The lane mask is assembled from ballots of BARE compares.
             unsigned long long m;
-            bool mine;
             if constexpr (STAGE == kStageAngle) {
                 const float2 er = g.v[3 * px], eg = g.v[3 * px + 1], eb = g.v[3 * px + 2];
                 const bool tc = is_tissue_f(er.x, eg.x, eb.x, ylimf);
@@ -759,20 +758,17 @@ __device__ __forceinline__ void select_sweep(const uint8_t* src, int P, int c0, 
                 const float t0 = fmaf(nhi0m, d, y), t1 = fmaf(nlo1m, d, y);
                 const bool pp = fminf(fminf(x, t0), -t1) > 0.0f;             // x > 0, y > hi0m d, y < lo1m d
                 m = __builtin_amdgcn_ballot_w64(tc) & ~__builtin_amdgcn_ballot_w64(pp);
-                mine = tc & !pp;
             } else {
                 float a1, a2;
                 lasso_interior(K.L, g.v[3 * px], g.v[3 * px + 1], g.v[3 * px + 2], a1, a2);
                 const bool g1 = a1 >= clo0, g2 = a2 >= clo1;
                 m = __builtin_amdgcn_ballot_w64(g1) | __builtin_amdgcn_ballot_w64(g2);
-                mine = g1 | g2;
             }
             if (TAIL) {
                 const bool inb = (cc < c1) & (ALIGNED | ((size_t)cc * 4 + px < (size_t)P));
                 m &= __builtin_amdgcn_ballot_w64(inb);
-                mine = mine & inb;
             }
-            sink.put(m, mine, ch, px, lane);
+            sink.put(m, ch, px, lane);
         }
     };
     Chunk cur[kTrip], nx[kTrip];                             // see moments_sweep
@@ -983,17 +979,26 @@ struct RawSink {
     unsigned int* overflow;     // (unused by this sink: an over-full list shows as head > cap)
     uint32_t cap;               // capacity of dst
     __device__ __forceinline__ void flush(int) {
-        if (n == 0) return;
-        raw_flush(buf, n, dst, head, cap);
+        if (n != 0) raw_flush(buf, n, dst, head, cap);
         n = 0;
     }
-    // one pixel row of the wave: m = lane mask of the flagged lanes (a wave-uniform value), mine = this lane's bit
-    __device__ __forceinline__ void put(unsigned long long m, bool mine, const Chunk& ch, int px, int lane) {
-        if (m == 0) return;                                         // wave-uniform: ~1 row in 7 has no candidate
+    // One pixel row of the wave: m = lane mask of the flagged lanes (a wave-uniform value).  Branch-free on the hot
+    // path: the masked LDS write is an asm block that swaps EXEC itself (measured: the three branches per row of
+    // the structured version cost more than all the arithmetic of the sweep).
+    __device__ __forceinline__ void put(unsigned long long m, const Chunk& ch, int px, int lane) {
         const uint32_t cnt = (uint32_t)__popcll(m);
-        if (n + cnt > (uint32_t)kStageWave) flush(lane);            // a row holds <= 64 entries: always fits afterwards
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-        if (mine) buf[n + rank] = chunk_pixel(ch, px) & 0xffffffu;
+        if (__builtin_expect(n + cnt > (uint32_t)kStageWave, 0)) flush(lane);   // rare, out of line; a row holds <= 64 entries
+        // fill level + rank of this lane among the flagged lanes: the fill level rides in as v_mbcnt's addend
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, n));
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uint32_t addr = lds_address(buf) + 4u * rank;
+        const uint32_t raw = chunk_pixel(ch, px) & 0xffffffu;
+        unsigned long long saved;
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_write_b32 %2, %3\n\ts_mov_b64 exec, %0"
+                     : "=&s"(saved) : "s"(m), "v"(addr), "v"(raw) : "memory");
+#else
+        (void)rank; (void)ch; (void)px;
+#endif
         n += cnt;
     }
 };
