@@ -152,9 +152,9 @@ __device__ __forceinline__ Chunk pack_trunc_general(const float (&t)[12]) {
 // The apply sweep over chunks [c0, c1) of one tile with `nthreads` cooperating threads, table values from the
 // row table.  Two chunks per trip; the next trip's chunks are in flight during the current one and the 12 table
 // gathers of a chunk are issued one chunk ahead of its arithmetic.
-template <bool ALIGNED, bool FAST>
+template <bool ALIGNED, bool FAST, class TR>
 __device__ __forceinline__ void apply_sweep(const uint8_t* src, uint8_t* dst, int P, int c0, int c1, int t, int nthreads,
-                                            const TabReader& T, const ApplyK& K) {
+                                            const TR& T, const ApplyK& K) {
     const size_t nbytes = (size_t)P * 3;
     struct G { float v[12]; };
     auto fetch = [&](int cc) { return load_chunk_clamped<ALIGNED>(src, nbytes, cc, c1); };

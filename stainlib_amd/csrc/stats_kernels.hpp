@@ -109,6 +109,10 @@ __device__ __forceinline__ TabView view_of(const RowTab& t) {
     const uint32_t c = (uint32_t)sizeof(TabEntry) * (threadIdx.x & (kTabCopies - 1));
     return TabView{lds_address(&t), (uint32_t)sizeof(TabEntry) * kTabCopies, c + 12u, c + 8u};
 }
+__device__ __forceinline__ TabView view_of_b(const RowTab& t) {                 // layout B: 32 x {gamma, od32}
+    const uint32_t c = 8u * (threadIdx.x & 31u);
+    return TabView{lds_address(&t), 256u, c + 4u, c};
+}
 // the 2 KB version for kernels that only run finish steps
 struct SmallTab {
     float f[256], g[256];
@@ -1341,8 +1345,8 @@ static __global__ __launch_bounds__(kSweepThreads, 4) void k_select(StatsArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     TileState& st = a.state[tile];
     if (st.status != SL_TILE_OK) return;                                   // block-uniform
-    s_tab.fill();
-    const TabReader T = TabReader::make(s_tab);
+    s_tab.fill_b();
+    const TabReaderB T = TabReaderB::make(s_tab);
     SelConsts K;
     if (STAGE == kStageAngle) {
         for (int i = 0; i < 6; ++i) K.V[i] = in_vgpr(st.Vf[i]);
@@ -1537,9 +1541,8 @@ template <int METHOD, bool TRANSFORM, bool ALIGNED>
 static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) {
     __shared__ FusedShared sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    sh.tab.fill();
-    __syncthreads();
-    const TabReader T = TabReader::make(sh.tab);
+    const TabReader T = TabReader::make(sh.tab);          // layout A: moment / dictionary sweeps
+    const TabReaderB TB = TabReaderB::make(sh.tab);       // layout B: everything after them
     const int nch = (a.P + 3) >> 2;
     uint32_t* samp = a.sample + (size_t)blockIdx.x * a.n_sample;
     uint32_t* rawl = a.raw + (size_t)blockIdx.x * a.cap_raw;
@@ -1551,7 +1554,7 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
         constexpr int STAGE = decltype(stage_tag)::value;
         K.lo0 = uni(sh.lo[0]); K.hi0 = uni(sh.hi[0]); K.lo1 = uni(sh.lo[1]); K.hi1 = uni(sh.hi[1]);
         RawSink sink{sh.stage[wave], 0u, rawl, &sh.n_raw, &sh.overflow, (uint32_t)a.cap_raw};
-        select_sweep<STAGE, ALIGNED, kFusedTrip>(src, a.P, 0, nch, tid, kFusedThreads, T, a.ylimf, K, sink);
+        select_sweep<STAGE, ALIGNED, kFusedTrip>(src, a.P, 0, nch, tid, kFusedThreads, TB, a.ylimf, K, sink);
         sink.flush(lane);
         __threadfence_block();
         __syncthreads();
@@ -1564,6 +1567,8 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
         int sweeps_used = 0;
 #define SL_PHASE(i) { if (a.phase_clock && tid == 0) a.phase_clock[(size_t)tile * 8 + (i)] = wall_clock64(); if (a.debug_stop == (i) + 1) { __syncthreads(); continue; } }
         SL_PHASE(0);
+        sh.tab.fill();                       // layout A for the moment / dictionary sweeps (all waves left the last tile's apply)
+        __syncthreads();
 
         if (METHOD == kMethodMacenko) {
             // ---------------- sweep 1: moments + sample
@@ -1579,6 +1584,7 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
                     for (int i = 0; i < 10; ++i) sh.red[wave][i] = v[i];
             }
             __syncthreads();
+            sh.tab.fill_b();                 // every wave is past sweep 1: switch the table to layout B (~1 us)
             if (tid < 10) {
                 double t = 0;
                 for (int w = 0; w < kFusedThreads / 64; ++w) t += sh.red[w][tid];
@@ -1598,7 +1604,7 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
             if (sh.status == SL_TILE_OK) {                                    // block-uniform
                 {
                     SampleAngleKey key;
-                    key.sample = samp; key.tab = view_of(sh.tab); key.cps_log2 = a.stride_log2 - 2; key.P = a.P; key.ylimf = a.ylimf;
+                    key.sample = samp; key.tab = view_of_b(sh.tab); key.cps_log2 = a.stride_log2 - 2; key.P = a.P; key.ylimf = a.ylimf;
                     for (int i = 0; i < 6; ++i) key.V[i] = sh.Vf[i];
                     float lo[2], hi[2];
                     angle_brackets<kFusedThreads>(key, a.n_sample, a.pct, lo, hi, sh.S);
@@ -1621,9 +1627,9 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
                 percentile_pos((double)T, 100.0 - a.pct, k[0], gfrac[0]);
                 percentile_pos((double)T, a.pct, k[1], gfrac[1]);
                 AngleTileKey tkey;
-                tkey.src = src; tkey.tab = view_of(sh.tab); tkey.ylimf = a.ylimf;
+                tkey.src = src; tkey.tab = view_of_b(sh.tab); tkey.ylimf = a.ylimf;
                 RawAngleKey2 rkey;
-                rkey.raw = rawl; rkey.tab = view_of(sh.tab);
+                rkey.raw = rawl; rkey.tab = view_of_b(sh.tab);
                 for (int i = 0; i < 6; ++i) { tkey.V[i] = sh.Vf[i]; rkey.V[i] = sh.Vf[i]; }
                 const bool complete = sh.n_raw <= (uint32_t)a.cap_raw && sh.overflow == 0;
                 const uint32_t n_raw = sh.n_raw < (uint32_t)a.cap_raw ? sh.n_raw : (uint32_t)a.cap_raw;
@@ -1743,6 +1749,7 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
                 const double nh = sqrt(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]), ne = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
                 for (int k = 0; k < 3; ++k) { sh.M[k] = h[k] / nh; sh.M[3 + k] = e[k] / ne; }
             }
+            sh.tab.fill_b();                 // the dictionary sweeps are over: layout B from here on
         }
         __syncthreads();
         const bool bad = sh.status != SL_TILE_OK;                               // block-uniform
@@ -1757,7 +1764,7 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
             // ---------------- concentration brackets from the sample
             {
                 SampleConcKey ckey;
-                ckey.sample = samp; ckey.tab = view_of(sh.tab); ckey.L = sh.L; ckey.cps_log2 = a.stride_log2 - 2;
+                ckey.sample = samp; ckey.tab = view_of_b(sh.tab); ckey.L = sh.L; ckey.cps_log2 = a.stride_log2 - 2;
                 ckey.P = a.P; ckey.col = 0;
                 float lo[2], hi[2];
                 conc_brackets<kFusedThreads>(ckey, a.n_sample, lo, hi, sh.S);
@@ -1779,9 +1786,9 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
                 double gfrac;
                 percentile_pos((double)a.P, 99.0, k, gfrac);
                 ConcTileKey tkey;
-                tkey.src = src; tkey.tab = view_of(sh.tab); tkey.L = sh.L;
+                tkey.src = src; tkey.tab = view_of_b(sh.tab); tkey.L = sh.L;
                 RawConcKey2 rkey;
-                rkey.raw = rawl; rkey.tab = view_of(sh.tab); rkey.L = sh.L;
+                rkey.raw = rawl; rkey.tab = view_of_b(sh.tab); rkey.L = sh.L;
                 const bool complete = sh.n_raw <= (uint32_t)a.cap_raw && sh.overflow == 0;
                 const uint32_t n_raw = sh.n_raw < (uint32_t)a.cap_raw ? sh.n_raw : (uint32_t)a.cap_raw;
                 const float los[2] = {sh.lo[0], sh.lo[1]}, his[2] = {sh.hi[0], sh.hi[1]};
@@ -1822,8 +1829,8 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
             } else {
                 ApplyK K;
                 apply_consts(sh.M, sh.maxC, a.M_tgt, a.maxC_tgt, a.lam, K);
-                if (K.fast) apply_sweep<ALIGNED, true>(src, dst, a.P, 0, nch, tid, kFusedThreads, T, K);
-                else apply_sweep<ALIGNED, false>(src, dst, a.P, 0, nch, tid, kFusedThreads, T, K);
+                if (K.fast) apply_sweep<ALIGNED, true>(src, dst, a.P, 0, nch, tid, kFusedThreads, TB, K);
+                else apply_sweep<ALIGNED, false>(src, dst, a.P, 0, nch, tid, kFusedThreads, TB, K);
             }
         }
         __syncthreads();     // sh.* is reused by the next tile
