@@ -1,9 +1,8 @@
 // macenko.hip -- host schedule + C ABI of the Macenko fit / transform (kernels: stats_kernels.hpp).
 //
-// Tiles are processed in GROUPS sized to stay resident in the 256 MiB Infinity Cache, so that the
-// second, third and fourth sweep of a group re-read the uint8 tiles on-die instead of from HBM
-// (tile-major schedule, SURVEY 7 hard part 4).  Per group: 3 sweeps + 3 one-workgroup-per-tile
-// finish kernels (+ the apply sweep for transform), all on the caller's stream, no host sync.
+// One-launch-per-phase schedule (batches below kFusedMinTiles): tiles are processed in groups of up to 1 GiB of
+// uint8 (bounds the workspace); per group 3 sweeps + 3 one-workgroup-per-tile finish kernels (+ the apply sweep
+// for transform), all on the caller's stream, no host sync.  Larger batches run the persistent fused kernel.
 #include "stats_kernels.hpp"
 #include "sl_host.hpp"
 
@@ -11,9 +10,10 @@ using namespace sl;
 
 namespace {
 
-constexpr size_t kGroupBytes = 96u << 20;   // uint8 bytes of one tile group (fits the 256 MiB MALL with output + slack)
+constexpr size_t kGroupBytes = (size_t)1 << 30;   // uint8 bytes of one tile group of the per-phase schedule (measured: big groups win --
+                                                  // the one-workgroup-per-tile finish kernels need many tiles to fill the chip; cache reuse between sweeps does not matter)
 
-constexpr int kFusedMinTiles = 144;         // measured crossover (tools/crossover.py): below it one launch per phase wins
+constexpr int kFusedMinTiles = 320;         // measured crossover (tools/crossover.py): below it one launch per phase wins
 constexpr int kFusedMaxGrid = 512;          // 2 resident 1024-thread workgroups per CU x 256 CUs
 
 struct Layout {
@@ -64,6 +64,7 @@ int run_stats_group(const uint8_t* rgb, int g0, int m, long P, const SlParams& p
     a.rgb = rgb + (size_t)g0 * 3 * P;
     a.P = (int)P;
     a.parts = L.parts;
+    a.n_items = m * L.parts;
     a.stride_log2 = L.stride_log2;
     a.n_sample = L.n_sample;
     a.ylimf = (float)y_limit_for_threshold(p.luminosity_threshold) - 2048.0f;   // exact: y_lim < 2^24
@@ -77,7 +78,8 @@ int run_stats_group(const uint8_t* rgb, int g0, int m, long P, const SlParams& p
     a.cand = (float*)(ws + L.off_list);
     a.state = (TileState*)(ws + L.off_state);
     const bool al = aligned4(a.rgb, P);
-    const dim3 gs((unsigned)((long)m * L.parts)), bs(kSweepThreads), gf((unsigned)m), bf(kFinishThreads);
+    const long items = (long)m * L.parts;
+    const dim3 gs((unsigned)(items < kFusedMaxGrid ? items : kFusedMaxGrid)), bs(kSweepThreads), gf((unsigned)m), bf(kFinishThreads);
     SlProfile* prof = p.profile;
     {
         ProfScope ps(prof, SL_PROF_MOMENTS, m, s);

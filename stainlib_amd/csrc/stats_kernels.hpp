@@ -71,7 +71,8 @@ struct TileState {
 struct StatsArgs {
     const uint8_t* rgb;      // first tile of the group / batch
     int P;
-    int parts;               // workgroups per tile (multi-kernel schedule)
+    int parts;               // parts per tile (multi-kernel schedule)
+    int n_items;             // tiles x parts of this group: the work list of the persistent sweep kernels
     int stride_log2;         // sampling stride = 1 << stride_log2 (>= 6)
     int n_sample;            // ceil(P / stride)
     float ylimf;             // tissue test threshold: y_lim - 2048 (see is_tissue_f)
@@ -1237,6 +1238,8 @@ __device__ __forceinline__ void part_range(int nch, int parts, int part, int& c0
     c1 = min(nch, c0 + span);
 }
 
+// The sweep kernels of this schedule are persistent too: at most 2 workgroups per CU, each filling its 64 KB table
+// once and then walking (tile, part) items blockIdx.x, +gridDim.x, ...  (StatsArgs.n_items = tiles x parts).
 template <bool ALIGNED>
 static __global__ __launch_bounds__(kSweepThreads, 4) void k_moments(StatsArgs a) {
     __shared__ RowTab s_tab;
@@ -1244,26 +1247,29 @@ static __global__ __launch_bounds__(kSweepThreads, 4) void k_moments(StatsArgs a
     s_tab.fill();
     __syncthreads();
     const TabReader T = TabReader::make(s_tab);
-    const int tile = blockIdx.x / a.parts, part = blockIdx.x % a.parts;
     const int tid = threadIdx.x, lane = tid & 63;
-    const uint8_t* src = a.rgb + (size_t)tile * a.P * 3;
-    uint32_t* samp = a.sample + (size_t)tile * a.n_sample;
-    int c0, c1;
-    part_range((a.P + 3) >> 2, a.parts, part, c0, c1);
-    Moments mo;
-    uint32_t n_tissue = 0;
-    moments_sweep<ALIGNED, kPhaseTrip>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, a.stride_log2, samp, mo, n_tissue);
-    double v[10];
-    mo.to_array(v, n_tissue, lane);
+    for (int item = blockIdx.x; item < a.n_items; item += gridDim.x) {
+        const int tile = item / a.parts, part = item % a.parts;
+        const uint8_t* src = a.rgb + (size_t)tile * a.P * 3;
+        uint32_t* samp = a.sample + (size_t)tile * a.n_sample;
+        int c0, c1;
+        part_range((a.P + 3) >> 2, a.parts, part, c0, c1);
+        Moments mo;
+        uint32_t n_tissue = 0;
+        moments_sweep<ALIGNED, kPhaseTrip>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, a.stride_log2, samp, mo, n_tissue);
+        double v[10];
+        mo.to_array(v, n_tissue, lane);
 #pragma unroll
-    for (int i = 0; i < 10; ++i) v[i] = wave_sum(v[i]);
-    if (lane == 0)
-        for (int i = 0; i < 10; ++i) s_red[tid >> 6][i] = v[i];
-    __syncthreads();
-    if (tid < 10) {
-        double t = 0;
-        for (int w = 0; w < kSweepThreads / 64; ++w) t += s_red[w][tid];
-        a.partials[((size_t)tile * a.parts + part) * 10 + tid] = t;
+        for (int i = 0; i < 10; ++i) v[i] = wave_sum(v[i]);
+        if (lane == 0)
+            for (int i = 0; i < 10; ++i) s_red[tid >> 6][i] = v[i];
+        __syncthreads();
+        if (tid < 10) {
+            double t = 0;
+            for (int w = 0; w < kSweepThreads / 64; ++w) t += s_red[w][tid];
+            a.partials[((size_t)tile * a.parts + part) * 10 + tid] = t;
+        }
+        __syncthreads();                         // s_red is reused by the next item
     }
 }
 
@@ -1341,28 +1347,30 @@ template <int STAGE, bool ALIGNED>
 static __global__ __launch_bounds__(kSweepThreads, 4) void k_select(StatsArgs a) {
     __shared__ RowTab s_tab;
     __shared__ uint32_t s_stage[kSweepThreads / 64][kStageWave];
-    const int tile = blockIdx.x / a.parts, part = blockIdx.x % a.parts;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    TileState& st = a.state[tile];
-    if (st.status != SL_TILE_OK) return;                                   // block-uniform
     s_tab.fill_b();
-    const TabReaderB T = TabReaderB::make(s_tab);
-    SelConsts K;
-    if (STAGE == kStageAngle) {
-        for (int i = 0; i < 6; ++i) K.V[i] = in_vgpr(st.Vf[i]);
-        K.L.g12 = 0.0f;
-    } else {
-        lasso_consts(st.M, a.lam, K.L);
-        vgpr(K.L);
-    }
-    K.lo0 = uni(st.lo[0]); K.hi0 = uni(st.hi[0]); K.lo1 = uni(st.lo[1]); K.hi1 = uni(st.hi[1]);
     __syncthreads();
-    const uint8_t* src = a.rgb + (size_t)tile * a.P * 3;
-    int c0, c1;
-    part_range((a.P + 3) >> 2, a.parts, part, c0, c1);
-    RawSink sink{s_stage[wave], 0u, a.raw + (size_t)tile * a.cap_raw, &st.n_raw, &st.overflow, (uint32_t)a.cap_raw};
-    select_sweep<STAGE, ALIGNED, kPhaseTrip>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, K, sink);
-    sink.flush(lane);
+    const TabReaderB T = TabReaderB::make(s_tab);
+    for (int item = blockIdx.x; item < a.n_items; item += gridDim.x) {
+        const int tile = item / a.parts, part = item % a.parts;
+        TileState& st = a.state[tile];
+        if (st.status != SL_TILE_OK) continue;                             // block-uniform
+        SelConsts K;
+        if (STAGE == kStageAngle) {
+            for (int i = 0; i < 6; ++i) K.V[i] = in_vgpr(st.Vf[i]);
+            K.L.g12 = 0.0f;
+        } else {
+            lasso_consts(st.M, a.lam, K.L);
+            vgpr(K.L);
+        }
+        K.lo0 = uni(st.lo[0]); K.hi0 = uni(st.hi[0]); K.lo1 = uni(st.lo[1]); K.hi1 = uni(st.hi[1]);
+        const uint8_t* src = a.rgb + (size_t)tile * a.P * 3;
+        int c0, c1;
+        part_range((a.P + 3) >> 2, a.parts, part, c0, c1);
+        RawSink sink{s_stage[wave], 0u, a.raw + (size_t)tile * a.cap_raw, &st.n_raw, &st.overflow, (uint32_t)a.cap_raw};
+        select_sweep<STAGE, ALIGNED, kPhaseTrip>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, K, sink);
+        sink.flush(lane);
+    }
 }
 
 static __global__ __launch_bounds__(kFinishThreads) void k_finish_angle(StatsArgs a) {
