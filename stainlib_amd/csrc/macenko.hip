@@ -1,6 +1,6 @@
 // macenko.hip -- host schedule + C ABI of the Macenko fit / transform (kernels: stats_kernels.hpp).
 //
-// One-launch-per-phase schedule (batches below kFusedMinTiles): tiles are processed in groups of up to 1 GiB of
+// One-launch-per-phase schedule (batches below kFusedMinTiles): tiles are processed in groups of up to 2 GiB of
 // uint8 (bounds the workspace); per group 3 sweeps + 3 one-workgroup-per-tile finish kernels (+ the apply sweep
 // for transform), all on the caller's stream, no host sync.  Larger batches run the persistent fused kernel.
 #include "stats_kernels.hpp"
@@ -10,10 +10,11 @@ using namespace sl;
 
 namespace {
 
-constexpr size_t kGroupBytes = (size_t)1 << 30;   // uint8 bytes of one tile group of the per-phase schedule (measured: big groups win --
+constexpr size_t kGroupBytes = (size_t)2 << 30;   // uint8 bytes of one tile group of the per-phase schedule (measured: big groups win --
                                                   // the one-workgroup-per-tile finish kernels need many tiles to fill the chip; cache reuse between sweeps does not matter)
 
-constexpr int kFusedMinTiles = 320;         // measured crossover (tools/crossover.py): below it one launch per phase wins
+constexpr int kFusedMinTiles = 448;         // measured crossover (tools/crossover.py): below it one launch per phase wins
+constexpr int kFusedMinTilesSmall = 288;    // ... for tiles below 512 Ki pixels (256x256: 0.18 vs 0.20 ms at 256 tiles, 0.28 vs 0.25 at 384)
 constexpr int kFusedMaxGrid = 512;          // 2 resident 1024-thread workgroups per CU x 256 CUs
 
 struct Layout {
@@ -28,6 +29,10 @@ size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 Layout make_layout(int n, long P, bool force_fused = false, int schedule = 0) {
     Layout L;
     L.parts = parts_for(P);
+    {   // the persistent sweep kernels walk tiles x parts items: no more parts than it takes to give every workgroup ~4 items
+        const long want = (4L * kFusedMaxGrid + n - 1) / (n > 0 ? n : 1);
+        if (L.parts > want) L.parts = (int)(want < 1 ? 1 : want);
+    }
     L.stride_log2 = 6;
     while (((P + (1L << L.stride_log2) - 1) >> L.stride_log2) > kMaxSample) ++L.stride_log2;
     L.n_sample = (int)((P + (1L << L.stride_log2) - 1) >> L.stride_log2);
@@ -37,7 +42,7 @@ Layout make_layout(int n, long P, bool force_fused = false, int schedule = 0) {
     if (g > n) g = n;
     if (g < 1) g = 1;
     L.G = (int)g;
-    L.fused = force_fused || (schedule == 2) || (schedule != 1 && n >= kFusedMinTiles);
+    L.fused = force_fused || (schedule == 2) || (schedule != 1 && n >= (P >= (1L << 19) ? kFusedMinTiles : kFusedMinTilesSmall));
     L.grid = n < kFusedMaxGrid ? n : kFusedMaxGrid;
     const size_t slots = L.fused ? (size_t)L.grid : (size_t)L.G;     // candidate buffers: per workgroup / per tile of a group
     size_t o = 0;

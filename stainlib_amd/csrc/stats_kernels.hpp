@@ -45,7 +45,7 @@ constexpr int kFinishThreads = 1024;
 constexpr int kFusedThreads = 512;  // 2 resident workgroups per CU (<=128 VGPRs, <80 KB LDS each)
 constexpr int kSweepThreads = 512;  // sweep kernels of the one-launch-per-phase schedule (same occupancy: 64 KB table each)
 constexpr int kFusedTrip = 4;       // chunks per lane and sweep trip in the fused kernel (even)
-constexpr int kPhaseTrip = 2;       // ... in the one-sweep kernels (32 Ki-pixel parts: 8 chunks per lane)
+constexpr int kPhaseTrip = 4;       // ... in the one-sweep kernels (32 Ki-pixel parts: 8 chunks per lane)
 constexpr int kStageWave = 256;     // per-wave LDS staging entries for raw candidates (8 KB per 8 waves)
 constexpr float kBracketZ = 6.0f;   // bracket half-width in standard deviations of the sample rank
 constexpr float kAngleMargin = 2e-5f;  // safety margin of the cheap pseudo-angle test (keys carry ~1e-7)
