@@ -1,0 +1,51 @@
+"""Randomised cross-check of the two kernel schedules (development aid): for random tile shapes, batch sizes and
+contents, the fused persistent kernel and the one-launch-per-phase schedule must agree (stain matrices to 1e-12,
+outputs to the byte up to the rare +-1 that a 1e-16 difference in a per-tile constant can cause)."""
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from stainlib_amd import engine  # noqa: E402
+from oracle import stain_oracle as so  # noqa: E402  (tile generator only)
+
+rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+tgt = engine.synth_tiles(1, 256, 256, seed=1, M_true=[[0.55, 0.75, 0.35], [0.10, 0.95, 0.20]])
+Mt, mct, _ = engine.macenko_fit(tgt)
+bad = 0
+for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
+    h, w = int(rng.randint(1, 400)), int(rng.randint(4, 500))
+    if rng.rand() < 0.3:
+        h, w = int(rng.choice([32, 64, 256, 512, 1024])), int(rng.choice([32, 64, 256, 512, 1024]))
+    n = int(rng.choice([1, 2, 3, 7, 33, 65, 130, 520, 700]))
+    while n * h * w > 300e6:
+        n = max(1, n // 2)
+    base = engine.synth_tiles(min(n, 9), h, w, seed=int(rng.randint(1 << 30)))
+    kind = rng.rand()
+    if kind < 0.15:                                   # few distinct colours: heavy ties
+        pal = base.reshape(-1, 3)[torch.randint(0, base.numel() // 3, (7,), device="cuda")]
+        base = pal[torch.randint(0, 7, base.shape[:3], device="cuda")]
+    elif kind < 0.25:                                 # mostly background
+        m = torch.rand(base.shape[:3], device="cuda") < 0.97
+        base = torch.where(m[..., None], torch.full_like(base, 250), base)
+    elif kind < 0.3:
+        base[0] = 255                                 # an empty tile
+    rgb = base[torch.arange(n, device="cuda") % base.shape[0]].contiguous()
+    res = []
+    for sched in (1, 2):
+        out, M, mc, st = engine.macenko_transform(rgb, Mt[0], mct[0], params=engine.make_params(schedule=sched))
+        res.append((out.clone(), M.clone(), mc.clone(), st.clone()))
+    (o1, M1, c1, s1), (o2, M2, c2, s2) = res
+    ok = torch.equal(s1, s2)
+    good = s1 == 0
+    dM = float((M1[good] - M2[good]).abs().max()) if good.any() else 0.0
+    dc = float(((c1[good] - c2[good]).abs() / c1[good].abs()).max()) if good.any() else 0.0
+    d = (o1.to(torch.int16) - o2.to(torch.int16)).abs()
+    rate = float((d != 0).float().mean())
+    ok = ok and dM < 1e-9 and dc < 1e-9 and int(d.max()) <= 1 and rate < 1e-4
+    bad += not ok
+    print(f"case {case:3d} n={n:4d} {h:4d}x{w:4d} kind={kind:.2f} status_equal={torch.equal(s1, s2)} nfail={int((s1 != 0).sum())} dM={dM:.1e} dmaxC={dc:.1e} "
+          f"u8 mismatch={rate:.1e} max={int(d.max())} {'OK' if ok else 'MISMATCH'}", flush=True)
+print("mismatching cases:", bad)
+sys.exit(1 if bad else 0)
