@@ -8,7 +8,6 @@ import torch
 
 sys.path.insert(0, ".")
 from stainlib_amd import engine  # noqa: E402
-from oracle import stain_oracle as so  # noqa: E402  (tile generator only)
 
 rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 tgt = engine.synth_tiles(1, 256, 256, seed=1, M_true=[[0.55, 0.75, 0.35], [0.10, 0.95, 0.20]])
