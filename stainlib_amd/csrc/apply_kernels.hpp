@@ -18,13 +18,14 @@ __device__ __forceinline__ Chunk load_chunk(const uint8_t* tile, size_t nbytes, 
         return reinterpret_cast<const Chunk*>(tile)[c];
     } else {
         // ragged tail: clamped addresses instead of predicated loads (no divergent control flow in the sweeps);
-        // bytes past the tile read as the last byte and are never used (callers test the pixel index)
+        // bytes past the tile are loaded from the last byte and then zeroed by a select
         uint32_t w[3] = {0, 0, 0};
         const size_t base = (size_t)c * 12, lastb = nbytes - 1;
 #pragma unroll
         for (int i = 0; i < 12; ++i) {
             const size_t at = base + i < lastb ? base + i : lastb;
-            w[i >> 2] |= (uint32_t)tile[at] << (8 * (i & 3));
+            const uint32_t b = tile[at];
+            w[i >> 2] |= (base + i <= lastb ? b : 0u) << (8 * (i & 3));
         }
         return Chunk{w[0], w[1], w[2]};
     }

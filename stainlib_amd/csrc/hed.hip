@@ -75,14 +75,15 @@ static __global__ __launch_bounds__(kWG) void k_hed(const uint8_t* __restrict__ 
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
             const int cc = c + u * kWG;
-            in[u] = cc < c1 ? load_chunk<ALIGNED>(src, nbytes, cc) : Chunk{0, 0, 0};      // zeros: keeps the byte sum exact
+            in[u] = load_chunk_clamped<ALIGNED>(src, nbytes, cc, c1);   // no predicated load (see load_chunk_clamped); dead lanes masked below
         }
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
             const int cc = c + u * kWG;
-            bsum = __builtin_amdgcn_udot4(in[u].w0, 0x01010101u, bsum, false);
-            bsum = __builtin_amdgcn_udot4(in[u].w1, 0x01010101u, bsum, false);
-            bsum = __builtin_amdgcn_udot4(in[u].w2, 0x01010101u, bsum, false);
+            const uint32_t one = cc < c1 ? 0x01010101u : 0u;                 // lanes past the end add nothing to the byte sum
+            bsum = __builtin_amdgcn_udot4(in[u].w0, one, bsum, false);
+            bsum = __builtin_amdgcn_udot4(in[u].w1, one, bsum, false);
+            bsum = __builtin_amdgcn_udot4(in[u].w2, one, bsum, false);
             float tv[12];
 #pragma unroll
             for (int px = 0; px < 4; ++px) {

@@ -111,6 +111,15 @@ def test_hed_batch_modes_and_ragged():
     odd = [so.synth_tile(33, 47, 8)]
     o, _ = engine.hed_augment(to_dev(odd), [sig[0]], [bia[0]])
     u8_parity(o[0].cpu().numpy(), so.hed_transform(odd[0], sig[0], bia[0]), max_rate=1e-3)
+    # the cutoff test on a ragged tile needs the EXACT byte sum: 4653 bytes whose mean sits 340 counts below the
+    # 0.95 limit -- three stray copies of the last byte (255) in the padding of the last chunk would push it over
+    edge = np.full((33, 47, 3), 242, np.uint8).reshape(-1)
+    edge[:100] = 250
+    edge[-1] = 255
+    edge = edge.reshape(33, 47, 3)
+    assert 0.95 * 255 * edge.size - 765 < edge.astype(np.int64).sum() <= 0.95 * 255 * edge.size
+    _, ap = engine.hed_augment(to_dev([edge]), [sig[0]], [bia[0]])
+    assert int(ap[0]) == 1
 
 
 SA = sorted(glob.glob(os.path.join(GOLDEN, "stainaug_*.npz")))
