@@ -54,10 +54,9 @@ extern "C" {
 #define SL_OP_STAIN_AUGMENT 6
 #define SL_OP_TILE_MOMENTS 7
 
-/* selection keys of the pooled slide-level mode (sl_slide_key_*) */
-#define SL_KEY_ANGLE 0 /* pseudo-angle of the projected OD, tissue pixels only (macenko_stain_extractor.py:29-34) */
-#define SL_KEY_CONC0 1 /* lasso concentration of stain 0, all pixels (normalizer.py:36,47) */
-#define SL_KEY_CONC1 2
+/* selection key sets of the pooled slide-level mode (sl_slide_key_*): each set carries TWO targets */
+#define SL_KEYSET_ANGLE 0 /* both targets: pseudo-angle of the projected OD, tissue pixels only (macenko_stain_extractor.py:29-34) */
+#define SL_KEYSET_CONC 1  /* target i: lasso concentration of stain i, all pixels (normalizer.py:36,47) */
 
 /* skimage semantics selector for sl_hed_augment */
 #define SL_HED_SKIMAGE_018 0 /* ln(max(rgb,1e-6))/ln(1e-6) @ hed_from_rgb  (golden-pinned) */
@@ -204,15 +203,17 @@ int sl_tile_moments(const uint8_t* rgb, int n, int h, int w, const SlParams* par
                     double* moments_out /* n x 10 */, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Keys are compared as order-preserving uint32 images of their binary32 value: ord(f) = bits(f) ^ 0x80000000 for
- * f >= 0, ~bits(f) for f < 0.  `basis` is a HOST pointer to 6 doubles: V (3x2, V[c*2+k]) for SL_KEY_ANGLE, the
- * stain matrix M (2x3) for SL_KEY_CONC*.  hist[256] (device, uint64) is ACCUMULATED into: bin = the 8 key bits
- * below the top `prefix_bits` bits, over the keys whose top `prefix_bits` (0, 8, 16 or 24) bits equal `prefix`. */
-int sl_slide_key_histogram(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int key,
-                           const double* basis, uint32_t prefix, int prefix_bits, unsigned long long* hist,
-                           void* stream);
-/* *min_out (device uint32, set to 0xffffffff by the caller) = min(*min_out, smallest key > key_ord). */
-int sl_slide_key_next_above(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int key,
-                            const double* basis, uint32_t key_ord, uint32_t* min_out, void* stream);
+ * f >= 0, ~bits(f) for f < 0.  `basis` is a HOST pointer to 6 doubles: V (3x2, V[c*2+k]) for SL_KEYSET_ANGLE, the
+ * stain matrix M (2x3) for SL_KEYSET_CONC.  Both targets of the key set are served by the same sweep: hist
+ * (device, 2 x 256 uint64) is ACCUMULATED into, target t counting bin = the 8 key bits below the top `prefix_bits`
+ * bits over the keys whose top `prefix_bits` (0, 8, 16 or 24) bits equal prefixes[t] (HOST pointer, 2 values). */
+int sl_slide_key_histogram(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int keyset,
+                           const double* basis, const uint32_t* prefixes, int prefix_bits,
+                           unsigned long long* hist, void* stream);
+/* min_out[t] (device uint32 x 2, set to 0xffffffff by the caller) = min(min_out[t], smallest key of target t
+ * above key_ords[t]) (key_ords: HOST pointer, 2 values). */
+int sl_slide_key_next_above(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int keyset,
+                            const double* basis, const uint32_t* key_ords, uint32_t* min_out, void* stream);
 
 #ifdef __cplusplus
 }

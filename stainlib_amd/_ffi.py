@@ -49,8 +49,8 @@ class StainlibHipError(RuntimeError):
 
 # ops (sl_workspace_bytes)
 OP_MACENKO_FIT, OP_MACENKO_TRANSFORM, OP_VAHADANE_FIT, OP_VAHADANE_TRANSFORM, OP_HED_AUGMENT, OP_STAIN_AUGMENT, OP_TILE_MOMENTS = range(1, 8)
-# selection keys of the pooled slide-level mode
-KEY_ANGLE, KEY_CONC0, KEY_CONC1 = range(3)
+# selection key sets of the pooled slide-level mode (two targets each)
+KEYSET_ANGLE, KEYSET_CONC = range(2)
 # per-tile status
 TILE_OK, TILE_EMPTY_MASK, TILE_DEGENERATE_COV, TILE_ZERO_MAXC = range(4)
 
@@ -74,9 +74,9 @@ _SIGNATURES = {
     "sl_grayscale_augment": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "sl_tile_moments": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(SlParams), _P, _P, C.c_size_t, _P]),
     "sl_slide_key_histogram": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(SlParams), C.c_int, C.POINTER(C.c_double),
-                                          C.c_uint32, C.c_int, _P, _P]),
+                                          C.POINTER(C.c_uint32), C.c_int, _P, _P]),
     "sl_slide_key_next_above": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(SlParams), C.c_int, C.POINTER(C.c_double),
-                                           C.c_uint32, _P, _P]),
+                                           C.POINTER(C.c_uint32), _P, _P]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

@@ -18,72 +18,116 @@ using namespace sl;
 
 namespace {
 
-constexpr int kSlideThreads = 256;
-
+// Both order statistics a stage needs are pinned in the SAME sweeps: the two angular percentiles share the key and
+// differ in the prefix; the two concentration columns come out of one lasso solve.
 struct SlideArgs {
     const uint8_t* rgb;
-    int P, parts;
+    int P, parts, n_items;
     float ylimf;
-    int key;                 // SL_KEY_*
+    int keyset;              // SL_KEYSET_ANGLE / SL_KEYSET_CONC
     float V[6];              // angle: V[c*2+k]
     double M[6];             // concentrations
     double lam;
-    uint32_t prefix;
+    uint32_t prefix[2];
     int prefix_bits;
-    uint32_t above;          // next_above: keys strictly greater than this
+    uint32_t above[2];       // next_above: keys strictly greater than these
 };
 
-// ordered-integer key of pixel (r,g,b); kAbsent when the pixel does not take part (not tissue)
-__device__ __forceinline__ uint32_t slide_key(const SlideArgs& a, const TabView& tab, const LassoK& L, uint32_t r, uint32_t g, uint32_t b) {
-    if (a.key == SL_KEY_ANGLE) {
-        if (!is_tissue_f(tab.gam(r), tab.gam(g), tab.gam(b), a.ylimf)) return kAbsent;
-        return f2ord(angle_key(a.V, tab.odf(r), tab.odf(g), tab.odf(b)));
+// One target's bookkeeping of a lane: matching keys are counted in runs (neighbouring pixels mostly fall into the
+// same bin, and in the first round nearly all keys do: per-key LDS atomics on one address would serialise).
+struct BinRun {
+    uint32_t bin = 0xffffffffu, run = 0;
+    __device__ __forceinline__ void add(uint32_t* hist, uint32_t b) {
+        if (b == bin) { ++run; return; }
+        if (run) atomicAdd(&hist[bin], run);
+        bin = b; run = 1;
     }
-    float c1, c2;
-    lasso2(L, tab.odf(r), tab.odf(g), tab.odf(b), c1, c2);
-    return f2ord(a.key == SL_KEY_CONC0 ? c1 : c2);
-}
+    __device__ __forceinline__ void flush(uint32_t* hist) { if (run) atomicAdd(&hist[bin], run); run = 0; }
+};
 
-template <bool NEXT_ABOVE>
-__global__ __launch_bounds__(kSlideThreads) void k_slide_keys(SlideArgs a, unsigned long long* hist, uint32_t* min_out) {
-    __shared__ SmallTab s_tab;
-    __shared__ uint32_t s_hist[256];
-    __shared__ uint32_t s_min;
-    s_tab.fill();
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_hist[i] = 0;
-    if (threadIdx.x == 0) s_min = 0xffffffffu;
+template <int KEYSET, bool NEXT_ABOVE, bool ALIGNED>
+__global__ __launch_bounds__(kSweepThreads, 4) void k_slide_keys(SlideArgs a, unsigned long long* hist, uint32_t* min_out) {
+    __shared__ RowTab s_tab;
+    __shared__ uint32_t s_hist[2][256];
+    __shared__ uint32_t s_min[2];
+    s_tab.fill_b();
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) (&s_hist[0][0])[i] = 0;
+    if (threadIdx.x < 2) s_min[threadIdx.x] = 0xffffffffu;
     __syncthreads();
-    const TabView tab = view_of(s_tab);
+    const TabReaderB T = TabReaderB::make(s_tab);
+    const int tid = threadIdx.x;
+    float V[6];
     LassoK L;
-    if (a.key != SL_KEY_ANGLE) lasso_consts(a.M, a.lam, L); else L.g12 = 0.0f;
-    const int tile = blockIdx.x / a.parts, part = blockIdx.x % a.parts;
-    const uint8_t* src = a.rgb + (size_t)tile * a.P * 3;
-    const int span = (a.P + a.parts - 1) / a.parts;
-    const int p0 = part * span, p1 = min(a.P, p0 + span);
-    uint32_t best = 0xffffffffu;
+    if (KEYSET == SL_KEYSET_ANGLE) {
+        for (int i = 0; i < 6; ++i) V[i] = in_vgpr(a.V[i]);
+    } else {
+        lasso_consts(a.M, a.lam, L);
+        vgpr(L);
+    }
     const int sh = 24 - a.prefix_bits;
-    for (int p = p0 + threadIdx.x; p < p1; p += kSlideThreads) {
-        const uint32_t o = slide_key(a, tab, L, src[3 * (size_t)p], src[3 * (size_t)p + 1], src[3 * (size_t)p + 2]);
-        if (o == kAbsent) continue;
-        if (NEXT_ABOVE) {
-            if (o > a.above) best = min(best, o);
-        } else if (a.prefix_bits == 0 || (o >> (32 - a.prefix_bits)) == a.prefix) {
-            atomicAdd(&s_hist[(o >> sh) & 255u], 1u);
+    const bool all = a.prefix_bits == 0;
+    const uint32_t p0 = a.prefix[0], p1 = a.prefix[1], hs = all ? 0u : (uint32_t)(32 - a.prefix_bits);
+    BinRun r0, r1;
+    uint32_t best0 = 0xffffffffu, best1 = 0xffffffffu;
+    const size_t nbytes = (size_t)a.P * 3;
+    for (int item = blockIdx.x; item < a.n_items; item += gridDim.x) {
+        const int tile = item / a.parts, part = item % a.parts;
+        const uint8_t* src = a.rgb + (size_t)tile * nbytes;
+        int c0, c1;
+        part_range((a.P + 3) >> 2, a.parts, part, c0, c1);
+        for (int c = c0 + tid; c < c1; c += kSweepThreads * 2) {
+            Chunk in[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) in[u] = load_chunk_clamped<ALIGNED>(src, nbytes, c + u * kSweepThreads, c1);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int cc = c + u * kSweepThreads;
+#pragma unroll
+                for (int px = 0; px < 4; ++px) {
+                    bool have = (cc < c1) & (ALIGNED | ((size_t)cc * 4 + px < (size_t)a.P));
+                    uint32_t o0, o1;
+                    if (KEYSET == SL_KEYSET_ANGLE) {
+                        const float2 er = T.gam_odf(T.addr(in[u], 3 * px)), eg = T.gam_odf(T.addr(in[u], 3 * px + 1)),
+                                     eb = T.gam_odf(T.addr(in[u], 3 * px + 2));
+                        have = have & is_tissue_f(er.x, eg.x, eb.x, a.ylimf);
+                        o0 = o1 = f2ord(angle_key(V, er.y, eg.y, eb.y));
+                    } else {
+                        float c1f, c2f;
+                        lasso2(L, T.odf(T.addr(in[u], 3 * px)), T.odf(T.addr(in[u], 3 * px + 1)), T.odf(T.addr(in[u], 3 * px + 2)), c1f, c2f);
+                        o0 = f2ord(c1f); o1 = f2ord(c2f);
+                    }
+                    if (!have) continue;
+                    if (NEXT_ABOVE) {
+                        if (o0 > a.above[0]) best0 = min(best0, o0);
+                        if (o1 > a.above[1]) best1 = min(best1, o1);
+                    } else {
+                        if (all || (o0 >> hs) == p0) r0.add(s_hist[0], (o0 >> sh) & 255u);
+                        if (all || (o1 >> hs) == p1) r1.add(s_hist[1], (o1 >> sh) & 255u);
+                    }
+                }
+            }
         }
     }
     if (NEXT_ABOVE) {
-        for (int o = 32; o > 0; o >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, o, 64));
-        if ((threadIdx.x & 63) == 0) atomicMin(&s_min, best);
+        for (int o = 32; o > 0; o >>= 1) {
+            best0 = min(best0, (uint32_t)__shfl_xor((int)best0, o, 64));
+            best1 = min(best1, (uint32_t)__shfl_xor((int)best1, o, 64));
+        }
+        if ((tid & 63) == 0) { atomicMin(&s_min[0], best0); atomicMin(&s_min[1], best1); }
         __syncthreads();
-        if (threadIdx.x == 0 && s_min != 0xffffffffu) atomicMin(min_out, s_min);
+        if (tid < 2 && s_min[tid] != 0xffffffffu) atomicMin(&min_out[tid], s_min[tid]);
     } else {
+        r0.flush(s_hist[0]); r1.flush(s_hist[1]);
         __syncthreads();
-        for (int i = threadIdx.x; i < 256; i += blockDim.x)
-            if (s_hist[i]) atomicAdd(&hist[i], (unsigned long long)s_hist[i]);
+        for (int i = tid; i < 512; i += blockDim.x) {
+            const uint32_t v = (&s_hist[0][0])[i];
+            if (v) atomicAdd(&hist[i], (unsigned long long)v);
+        }
     }
 }
 
 // per-tile moment sums in a fixed order (run-to-run identical): sweep -> partials -> one thread per (tile, moment)
+template <bool ALIGNED>
 __global__ __launch_bounds__(kSweepThreads, 4) void k_tile_moment_partials(const uint8_t* rgb, int P, int parts, float ylimf, double* partials) {
     __shared__ RowTab s_tab;
     __shared__ double s_red[kSweepThreads / 64][10];
@@ -97,10 +141,7 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_tile_moment_partials(const
     part_range((P + 3) >> 2, parts, part, c0, c1);
     Moments mo;
     uint32_t n_tissue = 0;
-    if ((P & 3) == 0 && ((uintptr_t)rgb & 3u) == 0)
-        moments_sweep<true, kPhaseTrip>(src, P, c0, c1, tid, kSweepThreads, T, ylimf, 6, nullptr, mo, n_tissue);
-    else
-        moments_sweep<false, kPhaseTrip>(src, P, c0, c1, tid, kSweepThreads, T, ylimf, 6, nullptr, mo, n_tissue);
+    moments_sweep<ALIGNED, kPhaseTrip>(src, P, c0, c1, tid, kSweepThreads, T, ylimf, 6, nullptr, mo, n_tissue);
     double v[10];
     mo.to_array(v, n_tissue, lane);
 #pragma unroll
@@ -123,22 +164,37 @@ __global__ void k_sum_partials(const double* partials, int n, int parts, double*
     out[i] = t;
 }
 
-int fill_args(SlideArgs& a, const uint8_t* rgb, int n, int h, int w, const SlParams* params, int key, const double* basis_host) {
+int fill_args(SlideArgs& a, const uint8_t* rgb, int n, int h, int w, const SlParams* params, int keyset, const double* basis_host) {
     if (!rgb || n <= 0 || h <= 0 || w <= 0 || !basis_host) return SL_ERR_BADARG;
     if ((long)h * w > (1L << 30)) return SL_ERR_BADARG;
-    if (key != SL_KEY_ANGLE && key != SL_KEY_CONC0 && key != SL_KEY_CONC1) return SL_ERR_BADARG;
+    if (keyset != SL_KEYSET_ANGLE && keyset != SL_KEYSET_CONC) return SL_ERR_BADARG;
     SlParams p;
     sl_default_params(&p);
     if (params) p = *params;
     a.rgb = rgb;
     a.P = h * w;
     a.parts = parts_for((long)h * w);
+    const long want = (4L * 512 + n - 1) / n;                   // ~4 items per persistent workgroup
+    if (a.parts > want) a.parts = (int)(want < 1 ? 1 : want);
+    a.n_items = n * a.parts;
     a.ylimf = (float)y_limit_for_threshold(p.luminosity_threshold) - 2048.0f;
-    a.key = key;
+    a.keyset = keyset;
     a.lam = p.lasso_lambda;
     for (int i = 0; i < 6; ++i) { a.V[i] = (float)basis_host[i]; a.M[i] = basis_host[i]; }
-    a.prefix = 0; a.prefix_bits = 0; a.above = 0;
+    a.prefix[0] = a.prefix[1] = 0; a.prefix_bits = 0; a.above[0] = a.above[1] = 0;
     return SL_OK;
+}
+
+template <bool NEXT>
+void launch_keys(const SlideArgs& a, bool al, unsigned long long* hist, uint32_t* min_out, hipStream_t s) {
+    const dim3 g((unsigned)(a.n_items < 512 ? a.n_items : 512)), b(kSweepThreads);
+    if (a.keyset == SL_KEYSET_ANGLE) {
+        if (al) hipLaunchKernelGGL((k_slide_keys<SL_KEYSET_ANGLE, NEXT, true>), g, b, 0, s, a, hist, min_out);
+        else    hipLaunchKernelGGL((k_slide_keys<SL_KEYSET_ANGLE, NEXT, false>), g, b, 0, s, a, hist, min_out);
+    } else {
+        if (al) hipLaunchKernelGGL((k_slide_keys<SL_KEYSET_CONC, NEXT, true>), g, b, 0, s, a, hist, min_out);
+        else    hipLaunchKernelGGL((k_slide_keys<SL_KEYSET_CONC, NEXT, false>), g, b, 0, s, a, hist, min_out);
+    }
 }
 
 }  // namespace
@@ -156,34 +212,36 @@ extern "C" int sl_tile_moments(const uint8_t* rgb, int n, int h, int w, const Sl
     if (params) p = *params;
     const float ylimf = (float)y_limit_for_threshold(p.luminosity_threshold) - 2048.0f;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_tile_moment_partials, dim3((unsigned)((long)n * parts)), dim3(kSweepThreads), 0, s, rgb, (int)P, parts, ylimf,
-                       (double*)workspace);
+    if (aligned4(rgb, P))
+        hipLaunchKernelGGL((k_tile_moment_partials<true>), dim3((unsigned)((long)n * parts)), dim3(kSweepThreads), 0, s, rgb, (int)P, parts,
+                           ylimf, (double*)workspace);
+    else
+        hipLaunchKernelGGL((k_tile_moment_partials<false>), dim3((unsigned)((long)n * parts)), dim3(kSweepThreads), 0, s, rgb, (int)P, parts,
+                           ylimf, (double*)workspace);
     hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((n * 10 + 255) / 256)), dim3(256), 0, s, (const double*)workspace, n, parts,
                        moments_out);
     return launch_status();
 }
 
-extern "C" int sl_slide_key_histogram(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int key,
-                                      const double* basis, uint32_t prefix, int prefix_bits, unsigned long long* hist,
-                                      void* stream) {
+extern "C" int sl_slide_key_histogram(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int keyset,
+                                      const double* basis, const uint32_t* prefixes, int prefix_bits,
+                                      unsigned long long* hist, void* stream) {
     SlideArgs a;
-    const int rc = fill_args(a, rgb, n, h, w, params, key, basis);
+    const int rc = fill_args(a, rgb, n, h, w, params, keyset, basis);
     if (rc) return rc;
-    if (!hist || (prefix_bits != 0 && prefix_bits != 8 && prefix_bits != 16 && prefix_bits != 24)) return SL_ERR_BADARG;
-    a.prefix = prefix; a.prefix_bits = prefix_bits;
-    hipLaunchKernelGGL((k_slide_keys<false>), dim3((unsigned)((long)n * a.parts)), dim3(kSlideThreads), 0, (hipStream_t)stream, a, hist,
-                       (uint32_t*)nullptr);
+    if (!hist || !prefixes || (prefix_bits != 0 && prefix_bits != 8 && prefix_bits != 16 && prefix_bits != 24)) return SL_ERR_BADARG;
+    a.prefix[0] = prefixes[0]; a.prefix[1] = prefixes[1]; a.prefix_bits = prefix_bits;
+    launch_keys<false>(a, aligned4(rgb, (long)h * w), hist, nullptr, (hipStream_t)stream);
     return launch_status();
 }
 
-extern "C" int sl_slide_key_next_above(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int key,
-                                       const double* basis, uint32_t key_ord, uint32_t* min_out, void* stream) {
+extern "C" int sl_slide_key_next_above(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int keyset,
+                                       const double* basis, const uint32_t* key_ords, uint32_t* min_out, void* stream) {
     SlideArgs a;
-    const int rc = fill_args(a, rgb, n, h, w, params, key, basis);
+    const int rc = fill_args(a, rgb, n, h, w, params, keyset, basis);
     if (rc) return rc;
-    if (!min_out) return SL_ERR_BADARG;
-    a.above = key_ord;
-    hipLaunchKernelGGL((k_slide_keys<true>), dim3((unsigned)((long)n * a.parts)), dim3(kSlideThreads), 0, (hipStream_t)stream, a,
-                       (unsigned long long*)nullptr, min_out);
+    if (!min_out || !key_ords) return SL_ERR_BADARG;
+    a.above[0] = key_ords[0]; a.above[1] = key_ords[1];
+    launch_keys<true>(a, aligned4(rgb, (long)h * w), nullptr, min_out, (hipStream_t)stream);
     return launch_status();
 }

@@ -19,7 +19,8 @@ This is an extension (the reference has no notion of a slide); its check is the 
     covariance over every tissue pixel of the slide, 1st/99th angular percentiles over those pixels, 99th
     percentile of each concentration over every pixel.  Sums and order statistics decompose over tiles and
     ranks: per-tile moment sums are all-reduced (10 doubles), and each exact order statistic of the binary32
-    key is pinned by a 4-round radix select whose 256-bin histograms are all-reduced (2 KiB per round).  All
+    key is pinned by a 4-round radix select whose 256-bin histograms are all-reduced (two order statistics per
+    sweep, 4 KiB per round).  All
     collectives are tiny and latency-bound.  Oracle: the reference restatement on the concatenated image.
 """
 from __future__ import annotations
@@ -98,39 +99,43 @@ def np_lerp(a: float, b: float, t: float) -> float:
     return b - d * (1.0 - t) if t >= 0.5 else a + d * t
 
 
-def exact_rank_pair(hist_fn, next_above_fn, k: int, group=None):
-    """Keys of ranks k and min(k+1, N-1) (0-based, ascending) of the union of every rank's keys, as ordered uint32.
+def exact_rank_pairs(hist_fn, next_above_fn, ks, group=None):
+    """For each of TWO targets t: the keys of ranks ks[t] and min(ks[t]+1, N_t-1) (0-based, ascending) of the union of
+    every rank's keys of that target, as ordered uint32: [(key_k, key_k1, N_t), ...].
 
-    hist_fn(prefix, prefix_bits) -> int64[256] tensor with THIS rank's histogram of the next 8 key bits among its
-    keys whose top prefix_bits bits equal prefix; next_above_fn(key) -> this rank's smallest key > key (0xffffffff
-    if none).  Four all-reduced histogram rounds pin the k-th key exactly; returns (key_k, key_k1, N)."""
+    hist_fn(prefixes, prefix_bits) -> int64 (2, 256) tensor: per target THIS rank's histogram of the next 8 key bits
+    among its keys whose top prefix_bits bits equal prefixes[t]; next_above_fn(keys) -> per target this rank's smallest
+    key above keys[t] (0xffffffff if none).  Both targets advance in lockstep, so the four all-reduced histogram
+    rounds that pin one order statistic exactly pin both (one sweep over the tiles per round)."""
     _, world = _world(group)
-    prefix, below, total, in_bin = 0, 0, None, 0
+    prefix, below, in_bin, total, k = [0, 0], [0, 0], [0, 0], [None, None], [int(ks[0]), int(ks[1])]
     for bits in (0, 8, 16, 24):
         h = hist_fn(prefix, bits)
         if world > 1:
             dist.all_reduce(h, group=group)
         hc = h.detach().cpu().tolist()
-        if total is None:
-            total = int(sum(hc))
-            if total == 0:
-                raise ValueError("no pixel carries this key")
-            k = min(max(int(k), 0), total - 1)
-        acc = below
-        for b in range(256):
-            if k < acc + hc[b]:
-                prefix, below, in_bin = (prefix << 8) | b, acc, int(hc[b])
-                break
-            acc += hc[b]
-    key_k = prefix
-    if k + 1 < below + in_bin or k + 1 >= total:
-        return key_k, key_k, total
-    nxt = next_above_fn(key_k)
-    if world > 1:
-        t = torch.tensor([nxt], dtype=torch.int64, device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
-        nxt = int(t.item())
-    return key_k, (nxt if nxt != 0xffffffff else key_k), total
+        for t in range(2):
+            if total[t] is None:
+                total[t] = int(sum(hc[t]))
+                if total[t] == 0:
+                    raise ValueError("no pixel carries this key")
+                k[t] = min(max(k[t], 0), total[t] - 1)
+            acc = below[t]
+            for b in range(256):
+                if k[t] < acc + hc[t][b]:
+                    prefix[t], below[t], in_bin[t] = (prefix[t] << 8) | b, acc, int(hc[t][b])
+                    break
+                acc += hc[t][b]
+    need = [not (k[t] + 1 < below[t] + in_bin[t] or k[t] + 1 >= total[t]) for t in range(2)]
+    nxt = list(prefix)
+    if any(need):
+        got = next_above_fn(prefix)
+        if world > 1:
+            tt = torch.tensor(got, dtype=torch.int64, device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MIN, group=group)
+            got = [int(x) for x in tt.tolist()]
+        nxt = [(got[t] if (need[t] and got[t] != 0xffffffff) else prefix[t]) for t in range(2)]
+    return [(prefix[t], nxt[t], total[t]) for t in range(2)]
 
 
 class PooledSlideStatistics:
@@ -167,32 +172,28 @@ class PooledSlideStatistics:
             if V[0, i] < 0:
                 V[:, i] *= -1.0
         Vf = V.astype(np.float32).astype(np.float64)                # the keys are evaluated in binary32
-        # ---- exact angular percentiles over those pixels (:29-34)
-        def pair(key, basis, k):
-            a, b, _ = exact_rank_pair(lambda pre, bits: engine.slide_key_histogram(tiles_local, key, basis, pre, bits, params=params),
-                                      lambda o: engine.slide_key_next_above(tiles_local, key, basis, o, params=params), k, self.group)
-            return ord_to_float(a), ord_to_float(b)
+        # ---- exact angular percentiles over those pixels (:29-34): both in the same four sweeps
+        def pairs(keyset, basis, ks):
+            res = exact_rank_pairs(lambda pre, bits: engine.slide_key_histogram(tiles_local, keyset, basis, pre, bits, params=params),
+                                   lambda o: engine.slide_key_next_above(tiles_local, keyset, basis, o, params=params), ks, self.group)
+            return [(ord_to_float(a), ord_to_float(b)) for a, b, _ in res]
 
         def angle_of_pseudo(p):
             if abs(p) <= 1.0:
                 return math.atan2(p, 1.0 - abs(p))
             pp = 2.0 - p if p > 0 else -2.0 - p
             return math.atan2(pp, -(1.0 - abs(pp)))
-        phis = []
-        for pct in (100.0 - self.pct, self.pct):
-            k, g = percentile_position(T, pct)
-            xa, xb = pair(_ffi.KEY_ANGLE, Vf.reshape(6), k)
-            phis.append(np_lerp(angle_of_pseudo(xa), angle_of_pseudo(xb), g))
+        (k_lo, g_lo), (k_hi, g_hi) = percentile_position(T, 100.0 - self.pct), percentile_position(T, self.pct)
+        (xa0, xb0), (xa1, xb1) = pairs(_ffi.KEYSET_ANGLE, Vf.reshape(6), (k_lo, k_hi))
+        phis = [np_lerp(angle_of_pseudo(xa0), angle_of_pseudo(xb0), g_lo), np_lerp(angle_of_pseudo(xa1), angle_of_pseudo(xb1), g_hi)]
         v1 = V @ np.array([math.cos(phis[0]), math.sin(phis[0])])          # :36-37
         v2 = V @ np.array([math.cos(phis[1]), math.sin(phis[1])])
         M = np.array([v1, v2]) if v1[0] > v2[0] else np.array([v2, v1])     # :40-43
         M = M / np.linalg.norm(M, axis=1, keepdims=True)                    # :44
-        # ---- 99th percentile of each concentration over every pixel (normalizer.py:36,47)
+        # ---- 99th percentile of each concentration over every pixel (normalizer.py:36,47): both columns per sweep
         k, g = percentile_position(n_pixels, 99.0)
-        maxC = []
-        for key in (_ffi.KEY_CONC0, _ffi.KEY_CONC1):
-            xa, xb = pair(key, M.reshape(6), k)
-            maxC.append(np_lerp(float(xa), float(xb), g))
+        (ca0, cb0), (ca1, cb1) = pairs(_ffi.KEYSET_CONC, M.reshape(6), (k, k))
+        maxC = [np_lerp(float(ca0), float(cb0), g), np_lerp(float(ca1), float(cb1), g)]
         return M, np.asarray(maxC, dtype=np.float64)
 
 

@@ -265,24 +265,28 @@ def _basis6(basis):
     return b, b.ctypes.data_as(C.POINTER(C.c_double))
 
 
-def slide_key_histogram(rgb, key, basis, prefix, prefix_bits, hist=None, params=None):
-    """Accumulate into hist (256 int64, device) the next 8 key bits of this process's pixels whose key starts with `prefix`."""
+def slide_key_histogram(rgb, keyset, basis, prefixes, prefix_bits, hist=None, params=None):
+    """Accumulate into hist ((2, 256) int64, device), for both targets of the key set, the next 8 key bits of this
+    process's pixels whose key starts with prefixes[t]."""
     n, h, w = _check_tiles(rgb)
     p = params if params is not None else _ffi.default_params()
     if hist is None:
-        hist = torch.zeros((256,), dtype=torch.int64, device=rgb.device)
+        hist = torch.zeros((2, 256), dtype=torch.int64, device=rgb.device)
     keep, bp = _basis6(basis)
-    _ffi.check(_ffi.lib().sl_slide_key_histogram(_ptr(rgb), n, h, w, C.byref(p), int(key), bp, int(prefix) & 0xffffffff,
-                                                 int(prefix_bits), _ptr(hist), _stream()), "sl_slide_key_histogram")
+    pre = (C.c_uint32 * 2)(int(prefixes[0]) & 0xffffffff, int(prefixes[1]) & 0xffffffff)
+    _ffi.check(_ffi.lib().sl_slide_key_histogram(_ptr(rgb), n, h, w, C.byref(p), int(keyset), bp, pre, int(prefix_bits),
+                                                 _ptr(hist), _stream()), "sl_slide_key_histogram")
     return hist
 
 
-def slide_key_next_above(rgb, key, basis, key_ord, params=None):
-    """Smallest key (ordered uint32, as a Python int) above key_ord among this process's pixels; 0xffffffff if none."""
+def slide_key_next_above(rgb, keyset, basis, key_ords, params=None):
+    """Per target: smallest key (ordered uint32, Python ints) above key_ords[t] among this process's pixels; 0xffffffff if none."""
     n, h, w = _check_tiles(rgb)
     p = params if params is not None else _ffi.default_params()
-    mn = torch.full((1,), -1, dtype=torch.int32, device=rgb.device)        # 0xffffffff
+    mn = torch.full((2,), -1, dtype=torch.int32, device=rgb.device)        # 0xffffffff
     keep, bp = _basis6(basis)
-    _ffi.check(_ffi.lib().sl_slide_key_next_above(_ptr(rgb), n, h, w, C.byref(p), int(key), bp, int(key_ord) & 0xffffffff,
-                                                  _ptr(mn), _stream()), "sl_slide_key_next_above")
-    return int(mn.item()) & 0xffffffff
+    ko = (C.c_uint32 * 2)(int(key_ords[0]) & 0xffffffff, int(key_ords[1]) & 0xffffffff)
+    _ffi.check(_ffi.lib().sl_slide_key_next_above(_ptr(rgb), n, h, w, C.byref(p), int(keyset), bp, ko, _ptr(mn), _stream()),
+               "sl_slide_key_next_above")
+    v = mn.cpu().tolist()
+    return [int(v[0]) & 0xffffffff, int(v[1]) & 0xffffffff]

@@ -97,19 +97,26 @@ def _keys(rank, world, n=5000, seed=3):
     return allk, allk[lo:hi]
 
 
-def _rank_pair_with_numpy_histograms(mine, k):
-    """Stand-in for the device kernels: histograms / next-above of THIS rank's keys with numpy."""
-    o = _f2ord(mine).astype(np.uint64)
+def _rank_pairs_with_numpy_histograms(mine, ks):
+    """Stand-in for the device kernels: histograms / next-above of THIS rank's keys with numpy; target 0 = the keys,
+    target 1 = their negation (so the two targets walk different prefixes in lockstep)."""
+    o = [_f2ord(mine).astype(np.uint64), _f2ord(-mine).astype(np.uint64)]
 
-    def hist_fn(prefix, bits):
-        sel = o if bits == 0 else o[(o >> np.uint64(32 - bits)) == np.uint64(prefix)]
-        b = (sel >> np.uint64(24 - bits)) & np.uint64(255)
-        return torch.from_numpy(np.bincount(b.astype(np.int64), minlength=256).astype(np.int64))
+    def hist_fn(prefixes, bits):
+        rows = []
+        for t in range(2):
+            sel = o[t] if bits == 0 else o[t][(o[t] >> np.uint64(32 - bits)) == np.uint64(prefixes[t])]
+            b = (sel >> np.uint64(24 - bits)) & np.uint64(255)
+            rows.append(np.bincount(b.astype(np.int64), minlength=256).astype(np.int64))
+        return torch.from_numpy(np.stack(rows))
 
-    def next_above_fn(key):
-        g = o[o > np.uint64(key)]
-        return int(g.min()) if len(g) else 0xffffffff
-    return sd.exact_rank_pair(hist_fn, next_above_fn, k)
+    def next_above_fn(keys):
+        out = []
+        for t in range(2):
+            g = o[t][o[t] > np.uint64(keys[t])]
+            out.append(int(g.min()) if len(g) else 0xffffffff)
+        return out
+    return sd.exact_rank_pairs(hist_fn, next_above_fn, ks)
 
 
 def _worker_rank_pair(rank, world, port, ks, q):
@@ -117,13 +124,13 @@ def _worker_rank_pair(rank, world, port, ks, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     _, mine = _keys(rank, world)
-    q.put((rank, [_rank_pair_with_numpy_histograms(mine, k) for k in ks]))
+    q.put((rank, [_rank_pairs_with_numpy_histograms(mine, (k, k2)) for k, k2 in ks]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_exact_rank_pair_world2_matches_sorted_union():
-    ks = [0, 53, 2500, 2699, 5399, 5406, 10 ** 9]          # incl. inside the block of ties and beyond the end
+def test_exact_rank_pairs_world2_match_sorted_union():
+    ks = [(0, 5406), (53, 2699), (2500, 2500), (5399, 17), (10 ** 9, 0)]   # incl. inside the block of ties and beyond the end
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -135,12 +142,14 @@ def test_exact_rank_pair_world2_matches_sorted_union():
         p.join(timeout=60)
         assert p.exitcode == 0
     allk, _ = _keys(0, 1)
-    srt = np.sort(allk)
+    srt = [np.sort(allk), np.sort(-allk)]
     assert res[0][1] == res[1][1]                            # identical on every rank
-    for k, (a, b, total) in zip(ks, res[0][1]):
-        kk = min(k, len(srt) - 1)
-        assert total == len(srt)
-        assert sd.ord_to_float(a) == srt[kk] and sd.ord_to_float(b) == srt[min(kk + 1, len(srt) - 1)]
+    for (k0, k1), pair in zip(ks, res[0][1]):
+        for t, k in enumerate((k0, k1)):
+            a, b, total = pair[t]
+            kk = min(k, len(srt[t]) - 1)
+            assert total == len(srt[t])
+            assert sd.ord_to_float(a) == srt[t][kk] and sd.ord_to_float(b) == srt[t][min(kk + 1, len(srt[t]) - 1)]
 
 
 def test_percentile_position_and_lerp_follow_numpy():
