@@ -12,22 +12,41 @@
 
 namespace sl {
 
+// Tiles whose byte size is not a multiple of 4 (or whose batch is not 4-byte aligned) take the same dwordx3
+// accesses at unaligned addresses (gfx950 serves them at full speed; checked on hardware).  Only the ragged last
+// chunk of a tile needs care: its load starts early enough to stay inside the tile and is shifted into place,
+// its store goes byte by byte.  No predicated load anywhere (see load_chunk_clamped).
+struct __attribute__((packed, aligned(1))) ChunkU { uint32_t w0, w1, w2; };
+
 template <bool ALIGNED>
 __device__ __forceinline__ Chunk load_chunk(const uint8_t* tile, size_t nbytes, int c) {
     if (ALIGNED) {
         return reinterpret_cast<const Chunk*>(tile)[c];
     } else {
-        // ragged tail: clamped addresses instead of predicated loads (no divergent control flow in the sweeps);
-        // bytes past the tile are loaded from the last byte and then zeroed by a select
-        uint32_t w[3] = {0, 0, 0};
-        const size_t base = (size_t)c * 12, lastb = nbytes - 1;
+        const size_t base = (size_t)c * 12;
+        if (nbytes < 12) {                                   // a tile of fewer than 4 pixels (uniform)
+            uint32_t w[3] = {0, 0, 0};
 #pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            const size_t at = base + i < lastb ? base + i : lastb;
-            const uint32_t b = tile[at];
-            w[i >> 2] |= (base + i <= lastb ? b : 0u) << (8 * (i & 3));
+            for (int i = 0; i < 12; ++i) {
+                const size_t at = base + i < nbytes - 1 ? base + i : nbytes - 1;
+                const uint32_t b = tile[at];
+                w[i >> 2] |= (base + i < nbytes ? b : 0u) << (8 * (i & 3));
+            }
+            return Chunk{w[0], w[1], w[2]};
         }
-        return Chunk{w[0], w[1], w[2]};
+        const size_t lim = nbytes - 12;
+        const size_t at = base < lim ? base : lim;
+        const ChunkU u = *reinterpret_cast<const ChunkU*>(tile + at);
+        const uint32_t d = (uint32_t)(base - at);            // 0 except for a ragged last chunk (1..11 bytes too early)
+        const uint32_t step = d >> 2, sh = 8u * (d & 3u);
+        const uint32_t a0 = step == 0 ? u.w0 : (step == 1 ? u.w1 : u.w2);
+        const uint32_t a1 = step == 0 ? u.w1 : (step == 1 ? u.w2 : 0u);
+        const uint32_t a2 = step == 0 ? u.w2 : 0u;
+        Chunk r;
+        r.w0 = (uint32_t)((((unsigned long long)a1 << 32) | a0) >> sh);
+        r.w1 = (uint32_t)((((unsigned long long)a2 << 32) | a1) >> sh);
+        r.w2 = a2 >> sh;
+        return r;                                            // bytes past the tile come out as zeros
     }
 }
 
@@ -45,8 +64,13 @@ __device__ __forceinline__ void store_chunk(uint8_t* tile, size_t nbytes, int c,
         reinterpret_cast<Chunk*>(tile)[c] = v;
     } else {
         const size_t base = (size_t)c * 12;
-        for (int i = 0; i < 12; ++i)
-            if (base + i < nbytes) tile[base + i] = (uint8_t)chunk_byte(v, i);
+        if (base + 12 <= nbytes) {
+            ChunkU u; u.w0 = v.w0; u.w1 = v.w1; u.w2 = v.w2;
+            *reinterpret_cast<ChunkU*>(tile + base) = u;
+        } else {
+            for (int i = 0; i < 12; ++i)
+                if (base + i < nbytes) tile[base + i] = (uint8_t)chunk_byte(v, i);
+        }
     }
 }
 
