@@ -15,18 +15,20 @@ constexpr size_t kGroupBytes = (size_t)2 << 30;   // uint8 bytes of one tile gro
 
 constexpr int kFusedMinTiles = 448;         // measured crossover (tools/crossover.py): below it one launch per phase wins
 constexpr int kFusedMinTilesSmall = 288;    // ... for tiles below 512 Ki pixels (256x256: 0.18 vs 0.20 ms at 256 tiles, 0.28 vs 0.25 at 384)
-constexpr int kFusedMaxGrid = 512;          // 2 resident 1024-thread workgroups per CU x 256 CUs
+constexpr int kFusedMaxGrid = 512;          // 2 resident 512-thread workgroups per CU x 256 CUs
+constexpr int kDictFusedMinTiles = 384;     // Vahadane: below it the dictionary sweeps run one launch per phase too
+constexpr int kDictFixedSweeps = 4;         // full sweeps launched after the sample stage; tiles that need more finish in k_dict_tail
 
 struct Layout {
     int parts, stride_log2, n_sample, G, cap_raw, cap_list;
     bool fused;
     int grid;                               // fused: workgroups launched
-    size_t off_M, off_maxC, off_status, off_partials, off_sample, off_cand, off_list, off_state, off_diag, total;
+    size_t off_M, off_maxC, off_status, off_partials, off_sample, off_cand, off_list, off_state, off_dstate, off_diag, total;
 };
 
 size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
-Layout make_layout(int n, long P, bool force_fused = false, int schedule = 0) {
+Layout make_layout(int n, long P, int method = kMethodMacenko, int schedule = 0) {
     Layout L;
     L.parts = parts_for(P);
     {   // the persistent sweep kernels walk tiles x parts items: no more parts than it takes to give every workgroup ~4 items
@@ -42,7 +44,8 @@ Layout make_layout(int n, long P, bool force_fused = false, int schedule = 0) {
     if (g > n) g = n;
     if (g < 1) g = 1;
     L.G = (int)g;
-    L.fused = force_fused || (schedule == 2) || (schedule != 1 && n >= (P >= (1L << 19) ? kFusedMinTiles : kFusedMinTilesSmall));
+    const int min_fused = method == kMethodVahadane ? kDictFusedMinTiles : (P >= (1L << 19) ? kFusedMinTiles : kFusedMinTilesSmall);
+    L.fused = (schedule == 2) || (schedule != 1 && n >= min_fused);
     L.grid = n < kFusedMaxGrid ? n : kFusedMaxGrid;
     const size_t slots = L.fused ? (size_t)L.grid : (size_t)L.G;     // candidate buffers: per workgroup / per tile of a group
     size_t o = 0;
@@ -50,7 +53,7 @@ Layout make_layout(int n, long P, bool force_fused = false, int schedule = 0) {
     L.off_maxC = o;     o = align_up(o + sizeof(double) * 2 * (size_t)n);
     L.off_status = o;   o = align_up(o + sizeof(int32_t) * (size_t)n);
     L.off_diag = o;     o = align_up(o + sizeof(int32_t) * (size_t)n);
-    L.off_partials = o; o = align_up(o + sizeof(double) * 10 * (size_t)L.parts * L.G);
+    L.off_partials = o; o = align_up(o + sizeof(double) * 32 * (size_t)L.parts * L.G);     // 10 (Macenko) / 32 (Vahadane) per item
     L.off_sample = o;   o = align_up(o + sizeof(uint32_t) * (size_t)L.n_sample * slots);
     // list capacities scale with the tile: ~3 % of the pixels are raw candidates, ~1 % end up in a bracket
     L.cap_raw = (int)(P / 12 > kMinCapRaw ? P / 12 : kMinCapRaw);
@@ -58,13 +61,12 @@ Layout make_layout(int n, long P, bool force_fused = false, int schedule = 0) {
     L.off_cand = o;     o = align_up(o + sizeof(uint32_t) * (size_t)L.cap_raw * slots);
     L.off_list = o;     o = align_up(o + sizeof(float) * 2 * (size_t)L.cap_list * slots);
     L.off_state = o;    o = align_up(o + sizeof(TileState) * (size_t)L.G);
+    L.off_dstate = o;   o = align_up(o + sizeof(DictState) * (size_t)L.G);
     L.total = o;
     return L;
 }
 
-// Runs the statistics stages for tiles [g0, g0+m) of the batch; results land in M_all/maxC_all/status_all.
-int run_stats_group(const uint8_t* rgb, int g0, int m, long P, const SlParams& p, const Layout& L, char* ws,
-                    double* M_all, double* maxC_all, int32_t* status_all, hipStream_t s) {
+StatsArgs stats_args(const uint8_t* rgb, int g0, int m, long P, const SlParams& p, const Layout& L, char* ws) {
     StatsArgs a;
     a.rgb = rgb + (size_t)g0 * 3 * P;
     a.P = (int)P;
@@ -82,6 +84,19 @@ int run_stats_group(const uint8_t* rgb, int g0, int m, long P, const SlParams& p
     a.raw = (uint32_t*)(ws + L.off_cand);
     a.cand = (float*)(ws + L.off_list);
     a.state = (TileState*)(ws + L.off_state);
+    a.dl_lambda = p.dl_lambda;
+    a.dl_tol = p.dl_tol;
+    a.dl_max_sweeps = p.dl_max_sweeps > 0 ? p.dl_max_sweeps : 1;
+    a.tile0 = g0;
+    a.dstate = (DictState*)(ws + L.off_dstate);
+    a.sweeps_out = nullptr;
+    return a;
+}
+
+// Runs the statistics stages for tiles [g0, g0+m) of the batch; results land in M_all/maxC_all/status_all.
+int run_stats_group(const uint8_t* rgb, int g0, int m, long P, const SlParams& p, const Layout& L, char* ws,
+                    double* M_all, double* maxC_all, int32_t* status_all, hipStream_t s) {
+    StatsArgs a = stats_args(rgb, g0, m, P, p, L, ws);
     const bool al = aligned4(a.rgb, P);
     const long items = (long)m * L.parts;
     const dim3 gs((unsigned)(items < kFusedMaxGrid ? items : kFusedMaxGrid)), bs(kSweepThreads), gf((unsigned)m), bf(kFinishThreads);
@@ -98,6 +113,47 @@ int run_stats_group(const uint8_t* rgb, int g0, int m, long P, const SlParams& p
         else    hipLaunchKernelGGL((k_select<kStageAngle, false>), gs, bs, 0, s, a);
     }
     { ProfScope ps(prof, SL_PROF_FINISH, m, s); hipLaunchKernelGGL(k_finish_angle, gf, bf, 0, s, a); }
+    {
+        ProfScope ps(prof, SL_PROF_SELECT_CONC, m, s);
+        if (al) hipLaunchKernelGGL((k_select<kStageConc, true>), gs, bs, 0, s, a);
+        else    hipLaunchKernelGGL((k_select<kStageConc, false>), gs, bs, 0, s, a);
+    }
+    {
+        ProfScope ps(prof, SL_PROF_FINISH, m, s);
+        hipLaunchKernelGGL(k_finish_conc, gf, bf, 0, s, a, M_all, maxC_all, status_all, g0);
+    }
+    return launch_status();
+}
+
+// The same for Vahadane: dictionary sweeps, then the concentration stage of the Macenko schedule.
+int run_dict_group(const uint8_t* rgb, int g0, int m, long P, const SlParams& p, const Layout& L, char* ws,
+                   double* M_all, double* maxC_all, int32_t* status_all, int32_t* sweeps_out, hipStream_t s) {
+    StatsArgs a = stats_args(rgb, g0, m, P, p, L, ws);
+    a.sweeps_out = sweeps_out;
+    const bool al = aligned4(a.rgb, P);
+    const long items = (long)m * L.parts;
+    const dim3 gs((unsigned)(items < kFusedMaxGrid ? items : kFusedMaxGrid)), bs(kSweepThreads), gf((unsigned)m), bf(kFinishThreads);
+    SlProfile* prof = p.profile;
+    {
+        ProfScope ps(prof, SL_PROF_DICT, m, s);
+        if (al) hipLaunchKernelGGL((k_dict<true, true>), gs, bs, 0, s, a);
+        else    hipLaunchKernelGGL((k_dict<false, true>), gs, bs, 0, s, a);
+    }
+    { ProfScope ps(prof, SL_PROF_FINISH, m, s); hipLaunchKernelGGL(k_dict_finish, gf, bf, 0, s, a, 1); }
+    const int fixed = a.dl_max_sweeps - 1 < kDictFixedSweeps ? a.dl_max_sweeps - 1 : kDictFixedSweeps;
+    for (int i = 0; i < fixed; ++i) {
+        {
+            ProfScope ps(prof, SL_PROF_DICT, m, s);
+            if (al) hipLaunchKernelGGL((k_dict<true, false>), gs, bs, 0, s, a);
+            else    hipLaunchKernelGGL((k_dict<false, false>), gs, bs, 0, s, a);
+        }
+        { ProfScope ps(prof, SL_PROF_FINISH, m, s); hipLaunchKernelGGL(k_dict_finish, gf, bf, 0, s, a, 0); }
+    }
+    {
+        ProfScope ps(prof, SL_PROF_FINISH, m, s);
+        if (al) hipLaunchKernelGGL((k_dict_tail<true>), gf, bf, 0, s, a);
+        else    hipLaunchKernelGGL((k_dict_tail<false>), gf, bf, 0, s, a);
+    }
     {
         ProfScope ps(prof, SL_PROF_SELECT_CONC, m, s);
         if (al) hipLaunchKernelGGL((k_select<kStageConc, true>), gs, bs, 0, s, a);
@@ -145,16 +201,23 @@ int run_fused(int method, const uint8_t* rgb, uint8_t* out, int n, long P, const
     a.dl_max_sweeps = p.dl_max_sweeps > 0 ? p.dl_max_sweeps : 1;
     a.sweeps_out = sweeps_out;
     const bool al = aligned4(rgb, P) && (!out || aligned4(out, P));
-    const dim3 g((unsigned)L.grid), b(kFusedThreads);
+    // Vahadane batches that cannot fill two workgroup slots per CU run one 1024-thread workgroup per tile instead
+    const bool wide = method == kMethodVahadane && n <= kFusedMaxGrid / 2;
+    const dim3 g((unsigned)L.grid), b(wide ? 1024 : kFusedThreads);
     ProfScope ps(p.profile, out ? SL_PROF_FUSED_TRANSFORM : SL_PROF_FUSED_FIT, n, s);
-#define SL_GO(M, T, A) hipLaunchKernelGGL((k_fused<M, T, A>), g, b, 0, s, a)
+#define SL_GO(M, T, A) hipLaunchKernelGGL((k_fused<M, T, A, kFusedThreads>), g, b, 0, s, a)
+#define SL_GO_WIDE(M, T, A) hipLaunchKernelGGL((k_fused<M, T, A, 1024>), g, b, 0, s, a)
     if (method == kMethodMacenko) {
         if (out) { if (al) SL_GO(kMethodMacenko, true, true); else SL_GO(kMethodMacenko, true, false); }
         else     { if (al) SL_GO(kMethodMacenko, false, true); else SL_GO(kMethodMacenko, false, false); }
+    } else if (wide) {
+        if (out) { if (al) SL_GO_WIDE(kMethodVahadane, true, true); else SL_GO_WIDE(kMethodVahadane, true, false); }
+        else     { if (al) SL_GO_WIDE(kMethodVahadane, false, true); else SL_GO_WIDE(kMethodVahadane, false, false); }
     } else {
         if (out) { if (al) SL_GO(kMethodVahadane, true, true); else SL_GO(kMethodVahadane, true, false); }
         else     { if (al) SL_GO(kMethodVahadane, false, true); else SL_GO(kMethodVahadane, false, false); }
     }
+#undef SL_GO_WIDE
 #undef SL_GO
     return launch_status();
 }
@@ -175,12 +238,15 @@ extern "C" size_t sl_workspace_bytes(int op, int n_tiles, int h, int w) {
         case SL_OP_MACENKO_FIT:
         case SL_OP_MACENKO_TRANSFORM:
         {   // SlParams.schedule may force either schedule: size for the larger of the two
-            const size_t a = make_layout(n_tiles, (long)h * w, false, 1).total, b = make_layout(n_tiles, (long)h * w, false, 2).total;
+            const size_t a = make_layout(n_tiles, (long)h * w, kMethodMacenko, 1).total, b = make_layout(n_tiles, (long)h * w, kMethodMacenko, 2).total;
             return a > b ? a : b;
         }
         case SL_OP_VAHADANE_FIT:
         case SL_OP_VAHADANE_TRANSFORM:
-            return make_layout(n_tiles, (long)h * w, true).total;
+        {
+            const size_t a = make_layout(n_tiles, (long)h * w, kMethodVahadane, 1).total, b = make_layout(n_tiles, (long)h * w, kMethodVahadane, 2).total;
+            return a > b ? a : b;
+        }
         case SL_OP_HED_AUGMENT:
             return (sizeof(unsigned long long) * (size_t)n_tiles + 255) & ~(size_t)255;
         case SL_OP_TILE_MOMENTS:
@@ -194,7 +260,7 @@ extern "C" int sl_macenko_fit(const uint8_t* rgb, int n, int h, int w, const SlP
                               double* maxC_out, int32_t* status, void* workspace, size_t workspace_bytes,
                               void* stream) {
     const long P = (long)h * w;
-    const Layout L = (n > 0 && h > 0 && w > 0) ? make_layout(n, P, false, params ? params->schedule : 0) : Layout{};
+    const Layout L = (n > 0 && h > 0 && w > 0) ? make_layout(n, P, kMethodMacenko, params ? params->schedule : 0) : Layout{};
     int rc = check_common(rgb, n, h, w, workspace, workspace_bytes, L.total);
     if (rc) return rc;
     SlParams p;
@@ -220,7 +286,7 @@ extern "C" int sl_macenko_transform(const uint8_t* rgb, uint8_t* out, int n, int
                                     double* maxC_src_out, int32_t* status, void* workspace, size_t workspace_bytes,
                                     void* stream) {
     const long P = (long)h * w;
-    const Layout L = (n > 0 && h > 0 && w > 0) ? make_layout(n, P, false, params ? params->schedule : 0) : Layout{};
+    const Layout L = (n > 0 && h > 0 && w > 0) ? make_layout(n, P, kMethodMacenko, params ? params->schedule : 0) : Layout{};
     int rc = check_common(rgb, n, h, w, workspace, workspace_bytes, L.total);
     if (rc) return rc;
     if (!out || !M_tgt || !maxC_tgt) return SL_ERR_BADARG;
@@ -249,21 +315,30 @@ extern "C" int sl_macenko_transform(const uint8_t* rgb, uint8_t* out, int n, int
     return SL_OK;
 }
 
-// Vahadane always runs the persistent schedule (its dictionary sweeps live inside the kernel).
+// Vahadane: the persistent kernel for large batches, one launch per phase below kDictFusedMinTiles tiles.
 extern "C" int sl_vahadane_fit(const uint8_t* rgb, int n, int h, int w, const SlParams* params, double* M_out,
                                double* maxC_out, int32_t* status, int32_t* sweeps_out, void* workspace,
                                size_t workspace_bytes, void* stream) {
     const long P = (long)h * w;
-    const Layout L = (n > 0 && h > 0 && w > 0) ? make_layout(n, P, true) : Layout{};
+    const Layout L = (n > 0 && h > 0 && w > 0) ? make_layout(n, P, kMethodVahadane, params ? params->schedule : 0) : Layout{};
     int rc = check_common(rgb, n, h, w, workspace, workspace_bytes, L.total);
     if (rc) return rc;
     SlParams p;
     sl_default_params(&p);
     if (params) p = *params;
     char* ws = (char*)workspace;
-    return run_fused(kMethodVahadane, rgb, nullptr, n, P, p, L, ws, nullptr, nullptr,
-                     M_out ? M_out : (double*)(ws + L.off_M), maxC_out ? maxC_out : (double*)(ws + L.off_maxC),
-                     status ? status : (int32_t*)(ws + L.off_status), sweeps_out, (hipStream_t)stream);
+    double* M_all = M_out ? M_out : (double*)(ws + L.off_M);
+    double* maxC_all = maxC_out ? maxC_out : (double*)(ws + L.off_maxC);
+    int32_t* st_all = status ? status : (int32_t*)(ws + L.off_status);
+    if (L.fused)
+        return run_fused(kMethodVahadane, rgb, nullptr, n, P, p, L, ws, nullptr, nullptr, M_all, maxC_all, st_all, sweeps_out,
+                         (hipStream_t)stream);
+    for (int g0 = 0; g0 < n; g0 += L.G) {
+        const int m = (n - g0) < L.G ? (n - g0) : L.G;
+        rc = run_dict_group(rgb, g0, m, P, p, L, ws, M_all, maxC_all, st_all, sweeps_out, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return SL_OK;
 }
 
 extern "C" int sl_vahadane_transform(const uint8_t* rgb, uint8_t* out, int n, int h, int w, const SlParams* params,
@@ -271,7 +346,7 @@ extern "C" int sl_vahadane_transform(const uint8_t* rgb, uint8_t* out, int n, in
                                      double* maxC_src_out, int32_t* status, void* workspace, size_t workspace_bytes,
                                      void* stream) {
     const long P = (long)h * w;
-    const Layout L = (n > 0 && h > 0 && w > 0) ? make_layout(n, P, true) : Layout{};
+    const Layout L = (n > 0 && h > 0 && w > 0) ? make_layout(n, P, kMethodVahadane, params ? params->schedule : 0) : Layout{};
     int rc = check_common(rgb, n, h, w, workspace, workspace_bytes, L.total);
     if (rc) return rc;
     if (!out || !M_tgt || !maxC_tgt) return SL_ERR_BADARG;
@@ -279,10 +354,25 @@ extern "C" int sl_vahadane_transform(const uint8_t* rgb, uint8_t* out, int n, in
     sl_default_params(&p);
     if (params) p = *params;
     char* ws = (char*)workspace;
-    return run_fused(kMethodVahadane, rgb, out, n, P, p, L, ws, M_tgt, maxC_tgt,
-                     M_src_out ? M_src_out : (double*)(ws + L.off_M),
-                     maxC_src_out ? maxC_src_out : (double*)(ws + L.off_maxC),
-                     status ? status : (int32_t*)(ws + L.off_status), nullptr, (hipStream_t)stream);
+    double* M_all = M_src_out ? M_src_out : (double*)(ws + L.off_M);
+    double* maxC_all = maxC_src_out ? maxC_src_out : (double*)(ws + L.off_maxC);
+    int32_t* st_all = status ? status : (int32_t*)(ws + L.off_status);
+    if (L.fused)
+        return run_fused(kMethodVahadane, rgb, out, n, P, p, L, ws, M_tgt, maxC_tgt, M_all, maxC_all, st_all, nullptr,
+                         (hipStream_t)stream);
+    for (int g0 = 0; g0 < n; g0 += L.G) {
+        const int m = (n - g0) < L.G ? (n - g0) : L.G;
+        rc = run_dict_group(rgb, g0, m, P, p, L, ws, M_all, maxC_all, st_all, nullptr, (hipStream_t)stream);
+        if (rc) return rc;
+        {
+            ProfScope ps(p.profile, SL_PROF_APPLY, m, (hipStream_t)stream);
+            rc = sl_normalize_apply(rgb + (size_t)g0 * 3 * P, out + (size_t)g0 * 3 * P, m, h, w,
+                                    M_all + 6 * (size_t)g0, maxC_all + 2 * (size_t)g0, M_tgt, maxC_tgt,
+                                    p.lasso_lambda, nullptr, stream);
+        }
+        if (rc) return rc;
+    }
+    return SL_OK;
 }
 
 // Development aid (not part of the public header): where the per-tile state lives in the workspace.
@@ -299,3 +389,10 @@ extern "C" int sl_debug_layout(int n, int h, int w, size_t* off_state, size_t* s
 
 extern "C" void sl_debug_set_phase_clock(long long* device_buf) { g_phase_clock = device_buf; }
 extern "C" void sl_debug_set_stop(int phase) { g_debug_stop = phase; }
+
+#ifdef SL_DEBUG_INNER
+extern "C" void sl_debug_inner(unsigned long long* out, int reset) {
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(sl::g_dbg_inner), 32);
+    if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; hipMemcpyToSymbol(HIP_SYMBOL(sl::g_dbg_inner), z, 32); }
+}
+#endif

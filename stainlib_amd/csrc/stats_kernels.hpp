@@ -84,6 +84,12 @@ struct StatsArgs {
     uint32_t* raw;           // [tile][cap_raw] raw candidate pixels (r | g<<8 | b<<16)
     float* cand;             // [tile][2][cap_list] bracket members (exact keys)
     TileState* state;        // [tile]                    (multi-kernel)
+    // Vahadane (multi-kernel): partials are [tile][part][32] there
+    double dl_lambda, dl_tol;
+    int dl_max_sweeps;
+    int tile0;               // first tile of the group within the batch (sweeps_out index)
+    struct DictState* dstate;   // [tile]
+    int32_t* sweeps_out;     // [n_tiles of the batch] (may be NULL)
 };
 
 
@@ -99,13 +105,10 @@ struct TabView {
     float gam(uint32_t) const { return 0.0f; }
 #endif
 };
-__device__ __forceinline__ uint32_t lds_address(const void* p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return (uint32_t)(uintptr_t)(SL_LDS const void*)p;
-#else
-    return 0;
-#endif
-}
+// LDS byte address of a pointer into shared memory: the low half of its flat address (the shared aperture sits in the
+// high half).  Not the generic->local cast: that one carries a null check, which this hipcc mis-folds into an illegal
+// v_cmp against src_shared_base when the pointer's origin is known.
+__device__ __forceinline__ uint32_t lds_address(const void* p) { return (uint32_t)(uintptr_t)p; }
 __device__ __forceinline__ TabView view_of(const RowTab& t) {
     const uint32_t c = (uint32_t)sizeof(TabEntry) * (threadIdx.x & (kTabCopies - 1));
     return TabView{lds_address(&t), (uint32_t)sizeof(TabEntry) * kTabCopies, c + 12u, c + 8u};
@@ -967,7 +970,14 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
 // trip, the fill level stays in an SGPR.
 // burst of a wave's staged candidates to the tile's list (cold: once per ~130 pixel rows; kept out of line so
 // that the eight call sites of a trip stay small)
-__device__ __noinline__ void raw_flush(const uint32_t* buf, uint32_t n, uint32_t* dst, unsigned int* head, uint32_t cap) {
+// buf_lds: LDS byte address of the wave's staging buffer (a flat pointer to LDS kept live across the sweep drives this
+// hipcc into an illegal post-RA copy of src_shared_base)
+__device__ __noinline__ void raw_flush(uint32_t buf_lds, uint32_t n, uint32_t* dst, unsigned int* head, uint32_t cap) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    SL_LDS const uint32_t* buf = (SL_LDS const uint32_t*)buf_lds;
+#else
+    const uint32_t* buf = nullptr;
+#endif
     const int lane = threadIdx.x & 63;
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(head, n);
@@ -977,7 +987,7 @@ __device__ __noinline__ void raw_flush(const uint32_t* buf, uint32_t n, uint32_t
 }
 
 struct RawSink {
-    uint32_t* buf;              // LDS, this wave's kStageWave entries
+    uint32_t buf;               // LDS byte address of this wave's kStageWave entries
     uint32_t n;                 // wave-uniform fill
     uint32_t* dst;              // global raw list of the tile
     unsigned int* head;         // list head (LDS in the fused kernel, global otherwise)
@@ -996,7 +1006,7 @@ struct RawSink {
         // fill level + rank of this lane among the flagged lanes: the fill level rides in as v_mbcnt's addend
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, n));
 #if defined(__HIP_DEVICE_COMPILE__)
-        const uint32_t addr = lds_address(buf) + 4u * rank;
+        const uint32_t addr = buf + 4u * rank;
         const uint32_t raw = chunk_pixel(ch, px) & 0xffffffu;
         unsigned long long saved;
         asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_write_b32 %2, %3\n\ts_mov_b64 exec, %0"
@@ -1141,56 +1151,84 @@ __device__ __forceinline__ void dict_sweep_sample(const uint32_t* samp, int n_sa
     }
 }
 
-// A (a11, a12, a22) and B (3x2) of the dictionary update from the class moments m[c] = {n, s(3), q(6)}
+// A (2x2) and B (3x2) of the dictionary update from the class moments m[c] = {n, s(3), q(6)}: with the codes of a
+// class written as alpha = W x - w (W = P D, w = lam P 1, P the class's inverse Gram block),
+//   A = sum_c  W S W' - (W s) w' - w (W s)' + n w w',     B = sum_c  S W' - s w'.
+// Class 0 (both stains active) has a full P; classes 1 / 2 (one stain) have a single non-zero entry, so only
+// A[0][0], B[:,0] resp. A[1][1], B[:,1] receive anything.  One lane runs this several hundred times per tile, so
+// its latency is a fixed cost of every tile: the one-stain classes are written out (a third of the generic
+// arithmetic) and the binary64 divisions (~100 dependent cycles each) are three reciprocals.
 __device__ __forceinline__ void ab_from_class_moments(const double* mom /*[3][10]*/, const double (&D)[2][3], double lam,
                                                       double (&A)[2][2], double (&B)[3][2]) {
     const double g11 = D[0][0] * D[0][0] + D[0][1] * D[0][1] + D[0][2] * D[0][2];
     const double g22 = D[1][0] * D[1][0] + D[1][1] * D[1][1] + D[1][2] * D[1][2];
     const double g12 = D[0][0] * D[1][0] + D[0][1] * D[1][1] + D[0][2] * D[1][2];
-    const double det = g11 * g22 - g12 * g12;
+    const double rdet = 1.0 / (g11 * g22 - g12 * g12), r11 = 1.0 / g11, r22 = 1.0 / g22;
     A[0][0] = A[0][1] = A[1][0] = A[1][1] = 0.0;
 #pragma unroll
     for (int k = 0; k < 3; ++k) B[k][0] = B[k][1] = 0.0;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        double Pm[2][2];
-        if (c == 0) { Pm[0][0] = g22 / det; Pm[0][1] = -g12 / det; Pm[1][0] = -g12 / det; Pm[1][1] = g11 / det; }
-        else if (c == 1) { Pm[0][0] = 1.0 / g11; Pm[0][1] = 0; Pm[1][0] = 0; Pm[1][1] = 0; }
-        else { Pm[0][0] = 0; Pm[0][1] = 0; Pm[1][0] = 0; Pm[1][1] = 1.0 / g22; }
-        const double* m = mom + 10 * c;
+    {   // ---- class 0: both active
+        const double* m = mom;
         const double n = m[0];
-        if (!(n > 0)) continue;
-        const double s1[3] = {m[1], m[2], m[3]};
-        const double S2[3][3] = {{m[4], m[5], m[6]}, {m[5], m[7], m[8]}, {m[6], m[8], m[9]}};
-        double W[2][3], w[2], Ws1[2], WS2[2][3];
+        if (n > 0) {
+            const double P00 = g22 * rdet, P01 = -g12 * rdet, P11 = g11 * rdet;
+            const double s1[3] = {m[1], m[2], m[3]};
+            const double S2[3][3] = {{m[4], m[5], m[6]}, {m[5], m[7], m[8]}, {m[6], m[8], m[9]}};
+            double W[2][3], Ws1[2], WS2[2][3];
+            const double w[2] = {lam * (P00 + P01), lam * (P01 + P11)};
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            w[r] = lam * (Pm[r][0] + Pm[r][1]);
+            for (int k = 0; k < 3; ++k) { W[0][k] = P00 * D[0][k] + P01 * D[1][k]; W[1][k] = P01 * D[0][k] + P11 * D[1][k]; }
 #pragma unroll
-            for (int k = 0; k < 3; ++k) W[r][k] = Pm[r][0] * D[0][k] + Pm[r][1] * D[1][k];
+            for (int r = 0; r < 2; ++r) {
+                Ws1[r] = W[r][0] * s1[0] + W[r][1] * s1[1] + W[r][2] * s1[2];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) WS2[r][k] = W[r][0] * S2[0][k] + W[r][1] * S2[1][k] + W[r][2] * S2[2][k];
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int q = r; q < 2; ++q)
+                    A[r][q] = WS2[r][0] * W[q][0] + WS2[r][1] * W[q][1] + WS2[r][2] * W[q][2] - Ws1[r] * w[q] - w[r] * Ws1[q] +
+                              n * w[r] * w[q];
+            A[1][0] = A[0][1];                                              // S is symmetric
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) B[k][r] = WS2[r][k] - s1[k] * w[r];
         }
+    }
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            Ws1[r] = W[r][0] * s1[0] + W[r][1] * s1[1] + W[r][2] * s1[2];
+    for (int j = 0; j < 2; ++j) {   // ---- class 1 + j: only stain j active, alpha_j = (D_j . x - lam) / g_jj
+        const double* m = mom + 10 * (1 + j);
+        const double n = m[0];
+        if (n > 0) {
+            const double rg = j == 0 ? r11 : r22, w = lam * rg;
+            const double s1[3] = {m[1], m[2], m[3]};
+            const double S2[3][3] = {{m[4], m[5], m[6]}, {m[5], m[7], m[8]}, {m[6], m[8], m[9]}};
+            double W[3], WS2[3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) WS2[r][k] = W[r][0] * S2[0][k] + W[r][1] * S2[1][k] + W[r][2] * S2[2][k];
+            for (int k = 0; k < 3; ++k) W[k] = rg * D[j][k];
+            const double Ws1 = W[0] * s1[0] + W[1] * s1[1] + W[2] * s1[2];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) WS2[k] = W[0] * S2[0][k] + W[1] * S2[1][k] + W[2] * S2[2][k];
+            A[j][j] += WS2[0] * W[0] + WS2[1] * W[1] + WS2[2] * W[2] - 2.0 * Ws1 * w + n * w * w;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) B[k][j] += WS2[k] - s1[k] * w;
         }
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-                A[r][q] += WS2[r][0] * W[q][0] + WS2[r][1] * W[q][1] + WS2[r][2] * W[q][2] - Ws1[r] * w[q] - w[r] * Ws1[q] +
-                           n * w[r] * w[q];
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-#pragma unroll
-            for (int r = 0; r < 2; ++r) B[k][r] += WS2[r][k] - s1[k] * w[r];
     }
 }
 
-// Iterate the block-coordinate dictionary update on frozen class moments until it stalls.
-// Returns the largest change of D over the whole call.
-__device__ __forceinline__ double dict_inner_solve(const double* mom, double (&D)[2][3], double lam, int max_it) {
+// Iterate the block-coordinate dictionary update on frozen class moments until a step moves D by less than
+// inner_tol (the caller ties it to what the outer iteration still needs).  Returns the largest change of D over the
+// whole call.
+#ifdef SL_DEBUG_INNER
+__device__ unsigned long long g_dbg_inner[4];     // solves, iterations, wall-clock ticks (development aid)
+#endif
+__device__ __forceinline__ double dict_inner_solve(const double* mom, double (&D)[2][3], double lam, int max_it, double inner_tol) {
+#ifdef SL_DEBUG_INNER
+    const long long dbg_t0 = wall_clock64();
+    int dbg_its = 0;
+#endif
     double D0[2][3];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -1203,29 +1241,169 @@ __device__ __forceinline__ double dict_inner_solve(const double* mom, double (&D
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             if (A[j][j] > 1e-300) {
+                const double ra = 1.0 / A[j][j];
                 double u[3];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    u[k] = (B[k][j] - (D[0][k] * A[0][j] + D[1][k] * A[1][j])) / A[j][j] + D[j][k];
+                    u[k] = (B[k][j] - (D[0][k] * A[0][j] + D[1][k] * A[1][j])) * ra + D[j][k];
                     u[k] = fmax(u[k], 0.0);                               // posD
                 }
-                const double nrm = fmax(sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]), 1.0);   // unit ball (modeD=0)
+                const double rn = 1.0 / fmax(sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]), 1.0);   // unit ball (modeD=0)
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    const double v = u[k] / nrm;
+                    const double v = u[k] * rn;
                     step = fmax(step, fabs(v - D[j][k]));
                     D[j][k] = v;
                 }
             }
         }
-        if (step < 1e-13) break;
+#ifdef SL_DEBUG_INNER
+        ++dbg_its;
+#endif
+        if (step < inner_tol) break;
     }
+#ifdef SL_DEBUG_INNER
+    atomicAdd(&g_dbg_inner[0], 1ull); atomicAdd(&g_dbg_inner[1], (unsigned long long)dbg_its);
+    atomicAdd(&g_dbg_inner[2], (unsigned long long)(wall_clock64() - dbg_t0));
+#endif
     double delta = 0.0;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int k = 0; k < 3; ++k) delta = fmax(delta, fabs(D[j][k] - D0[j][k]));
     return delta;
+}
+
+// The state of one tile's dictionary iteration (shared memory in the fused kernel, workspace in the per-phase schedule)
+struct DictIter {
+    double D[6];
+    double Dprev[6];
+    double delta;
+    int inner_cap;
+    int status;
+};
+__device__ __forceinline__ void dict_iter_init(DictIter& it) {
+    // deterministic start: Ruifrok's H and E optical-density vectors, unit norm
+    const double h[3] = {0.65, 0.70, 0.29}, e[3] = {0.07, 0.99, 0.11};
+    const double nh = sqrt(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]), ne = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+    for (int k = 0; k < 3; ++k) { it.D[k] = h[k] / nh; it.D[3 + k] = e[k] / ne; }
+    it.status = SL_TILE_OK;
+    it.delta = 1.0;
+    for (int k = 0; k < 6; ++k) it.Dprev[k] = 1e300;
+    it.inner_cap = 500;
+}
+// one lane: the dictionary update from the 31 class-moment sums of a sweep (sum[30] = tissue pixels seen).
+// stage: 0 first full sweep, 1 sample iteration, 2 full sweep; outer = steps already taken in this stage.
+// goal = the change of D below which the caller stops iterating this stage: the frozen-partition solve runs to
+// 1e-3 of it (at its ~0.7 linear rate the remaining error is ~2 steps), never below 1e-13.
+__device__ __forceinline__ void dict_iter_update(DictIter& it, const double* sum, double lam, int stage, int outer, double goal) {
+    if (sum[30] < 1.0) {
+        if (stage != 1) it.status = SL_TILE_EMPTY_MASK;      // (an empty SAMPLE only ends the sample stage)
+        it.delta = 0.0;
+        return;
+    }
+    double D[2][3];
+    for (int j = 0; j < 2; ++j)
+        for (int k = 0; k < 3; ++k) D[j][k] = it.D[3 * j + k];
+    const double delta = dict_inner_solve(sum, D, lam, it.inner_cap, fmax(1e-3 * goal, 1e-13));
+    // The frozen-partition solve is a Newton-like step on a piecewise-smooth map and can fall
+    // into a 2-cycle between two partitions: the new iterate then returns to the one before
+    // last.  In that case restart from the midpoint and shorten the inner solve; at one inner
+    // iteration the scheme IS plain block-coordinate descent (monotone).
+    double back = 0.0;
+    for (int j = 0; j < 2; ++j)
+        for (int k = 0; k < 3; ++k) back = fmax(back, fabs(D[j][k] - it.Dprev[3 * j + k]));
+    const bool cycling = outer >= 2 && back < 0.25 * delta && it.inner_cap > 1;
+    if (cycling) it.inner_cap = it.inner_cap > 4 ? it.inner_cap / 4 : 1;
+    for (int j = 0; j < 2; ++j)
+        for (int k = 0; k < 3; ++k) {
+            const double cur = it.D[3 * j + k];
+            it.Dprev[3 * j + k] = cur;
+            it.D[3 * j + k] = cycling ? 0.5 * (D[j][k] + cur) : D[j][k];
+        }
+    it.delta = delta;
+}
+// the sample stage is over: the full sweeps restart the cycle detector
+__device__ __forceinline__ void dict_iter_restart(DictIter& it) {
+    for (int k = 0; k < 6; ++k) it.Dprev[k] = 1e300;
+    it.inner_cap = 500;
+    it.delta = 1.0;
+}
+// H first: swap when D[0,0] < D[1,0] (vahadane_stain_extractor.py:40-41), unit-norm rows (:43)
+__device__ __forceinline__ void dict_iter_stain_matrix(const DictIter& it, double* M) {
+    const bool swap = it.D[0] < it.D[3];
+    double h[3], e[3];
+    for (int k = 0; k < 3; ++k) { h[k] = swap ? it.D[3 + k] : it.D[k]; e[k] = swap ? it.D[k] : it.D[3 + k]; }
+    const double nh = sqrt(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]), ne = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+    for (int k = 0; k < 3; ++k) { M[k] = h[k] / nh; M[3 + k] = e[k] / ne; }
+}
+
+struct DictProgress { int stage, outer, sample_its, sweeps_used; };   // workgroup-uniform
+constexpr double kDictSampleTol = 1e-6;   // the sample stage ends when an update moves D by less than this
+
+// workgroup-uniform bookkeeping after an update; returns false when the iteration is over (it.status / it.delta are
+// read by every thread: call between barriers).  Ends with a barrier when the stage changes.
+__device__ __forceinline__ bool dict_advance(DictIter& it, DictProgress& pr, double tol, int tid) {
+    ++pr.outer;
+    if (pr.stage != 1) ++pr.sweeps_used;
+    if (it.status != SL_TILE_OK) return false;
+    if (pr.stage == 0) {
+        pr.stage = 1; pr.outer = 0;
+    } else if (pr.stage == 1) {
+        ++pr.sample_its;
+        if (it.delta < kDictSampleTol || pr.sample_its >= 40) {                // sample fixed point reached: back to the tile
+            pr.stage = 2; pr.outer = 0;
+            __syncthreads();
+            if (tid == 0) dict_iter_restart(it);
+            __syncthreads();
+        }
+    } else if (it.delta < tol) {
+        return false;
+    }
+    return true;
+}
+
+// One workgroup iterates a tile's dictionary from (it, pr) until it settles.  Schedule: one full sweep (it also drops
+// the sample), then the SAME fixed-point iteration on the 16 Ki-pixel sample until it settles (each step costs 1/64 of
+// a sweep), then full sweeps from that warm start until the dictionary moves by less than tol: ~4 full sweeps instead
+// of ~9.  T must be a layout-A reader; red/sum are workgroup scratch.  Ends with a barrier.  SAMPLE_ONLY: only the
+// sample stage (the per-phase schedule runs the full sweeps as launches of their own).
+template <bool ALIGNED, int NT, bool SAMPLE_ONLY = false>
+__device__ __forceinline__ void dict_learn(const uint8_t* src, int P, int nch, int tid, const TabReader& T, float ylimf,
+                                           int stride_log2, uint32_t* samp, int n_sample, double lam, double tol, int max_sweeps,
+                                           DictIter& it, double (*red)[32], double* sum, DictProgress& pr) {
+    const int lane = tid & 63, wave = tid >> 6;
+    while (pr.sweeps_used < max_sweeps && (!SAMPLE_ONLY || pr.stage == 1)) {
+        LassoK64 Ld;
+        lasso_consts64(it.D, lam, Ld);
+        uni(Ld);
+        ClsAcc acc[3];
+        uint32_t n_tissue = 0;
+        if (!SAMPLE_ONLY && pr.stage == 0)
+            dict_sweep<ALIGNED, true>(src, P, 0, nch, tid, NT, T, ylimf, stride_log2, Ld, samp, acc, n_tissue);
+        else if (SAMPLE_ONLY || pr.stage == 1)
+            dict_sweep_sample(samp, n_sample, stride_log2, P, tid, NT, T, ylimf, Ld, acc, n_tissue);
+        else
+            dict_sweep<ALIGNED, false>(src, P, 0, nch, tid, NT, T, ylimf, stride_log2, Ld, samp, acc, n_tissue);
+        double v[31];
+        acc[0].to_array(v); acc[1].to_array(v + 10); acc[2].to_array(v + 20);
+        v[30] = lane == 0 ? (double)n_tissue : 0.0;      // n_tissue is wave-uniform
+#pragma unroll
+        for (int i = 0; i < 31; ++i) v[i] = wave_sum(v[i]);
+        __syncthreads();                                             // previous iteration's readers of red are done
+        if (lane == 0)
+            for (int i = 0; i < 31; ++i) red[wave][i] = v[i];
+        __syncthreads();
+        if (tid < 31) {
+            double t = 0;
+            for (int w = 0; w < NT / 64; ++w) t += red[w][tid];
+            sum[tid] = t;
+        }
+        __syncthreads();
+        if (tid == 0) dict_iter_update(it, sum, lam, pr.stage, pr.outer, pr.stage == 1 ? kDictSampleTol : tol);
+        __syncthreads();
+        if (!dict_advance(it, pr, tol, tid)) break;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1367,7 +1545,7 @@ static __global__ __launch_bounds__(kSweepThreads, 4) void k_select(StatsArgs a)
         const uint8_t* src = a.rgb + (size_t)tile * a.P * 3;
         int c0, c1;
         part_range((a.P + 3) >> 2, a.parts, part, c0, c1);
-        RawSink sink{s_stage[wave], 0u, a.raw + (size_t)tile * a.cap_raw, &st.n_raw, &st.overflow, (uint32_t)a.cap_raw};
+        RawSink sink{lds_address(s_stage[wave]), 0u, a.raw + (size_t)tile * a.cap_raw, &st.n_raw, &st.overflow, (uint32_t)a.cap_raw};
         select_sweep<STAGE, ALIGNED, kPhaseTrip>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, K, sink);
         sink.flush(lane);
     }
@@ -1490,6 +1668,159 @@ static __global__ __launch_bounds__(kFinishThreads) void k_finish_conc(StatsArgs
     if (tid == 0 && status_out) status_out[tile0 + tile] = st.status;
 }
 
+// ---- Vahadane, one launch per phase: k_dict<first> + k_dict_finish(first) [the sample stage runs inside it], then a
+// fixed number of (k_dict, k_dict_finish) pairs that skip settled tiles, then k_dict_tail: tiles that still move (rare)
+// finish on one workgroup each; it also sets up the concentration stage, which then runs the Macenko kernels
+// (k_select<kStageConc>, k_finish_conc, apply).
+template <int NT>
+struct DictScratch {
+    double red[NT / 64][32];
+    double sum[32];
+    DictIter it;
+};
+struct DictState {
+    DictIter it;
+    DictProgress pr;
+    int done;
+    int pad_;
+};
+
+template <bool ALIGNED, bool FIRST>
+static __global__ __launch_bounds__(kSweepThreads, 4) void k_dict(StatsArgs a) {
+    __shared__ RowTab s_tab;
+    __shared__ double s_red[kSweepThreads / 64][32];
+    s_tab.fill();
+    __syncthreads();
+    const TabReader T = TabReader::make(s_tab);
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int item = blockIdx.x; item < a.n_items; item += gridDim.x) {
+        const int tile = item / a.parts, part = item % a.parts;
+        const DictState& ds = a.dstate[tile];
+        if (!FIRST && ds.done) continue;                                    // block-uniform
+        LassoK64 Ld;
+        if (FIRST) {
+            DictIter it0;
+            dict_iter_init(it0);
+            lasso_consts64(it0.D, a.dl_lambda, Ld);
+        } else {
+            lasso_consts64(ds.it.D, a.dl_lambda, Ld);
+        }
+        uni(Ld);
+        const uint8_t* src = a.rgb + (size_t)tile * a.P * 3;
+        uint32_t* samp = a.sample + (size_t)tile * a.n_sample;
+        int c0, c1;
+        part_range((a.P + 3) >> 2, a.parts, part, c0, c1);
+        ClsAcc acc[3];
+        uint32_t n_tissue = 0;
+        dict_sweep<ALIGNED, FIRST>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, a.stride_log2, Ld, samp, acc, n_tissue);
+        double v[31];
+        acc[0].to_array(v); acc[1].to_array(v + 10); acc[2].to_array(v + 20);
+        v[30] = lane == 0 ? (double)n_tissue : 0.0;
+#pragma unroll
+        for (int i = 0; i < 31; ++i) v[i] = wave_sum(v[i]);
+        if (lane == 0)
+            for (int i = 0; i < 31; ++i) s_red[tid >> 6][i] = v[i];
+        __syncthreads();
+        if (tid < 31) {
+            double t = 0;
+            for (int w = 0; w < kSweepThreads / 64; ++w) t += s_red[w][tid];
+            a.partials[((size_t)tile * a.parts + part) * 32 + tid] = t;
+        }
+        __syncthreads();                         // s_red is reused by the next item
+    }
+}
+
+__device__ __forceinline__ void dict_finalize(const DictIter& it, TileState& st) {
+    st.status = it.status;
+    if (it.status == SL_TILE_OK) dict_iter_stain_matrix(it, st.M);
+    else for (int i = 0; i < 6; ++i) st.M[i] = nan_d();
+}
+
+static __global__ __launch_bounds__(kFinishThreads) void k_dict_finish(StatsArgs a, int first) {
+    __shared__ RowTab s_tab;
+    __shared__ DictScratch<kFinishThreads> s_d;
+    const int tile = blockIdx.x, tid = threadIdx.x;
+    DictState& ds = a.dstate[tile];
+    if (!first && ds.done) return;
+    DictProgress pr{0, 0, 0, 0};
+    if (first) {
+        s_tab.fill();
+        if (tid == 0) dict_iter_init(s_d.it);
+    } else {
+        pr = ds.pr;
+        if (tid == 0) s_d.it = ds.it;
+    }
+    if (tid < 31) {                                   // fixed order => run-to-run identical sums
+        double t = 0;
+        for (int p = 0; p < a.parts; ++p) t += a.partials[((size_t)tile * a.parts + p) * 32 + tid];
+        s_d.sum[tid] = t;
+    }
+    __syncthreads();
+    if (tid == 0) dict_iter_update(s_d.it, s_d.sum, a.dl_lambda, pr.stage, pr.outer, a.dl_tol);
+    __syncthreads();
+    bool go = dict_advance(s_d.it, pr, a.dl_tol, tid) && pr.sweeps_used < a.dl_max_sweeps;
+    if (go && pr.stage == 1) {                        // block-uniform; only after the first sweep
+        const TabReader T = TabReader::make(s_tab);
+        dict_learn<true, kFinishThreads, true>(nullptr, a.P, 0, tid, T, a.ylimf, a.stride_log2, a.sample + (size_t)tile * a.n_sample,
+                                               a.n_sample, a.dl_lambda, a.dl_tol, a.dl_max_sweeps, s_d.it, s_d.red, s_d.sum, pr);
+        go = s_d.it.status == SL_TILE_OK && pr.stage == 2;
+    }
+    if (tid == 0) {
+        ds.it = s_d.it;
+        ds.pr = pr;
+        ds.done = go ? 0 : 1;
+        if (!go) dict_finalize(s_d.it, a.state[tile]);
+    }
+}
+
+template <bool ALIGNED>
+static __global__ __launch_bounds__(kFinishThreads) void k_dict_tail(StatsArgs a) {
+    __shared__ RowTab s_tab;
+    __shared__ SelScratch S;
+    __shared__ DictScratch<kFinishThreads> s_d;
+    __shared__ LassoK s_L;
+    __shared__ int s_status;
+    const int tile = blockIdx.x, tid = threadIdx.x;
+    DictState& ds = a.dstate[tile];
+    TileState& st = a.state[tile];
+    s_tab.fill();
+    __syncthreads();
+    if (!ds.done) {                                   // block-uniform: this tile needs more sweeps than the launches gave it
+        DictProgress pr = ds.pr;
+        if (tid == 0) s_d.it = ds.it;
+        __syncthreads();
+        const TabReader T = TabReader::make(s_tab);
+        dict_learn<ALIGNED, kFinishThreads>(a.rgb + (size_t)tile * a.P * 3, a.P, (a.P + 3) >> 2, tid, T, a.ylimf, a.stride_log2,
+                                            a.sample + (size_t)tile * a.n_sample, a.n_sample, a.dl_lambda, a.dl_tol,
+                                            a.dl_max_sweeps, s_d.it, s_d.red, s_d.sum, pr);
+        if (tid == 0) {
+            ds.pr = pr;
+            ds.done = 1;
+            dict_finalize(s_d.it, st);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        st.fallbacks = 0;
+        st.n_raw = 0; st.overflow = 0;
+        if (a.sweeps_out) a.sweeps_out[a.tile0 + tile] = ds.pr.sweeps_used;
+        s_status = st.status;
+        if (st.status == SL_TILE_OK) { LassoK L; lasso_consts(st.M, a.lam, L); s_L = L; }
+    }
+    __syncthreads();
+    if (s_status != SL_TILE_OK) return;               // block-uniform
+    SampleConcKey ckey;
+    ckey.sample = a.sample + (size_t)tile * a.n_sample;
+    ckey.tab = view_of(s_tab);
+    ckey.L = s_L;
+    ckey.cps_log2 = a.stride_log2 - 2;
+    ckey.P = a.P;
+    ckey.col = 0;
+    float lo[2], hi[2];
+    conc_brackets<kFinishThreads>(ckey, a.n_sample, lo, hi, S);
+    if (tid == 0) { st.lo[0] = lo[0]; st.hi[0] = hi[0]; st.lo[1] = lo[1]; st.hi[1] = hi[1]; }
+}
+
 // ------------------------------------------------------------------------------------------
 // fused persistent schedule: one workgroup = one tile at a time, all phases
 // ------------------------------------------------------------------------------------------
@@ -1522,17 +1853,15 @@ struct FusedArgs {
     int32_t* sweeps_out;     // [n_tiles] (may be NULL)
 };
 
+template <int NT>
 struct FusedShared {
     RowTab tab;              // 64 KB, first member: LDS offset 0
-    uint32_t stage[kFusedThreads / 64][kStageWave];     // 8 KB
+    uint32_t stage[NT / 64][kStageWave];     // 1 KB per wave
     unsigned int n_raw, overflow;
     SelScratch S;
-    double red[kFusedThreads / 64][32];
+    double red[NT / 64][32];
     double sum[32];
-    double D[6];
-    double delta;
-    double Dprev[6];
-    int inner_cap;
+    DictIter it;
     double Vd[6];
     double M[6];
     double maxC[2];
@@ -1545,9 +1874,11 @@ struct FusedShared {
 
 enum { kMethodMacenko = 0, kMethodVahadane = 1 };
 
-template <int METHOD, bool TRANSFORM, bool ALIGNED>
-static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) {
-    __shared__ FusedShared sh;
+// NT = 512: two workgroups per CU (the throughput configuration).  NT = 1024: one workgroup per CU, used when the batch
+// has no more tiles than CUs -- the tile's latency halves (Vahadane below 257 tiles; Macenko runs per phase there).
+template <int METHOD, bool TRANSFORM, bool ALIGNED, int NT>
+static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
+    __shared__ FusedShared<NT> sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const TabReader T = TabReader::make(sh.tab);          // layout A: moment / dictionary sweeps
     const TabReaderB TB = TabReaderB::make(sh.tab);       // layout B: everything after them
@@ -1561,8 +1892,8 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
     auto run_select = [&](auto stage_tag, const uint8_t* src, SelConsts& K) {
         constexpr int STAGE = decltype(stage_tag)::value;
         K.lo0 = uni(sh.lo[0]); K.hi0 = uni(sh.hi[0]); K.lo1 = uni(sh.lo[1]); K.hi1 = uni(sh.hi[1]);
-        RawSink sink{sh.stage[wave], 0u, rawl, &sh.n_raw, &sh.overflow, (uint32_t)a.cap_raw};
-        select_sweep<STAGE, ALIGNED, kFusedTrip>(src, a.P, 0, nch, tid, kFusedThreads, TB, a.ylimf, K, sink);
+        RawSink sink{lds_address(sh.stage[wave]), 0u, rawl, &sh.n_raw, &sh.overflow, (uint32_t)a.cap_raw};
+        select_sweep<STAGE, ALIGNED, kFusedTrip>(src, a.P, 0, nch, tid, NT, TB, a.ylimf, K, sink);
         sink.flush(lane);
         __threadfence_block();
         __syncthreads();
@@ -1583,7 +1914,7 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
             {
                 Moments mo;
                 uint32_t n_tissue = 0;
-                moments_sweep<ALIGNED, kFusedTrip>(src, a.P, 0, nch, tid, kFusedThreads, T, a.ylimf, a.stride_log2, samp, mo, n_tissue);
+                moments_sweep<ALIGNED, kFusedTrip>(src, a.P, 0, nch, tid, NT, T, a.ylimf, a.stride_log2, samp, mo, n_tissue);
                 double v[10];
                 mo.to_array(v, n_tissue, lane);
 #pragma unroll
@@ -1595,7 +1926,7 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
             sh.tab.fill_b();                 // every wave is past sweep 1: switch the table to layout B (~1 us)
             if (tid < 10) {
                 double t = 0;
-                for (int w = 0; w < kFusedThreads / 64; ++w) t += sh.red[w][tid];
+                for (int w = 0; w < NT / 64; ++w) t += sh.red[w][tid];
                 sh.sum[tid] = t;
             }
             __syncthreads();
@@ -1615,7 +1946,7 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
                     key.sample = samp; key.tab = view_of_b(sh.tab); key.cps_log2 = a.stride_log2 - 2; key.P = a.P; key.ylimf = a.ylimf;
                     for (int i = 0; i < 6; ++i) key.V[i] = sh.Vf[i];
                     float lo[2], hi[2];
-                    angle_brackets<kFusedThreads>(key, a.n_sample, a.pct, lo, hi, sh.S);
+                    angle_brackets<NT>(key, a.n_sample, a.pct, lo, hi, sh.S);
                     if (tid == 0) { sh.lo[0] = lo[0]; sh.hi[0] = hi[0]; sh.lo[1] = lo[1]; sh.hi[1] = hi[1]; }
                     __syncthreads();
                 }
@@ -1661,101 +1992,17 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
         } else {
             // ---------------- Vahadane: class-moment dictionary learning
             if (tid == 0) {
-                // deterministic start: Ruifrok's H and E optical-density vectors, unit norm
-                const double h[3] = {0.65, 0.70, 0.29}, e[3] = {0.07, 0.99, 0.11};
-                const double nh = sqrt(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]), ne = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
-                for (int k = 0; k < 3; ++k) { sh.D[k] = h[k] / nh; sh.D[3 + k] = e[k] / ne; }
-                sh.status = SL_TILE_OK;
-                sh.delta = 1.0;
+                dict_iter_init(sh.it);
                 sh.n_raw = 0; sh.overflow = 0;
-                for (int k = 0; k < 6; ++k) sh.Dprev[k] = 1e300;
-                sh.inner_cap = 500;
             }
             __syncthreads();
-            // Schedule: one full sweep (it also drops the sample), then the SAME fixed-point iteration on the
-            // 16 Ki-pixel sample until it settles (each step costs 1/64 of a sweep), then full sweeps from that
-            // warm start until the dictionary moves by less than dl_tol: ~4 full sweeps instead of ~9.
-            int stage = 0;                   // 0: first full sweep, 1: sample iterations, 2: full sweeps
-            int sample_its = 0, outer = 0;   // outer counts steps of the current stage (cycle detector)
-            while (sweeps_used < a.dl_max_sweeps) {
-                LassoK64 Ld;
-                lasso_consts64(sh.D, a.dl_lambda, Ld);
-                uni(Ld);
-                ClsAcc acc[3];
-                uint32_t n_tissue = 0;
-                if (stage == 0)
-                    dict_sweep<ALIGNED, true>(src, a.P, 0, nch, tid, kFusedThreads, T, a.ylimf, a.stride_log2, Ld, samp, acc, n_tissue);
-                else if (stage == 1)
-                    dict_sweep_sample(samp, a.n_sample, a.stride_log2, a.P, tid, kFusedThreads, T, a.ylimf, Ld, acc, n_tissue);
-                else
-                    dict_sweep<ALIGNED, false>(src, a.P, 0, nch, tid, kFusedThreads, T, a.ylimf, a.stride_log2, Ld, samp, acc, n_tissue);
-                double v[31];
-                acc[0].to_array(v); acc[1].to_array(v + 10); acc[2].to_array(v + 20);
-                v[30] = lane == 0 ? (double)n_tissue : 0.0;      // n_tissue is wave-uniform
-#pragma unroll
-                for (int i = 0; i < 31; ++i) v[i] = wave_sum(v[i]);
-                __syncthreads();                                             // previous iteration's readers of sh.red are done
-                if (lane == 0)
-                    for (int i = 0; i < 31; ++i) sh.red[wave][i] = v[i];
-                __syncthreads();
-                if (tid < 31) {
-                    double t = 0;
-                    for (int w = 0; w < kFusedThreads / 64; ++w) t += sh.red[w][tid];
-                    sh.sum[tid] = t;
-                }
-                __syncthreads();
-                if (tid == 0) {
-                    if (sh.sum[30] < 1.0) {
-                        if (stage != 1) sh.status = SL_TILE_EMPTY_MASK;      // (an empty SAMPLE only ends the sample stage)
-                        sh.delta = 0.0;
-                    } else {
-                        double D[2][3];
-                        for (int j = 0; j < 2; ++j)
-                            for (int k = 0; k < 3; ++k) D[j][k] = sh.D[3 * j + k];
-                        const double delta = dict_inner_solve(sh.sum, D, a.dl_lambda, sh.inner_cap);
-                        // The frozen-partition solve is a Newton-like step on a piecewise-smooth map and can fall
-                        // into a 2-cycle between two partitions: the new iterate then returns to the one before
-                        // last.  In that case restart from the midpoint and shorten the inner solve; at one inner
-                        // iteration the scheme IS plain block-coordinate descent (monotone).
-                        double back = 0.0;
-                        for (int j = 0; j < 2; ++j)
-                            for (int k = 0; k < 3; ++k) back = fmax(back, fabs(D[j][k] - sh.Dprev[3 * j + k]));
-                        const bool cycling = outer >= 2 && back < 0.25 * delta && sh.inner_cap > 1;
-                        if (cycling) sh.inner_cap = sh.inner_cap > 4 ? sh.inner_cap / 4 : 1;
-                        for (int j = 0; j < 2; ++j)
-                            for (int k = 0; k < 3; ++k) {
-                                const double cur = sh.D[3 * j + k];
-                                sh.Dprev[3 * j + k] = cur;
-                                sh.D[3 * j + k] = cycling ? 0.5 * (D[j][k] + cur) : D[j][k];
-                            }
-                        sh.delta = delta;
-                    }
-                }
-                __syncthreads();
-                ++outer;
-                if (stage != 1) ++sweeps_used;
-                if (sh.status != SL_TILE_OK) break;                           // block-uniform
-                if (stage == 0) {
-                    stage = 1; outer = 0;
-                } else if (stage == 1) {
-                    ++sample_its;
-                    if (sh.delta < 1e-6 || sample_its >= 40) {                // sample fixed point reached: back to the tile
-                        stage = 2; outer = 0;
-                        __syncthreads();
-                        if (tid == 0) { for (int k = 0; k < 6; ++k) sh.Dprev[k] = 1e300; sh.inner_cap = 500; sh.delta = 1.0; }
-                        __syncthreads();
-                    }
-                } else if (sh.delta < a.dl_tol) {
-                    break;
-                }
-            }
-            if (tid == 0 && sh.status == SL_TILE_OK) {
-                // H first: swap when D[0,0] < D[1,0] (vahadane_stain_extractor.py:40-41), unit-norm rows (:43)
-                const bool swap = sh.D[0] < sh.D[3];
-                double h[3], e[3];
-                for (int k = 0; k < 3; ++k) { h[k] = swap ? sh.D[3 + k] : sh.D[k]; e[k] = swap ? sh.D[k] : sh.D[3 + k]; }
-                const double nh = sqrt(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]), ne = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
-                for (int k = 0; k < 3; ++k) { sh.M[k] = h[k] / nh; sh.M[3 + k] = e[k] / ne; }
+            DictProgress pr{0, 0, 0, 0};
+            dict_learn<ALIGNED, NT>(src, a.P, nch, tid, T, a.ylimf, a.stride_log2, samp, a.n_sample, a.dl_lambda, a.dl_tol,
+                                    a.dl_max_sweeps, sh.it, sh.red, sh.sum, pr);
+            sweeps_used = pr.sweeps_used;
+            if (tid == 0) {
+                sh.status = sh.it.status;
+                if (sh.status == SL_TILE_OK) dict_iter_stain_matrix(sh.it, sh.M);
             }
             sh.tab.fill_b();                 // the dictionary sweeps are over: layout B from here on
         }
@@ -1775,7 +2022,7 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
                 ckey.sample = samp; ckey.tab = view_of_b(sh.tab); ckey.L = sh.L; ckey.cps_log2 = a.stride_log2 - 2;
                 ckey.P = a.P; ckey.col = 0;
                 float lo[2], hi[2];
-                conc_brackets<kFusedThreads>(ckey, a.n_sample, lo, hi, sh.S);
+                conc_brackets<NT>(ckey, a.n_sample, lo, hi, sh.S);
                 if (tid == 0) { sh.lo[0] = lo[0]; sh.hi[0] = hi[0]; sh.lo[1] = lo[1]; sh.hi[1] = hi[1]; }
                 __syncthreads();
             }
@@ -1833,12 +2080,12 @@ static __global__ __launch_bounds__(kFusedThreads, 4) void k_fused(FusedArgs a) 
         if (TRANSFORM) {
             uint8_t* dst = a.out + (size_t)tile * nbytes;
             if (bad) {
-                for (int c = tid; c < nch; c += kFusedThreads) store_chunk<ALIGNED>(dst, nbytes, c, load_chunk<ALIGNED>(src, nbytes, c));
+                for (int c = tid; c < nch; c += NT) store_chunk<ALIGNED>(dst, nbytes, c, load_chunk<ALIGNED>(src, nbytes, c));
             } else {
                 ApplyK K;
                 apply_consts(sh.M, sh.maxC, a.M_tgt, a.maxC_tgt, a.lam, K);
-                if (K.fast) apply_sweep<ALIGNED, true>(src, dst, a.P, 0, nch, tid, kFusedThreads, TB, K);
-                else apply_sweep<ALIGNED, false>(src, dst, a.P, 0, nch, tid, kFusedThreads, TB, K);
+                if (K.fast) apply_sweep<ALIGNED, true>(src, dst, a.P, 0, nch, tid, NT, TB, K);
+                else apply_sweep<ALIGNED, false>(src, dst, a.P, 0, nch, tid, NT, TB, K);
             }
         }
         __syncthreads();     // sh.* is reused by the next tile

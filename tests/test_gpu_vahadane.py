@@ -19,11 +19,13 @@ def _oracle_fit(I):
     return M, np.percentile(C, 99, axis=0), info
 
 
+# both schedules: 1 = one launch per phase (automatic below 384 tiles), 2 = the persistent fused kernel
+@pytest.mark.parametrize("schedule", [1, 2])
 @pytest.mark.parametrize("h,w", [(96, 96), (128, 160), (33, 47), (32, 40)])   # (32,40): waves without pixels
-def test_vahadane_fit_vs_converged_oracle(h, w):
+def test_vahadane_fit_vs_converged_oracle(h, w, schedule):
     from stainlib_amd import engine
     tiles = [so.synth_tile(h, w, s) for s in (2, 3, 4)]
-    p = engine.make_params(dl_tol=1e-9)
+    p = engine.make_params(dl_tol=1e-9, schedule=schedule)
     M, mc, st, sweeps = engine.vahadane_fit(to_dev(tiles), params=p)
     M, mc, st, sweeps = M.cpu().numpy(), mc.cpu().numpy(), st.cpu().numpy(), sweeps.cpu().numpy()
     assert (st == 0).all() and (sweeps < 40).all() and (sweeps >= 2).all()
@@ -81,3 +83,32 @@ def test_vahadane_1024_tile():
     Mo, mco, info = _oracle_fit(I)
     np.testing.assert_allclose(M.cpu().numpy()[0], Mo, rtol=0, atol=V_ATOL)
     assert int(sweeps[0]) < 30
+
+
+def test_vahadane_schedules_agree():
+    """The per-phase schedule and the fused kernel run the same iteration (only the binary64 summation order differs);
+    a tight tolerance forces more full sweeps than the fixed launches provide, so the straggler path runs too."""
+    from stainlib_amd import engine
+    rng = np.random.default_rng(5)
+    tiles = [so.synth_tile(192, 256, 100 + s) for s in range(6)]
+    tiles[3] = np.full((192, 256, 3), 255, np.uint8)                     # empty mask
+    tiles[4] = rng.integers(0, 256, (192, 256, 3), dtype=np.uint8)       # no structure at all
+    tgt = so.synth_tile(192, 256, 1001, so.M_TRUE_TGT)
+    Mt, mct, _, _ = engine.vahadane_fit(to_dev([tgt]))
+    for tol in (1e-7, 1e-12):
+        res = []
+        for schedule in (1, 2):
+            p = engine.make_params(dl_tol=tol, schedule=schedule)
+            M, mc, st, sweeps = engine.vahadane_fit(to_dev(tiles), params=p)
+            o, M2, mc2, st2 = engine.vahadane_transform(to_dev(tiles), Mt[0], mct[0], params=p)
+            assert torch.equal(st, st2)
+            np.testing.assert_allclose(M.cpu().numpy(), M2.cpu().numpy(), rtol=0, atol=1e-13, equal_nan=True)
+            res.append((M.cpu().numpy(), mc.cpu().numpy(), st.cpu().numpy(), sweeps.cpu().numpy(), o.cpu().numpy()))
+        a, b = res
+        assert list(a[2]) == list(b[2]) and a[2][3] == 1
+        np.testing.assert_allclose(a[0], b[0], rtol=0, atol=max(10 * tol, 1e-11), equal_nan=True)
+        np.testing.assert_allclose(a[1], b[1], rtol=1e-6, equal_nan=True)
+        d = np.abs(a[4].astype(np.int16) - b[4].astype(np.int16))
+        assert d.max() <= 1 and (d != 0).mean() < 1e-4
+        if tol == 1e-12:
+            assert a[3].max() > 5                                          # beyond first + fixed sweeps: the tail kernel ran
