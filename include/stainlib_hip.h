@@ -96,7 +96,7 @@ typedef struct SlParams {
     double lasso_lambda;        /* 0.01 */
     double dl_lambda;           /* 0.1  (Vahadane) */
     int32_t dl_max_sweeps;      /* 200  (Vahadane; the reference is wall-clock budgeted) */
-    int32_t schedule;           /* 0 = automatic; 1 = one launch per phase; 2 = persistent fused kernel (Macenko) */
+    int32_t schedule;           /* 0 = automatic; 1 = one launch per phase; 2 = persistent fused kernel */
     double dl_tol;              /* 1e-7 max-abs change of the dictionary between sweeps */
     SlProfile* profile;         /* NULL (default): no timing events */
 } SlParams;

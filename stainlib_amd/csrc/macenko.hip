@@ -16,7 +16,9 @@ constexpr size_t kGroupBytes = (size_t)2 << 30;   // uint8 bytes of one tile gro
 constexpr int kFusedMinTiles = 448;         // measured crossover (tools/crossover.py): below it one launch per phase wins
 constexpr int kFusedMinTilesSmall = 288;    // ... for tiles below 512 Ki pixels (256x256: 0.18 vs 0.20 ms at 256 tiles, 0.28 vs 0.25 at 384)
 constexpr int kFusedMaxGrid = 512;          // 2 resident 512-thread workgroups per CU x 256 CUs
-constexpr int kDictFusedMinTiles = 384;     // Vahadane: below it the dictionary sweeps run one launch per phase too
+constexpr int kDictFusedMinTiles = 480;     // Vahadane: below it the dictionary sweeps run one launch per phase too (measured: 1024^2 tiles 5.3 vs
+                                            // 6.3 ms at 384, 6.7 vs 6.6 at 512; a fused grid below 512 workgroups leaves slots idle)
+constexpr int kDictFusedMinTilesSmall = 192;   // ... for tiles below 512 Ki pixels (512^2: 0.82 vs 1.34 ms at 64 tiles, 1.53 vs 1.46 at 256)
 constexpr int kDictFixedSweeps = 4;         // full sweeps launched after the sample stage; tiles that need more finish in k_dict_tail
 
 struct Layout {
@@ -44,7 +46,7 @@ Layout make_layout(int n, long P, int method = kMethodMacenko, int schedule = 0)
     if (g > n) g = n;
     if (g < 1) g = 1;
     L.G = (int)g;
-    const int min_fused = method == kMethodVahadane ? kDictFusedMinTiles : (P >= (1L << 19) ? kFusedMinTiles : kFusedMinTilesSmall);
+    const int min_fused = method == kMethodVahadane ? (P >= (1L << 19) ? kDictFusedMinTiles : kDictFusedMinTilesSmall) : (P >= (1L << 19) ? kFusedMinTiles : kFusedMinTilesSmall);
     L.fused = (schedule == 2) || (schedule != 1 && n >= min_fused);
     L.grid = n < kFusedMaxGrid ? n : kFusedMaxGrid;
     const size_t slots = L.fused ? (size_t)L.grid : (size_t)L.G;     // candidate buffers: per workgroup / per tile of a group

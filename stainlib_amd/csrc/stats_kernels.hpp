@@ -1218,48 +1218,98 @@ __device__ __forceinline__ void ab_from_class_moments(const double* mom /*[3][10
     }
 }
 
-// Iterate the block-coordinate dictionary update on frozen class moments until a step moves D by less than
-// inner_tol (the caller ties it to what the outer iteration still needs).  Returns the largest change of D over the
-// whole call.
 #ifdef SL_DEBUG_INNER
-__device__ unsigned long long g_dbg_inner[4];     // solves, iterations, wall-clock ticks (development aid)
+__device__ unsigned long long g_dbg_inner[4];     // solves, passes, wall-clock ticks (development aid)
 #endif
+// one pass of the block-coordinate dictionary update on frozen class moments: D <- g(D)
+__device__ __forceinline__ void dict_bcd_pass(const double* mom, double (&D)[2][3], double lam) {
+    double A[2][2], B[3][2];
+    ab_from_class_moments(mom, D, lam, A, B);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (A[j][j] > 1e-300) {
+            const double ra = 1.0 / A[j][j];
+            double u[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                u[k] = (B[k][j] - (D[0][k] * A[0][j] + D[1][k] * A[1][j])) * ra + D[j][k];
+                u[k] = fmax(u[k], 0.0);                               // posD
+            }
+            const double rn = 1.0 / fmax(sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]), 1.0);   // unit ball (modeD=0)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) D[j][k] = u[k] * rn;
+        }
+    }
+}
+
+// Iterate D <- g(D) until a pass moves D by less than inner_tol (the caller ties it to what the outer iteration still
+// needs).  The plain iteration contracts at ~0.7 per pass (~37 passes); depth-1 Anderson mixing
+//     D+ = g(D) - gamma (g(D) - g(D_prev)),  gamma = <f, f - f_prev> / |f - f_prev|^2,  f = g(D) - D
+// removes the dominant mode (same fixed points: it stops only where g(D) = D).  A mixed step is taken only while the
+// residual keeps shrinking and |gamma| is moderate; otherwise the pass is a plain one.  max_it = 1 is exactly one
+// plain pass.  Returns the largest change of D over the whole call.
 __device__ __forceinline__ double dict_inner_solve(const double* mom, double (&D)[2][3], double lam, int max_it, double inner_tol) {
 #ifdef SL_DEBUG_INNER
     const long long dbg_t0 = wall_clock64();
     int dbg_its = 0;
 #endif
-    double D0[2][3];
+    double D0[2][3], gp[2][3], fp[2][3];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) D0[j][k] = D[j][k];
+        for (int k = 0; k < 3; ++k) { D0[j][k] = D[j][k]; gp[j][k] = 0.0; fp[j][k] = 0.0; }
+    double fn_prev = 1e300;
+    bool have_prev = false;
     for (int it = 0; it < max_it; ++it) {
-        double A[2][2], B[3][2];
-        ab_from_class_moments(mom, D, lam, A, B);
-        double step = 0.0;
+        double G[2][3];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (A[j][j] > 1e-300) {
-                const double ra = 1.0 / A[j][j];
-                double u[3];
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    u[k] = (B[k][j] - (D[0][k] * A[0][j] + D[1][k] * A[1][j])) * ra + D[j][k];
-                    u[k] = fmax(u[k], 0.0);                               // posD
-                }
-                const double rn = 1.0 / fmax(sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]), 1.0);   // unit ball (modeD=0)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const double v = u[k] * rn;
-                    step = fmax(step, fabs(v - D[j][k]));
-                    D[j][k] = v;
-                }
-            }
-        }
+            for (int k = 0; k < 3; ++k) G[j][k] = D[j][k];
+        dict_bcd_pass(mom, G, lam);
 #ifdef SL_DEBUG_INNER
         ++dbg_its;
 #endif
+        double f[2][3], step = 0.0, fn = 0.0, fdf = 0.0, dfdf = 0.0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                f[j][k] = G[j][k] - D[j][k];
+                step = fmax(step, fabs(f[j][k]));
+                fn = fma(f[j][k], f[j][k], fn);
+                const double df = f[j][k] - fp[j][k];
+                fdf = fma(f[j][k], df, fdf);
+                dfdf = fma(df, df, dfdf);
+            }
+        const bool last = step < inner_tol || it + 1 == max_it;
+        double gamma = 0.0;
+        if (!last && have_prev && fn < fn_prev && dfdf > 1e-300) {
+            gamma = fdf / dfdf;
+            if (!(fabs(gamma) <= 20.0)) gamma = 0.0;
+        }
+        if (gamma != 0.0) {                           // (one lane runs this: a real branch, the plain pass skips the projection)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                double u[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) u[k] = fmax(G[j][k] - gamma * (G[j][k] - gp[j][k]), 0.0);   // the mixed point stays feasible
+                const double rn = 1.0 / fmax(sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]), 1.0);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) D[j][k] = u[k] * rn;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) D[j][k] = G[j][k];
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { gp[j][k] = G[j][k]; fp[j][k] = f[j][k]; }
+        fn_prev = fn;
+        have_prev = true;
         if (step < inner_tol) break;
     }
 #ifdef SL_DEBUG_INNER

@@ -19,7 +19,7 @@ def _oracle_fit(I):
     return M, np.percentile(C, 99, axis=0), info
 
 
-# both schedules: 1 = one launch per phase (automatic below 384 tiles), 2 = the persistent fused kernel
+# both schedules: 1 = one launch per phase (automatic below 480 tiles), 2 = the persistent fused kernel
 @pytest.mark.parametrize("schedule", [1, 2])
 @pytest.mark.parametrize("h,w", [(96, 96), (128, 160), (33, 47), (32, 40)])   # (32,40): waves without pixels
 def test_vahadane_fit_vs_converged_oracle(h, w, schedule):
