@@ -32,15 +32,20 @@ extern "C" int sl_stain_augment(const uint8_t* rgb, uint8_t* out, int n, int h, 
     if (params) p = *params;
     const long P = (long)h * w;
     if (P > (1L << 30)) return SL_ERR_BADARG;
-    const int parts = parts_for(P);
-    const dim3 grid((unsigned)((long)n * parts)), block(kWG);
+    int parts = parts_for(P);
+    {   // persistent workgroups walk tiles x parts items: no more parts than it takes to give every workgroup ~4 items
+        const long want = (4L * 512 + n - 1) / n;
+        if (parts > want) parts = (int)(want < 1 ? 1 : want);
+    }
+    const long items = (long)n * parts;
+    const dim3 grid((unsigned)(items < 512 ? items : 512)), block(kAugThreads);
     const uint32_t y_lim = y_limit_for_threshold(p.luminosity_threshold);
     hipStream_t s = (hipStream_t)stream;
     if (aligned4(rgb, P) && aligned4(out, P))
-        hipLaunchKernelGGL((k_stain_augment<true>), grid, block, 0, s, rgb, out, (int)P, parts, M, alpha_beta,
+        hipLaunchKernelGGL((k_stain_augment<true>), grid, block, 0, s, rgb, out, (int)P, parts, (int)items, M, alpha_beta,
                            augment_background, y_lim, p.lasso_lambda);
     else
-        hipLaunchKernelGGL((k_stain_augment<false>), grid, block, 0, s, rgb, out, (int)P, parts, M, alpha_beta,
+        hipLaunchKernelGGL((k_stain_augment<false>), grid, block, 0, s, rgb, out, (int)P, parts, (int)items, M, alpha_beta,
                            augment_background, y_lim, p.lasso_lambda);
     return launch_status();
 }

@@ -302,59 +302,120 @@ static __global__ __launch_bounds__(kWG) void k_apply(const uint8_t* __restrict_
 }
 
 // StainAugmentor.pop: own stain matrix both ways, affine on the concentrations of tissue pixels
-// (augmenter.py:435-443), clip (augmenter.py:447).
-template <bool ALIGNED>
-static __global__ __launch_bounds__(kWG) void k_stain_augment(const uint8_t* __restrict__ rgb, uint8_t* __restrict__ out,
-                                                       int P, int parts, const double* __restrict__ M,
-                                                       const float* __restrict__ alpha_beta, int augment_background,
-                                                       uint32_t y_lim, double lam) {
-    __shared__ float2 s_t[256];                  // {od32, gamma} per byte value: one ds_read_b64 per channel
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_t[i] = make_float2(d_od_f32[i], (float)d_gamma[i]);
-    const int tile = blockIdx.x / parts, part = blockIdx.x % parts;
-    const int tid = threadIdx.x;
-    // per-tile constants live in VGPRs (a VALU op with an SGPR operand issues at half rate on gfx950)
-    LassoK L;
-    lasso_consts(M + 6 * (size_t)tile, lam, L);
-    vgpr(L);
-    ReconK R;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) R.q[i][c] = in_vgpr((float)(-1.4426950408889634 * M[6 * (size_t)tile + 3 * i + c]));
-    const float al0 = in_vgpr(alpha_beta[4 * (size_t)tile + 0]), be0 = in_vgpr(alpha_beta[4 * (size_t)tile + 1]);
-    const float al1 = in_vgpr(alpha_beta[4 * (size_t)tile + 2]), be1 = in_vgpr(alpha_beta[4 * (size_t)tile + 3]);
-    const float ylimf = (float)y_lim - 2048.0f;
-    __syncthreads();
+// (augmenter.py:435-443), clip (augmenter.py:447).  Persistent 512-thread workgroups over (tile, part) items with the
+// row table in layout B: one conflict-free ds_read_b64 {gamma, od32} per byte, gathers issued one chunk ahead of the
+// arithmetic, the next trip's chunks in flight (the structure of apply_sweep).
+struct AugmentK {
+    LassoK L;            // VGPR-resident
+    float q[2][3];       // -log2(e) * M[i][c]
+    float al0, be0, al1, be1, ylimf;
+};
 
+template <bool ALIGNED, bool ALL, bool FAST, class TR>
+__device__ __forceinline__ void augment_sweep(const uint8_t* src, uint8_t* dst, int P, int c0, int c1, int t, int nthreads,
+                                              const TR& T, const AugmentK& K) {
     const size_t nbytes = (size_t)P * 3;
-    const uint8_t* src = rgb + (size_t)tile * nbytes;
-    uint8_t* dst = out + (size_t)tile * nbytes;
-    const int nch = (P + 3) >> 2;
-    const int span = (nch + parts - 1) / parts;
-    const int c0 = part * span;
-    const int c1 = min(nch, c0 + span);
-    auto process = [&](const Chunk& in, int c) {
-        float t[12];
+    struct G { float2 v[12]; };
+    auto fetch = [&](int cc) { return load_chunk_clamped<ALIGNED>(src, nbytes, cc, c1); };
+    auto gather = [&](const Chunk& ch) {
+        G g;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) g.v[i] = T.gam_odf(T.addr(ch, i));
+        return g;
+    };
+    auto compute = [&](const G& g, int cc) {
+        float tv[12];
 #pragma unroll
         for (int px = 0; px < 4; ++px) {
-            const float2 er = s_t[chunk_byte(in, 3 * px)], eg = s_t[chunk_byte(in, 3 * px + 1)], eb = s_t[chunk_byte(in, 3 * px + 2)];
-            const bool tissue = augment_background || is_tissue_f(er.y, eg.y, eb.y, ylimf);
-            float a1, a2, v[3];
-            lasso2(L, er.x, eg.x, eb.x, a1, a2);
-            a1 = tissue ? fmaf(a1, al0, be0) : a1;
-            a2 = tissue ? fmaf(a2, al1, be1) : a2;
-            recon_px<false>(R, a1, a2, v);         // the clip to 255 (augmenter.py:447) is the saturation of the pack below
-            t[3 * px] = v[0]; t[3 * px + 1] = v[1]; t[3 * px + 2] = v[2];
+            const float2 er = g.v[3 * px], eg = g.v[3 * px + 1], eb = g.v[3 * px + 2];     // x = gamma, y = od32
+            float a1, a2;
+            if (FAST) {                                    // g12 >= 0: branch-free lasso (see lasso2, apply_px)
+                float i1, i2;
+                lasso_interior(K.L, er.y, eg.y, eb.y, i1, i2);
+                const float s1 = fmaf(K.L.ws1[2], eb.y, fmaf(K.L.ws1[1], eg.y, fmaf(K.L.ws1[0], er.y, K.L.ks1)));
+                const float s2 = fmaf(K.L.ws2[2], eb.y, fmaf(K.L.ws2[1], eg.y, fmaf(K.L.ws2[0], er.y, K.L.ks2)));
+                a1 = fmaxf(fminf(i1, s1), 0.0f);
+                a2 = fmaxf(fminf(i2, s2), 0.0f);
+            } else {
+                lasso2(K.L, er.y, eg.y, eb.y, a1, a2);
+            }
+            if (ALL) {
+                a1 = fmaf(a1, K.al0, K.be0);
+                a2 = fmaf(a2, K.al1, K.be1);
+            } else {
+                const bool tissue = is_tissue_f(er.x, eg.x, eb.x, K.ylimf);
+                a1 = tissue ? fmaf(a1, K.al0, K.be0) : a1;
+                a2 = tissue ? fmaf(a2, K.al1, K.be1) : a2;
+            }
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) tv[3 * px + ch] = 255.0f * __builtin_amdgcn_exp2f(fmaf(a1, K.q[0][ch], a2 * K.q[1][ch]));
         }
-        const Chunk o = pack_trunc_fast(t);         // values are >= 0; > 255 saturates = np.clip(.., 0, 255)
-        if (c < c1) store_chunk<ALIGNED>(dst, nbytes, c, o);
+        const Chunk o = pack_trunc_fast(tv);        // values are >= 0; > 255 saturates = np.clip(.., 0, 255)
+        if (cc < c1) store_chunk<ALIGNED>(dst, nbytes, cc, o);
     };
-    for (int c = c0 + tid; c < c1; c += kWG * kU) {
-        Chunk in[kU];
+    constexpr int N = 2;                                       // chunks per lane and trip; the next trip is in flight
+    Chunk cur[N], nx[N];
 #pragma unroll
-        for (int u = 0; u < kU; ++u) in[u] = load_chunk_clamped<ALIGNED>(src, nbytes, c + u * kWG, c1);
+    for (int k = 0; k < N; ++k) { cur[k] = fetch(c0 + t + k * nthreads); nx[k] = fetch(c0 + t + (N + k) * nthreads); }
+    G g[2];
+    g[0] = gather(cur[0]);
+    for (int c = c0 + t; c < c1; c += N * nthreads) {
 #pragma unroll
-        for (int u = 0; u < kU; ++u) process(in[u], c + u * kWG);
+        for (int k = 0; k < N; ++k) {
+            if (k + 1 < N) {
+                g[(k + 1) & 1] = gather(cur[k + 1]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < N; ++j) { cur[j] = nx[j]; nx[j] = fetch(c + (2 * N + j) * nthreads); }
+                g[0] = gather(cur[0]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            compute(g[k & 1], c + k * nthreads);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+constexpr int kAugThreads = 512;
+
+template <bool ALIGNED>
+static __global__ __launch_bounds__(kAugThreads, 4) void k_stain_augment(const uint8_t* __restrict__ rgb, uint8_t* __restrict__ out,
+                                                       int P, int parts, int n_items, const double* __restrict__ M,
+                                                       const float* __restrict__ alpha_beta, int augment_background,
+                                                       uint32_t y_lim, double lam) {
+    __shared__ RowTab s_tab;
+    s_tab.fill_b();
+    __syncthreads();
+    const TabReaderB T = TabReaderB::make(s_tab);
+    const int tid = threadIdx.x;
+    const size_t nbytes = (size_t)P * 3;
+    const int nch = (P + 3) >> 2;
+    const int span = (((nch + parts - 1) / parts) + 63) & ~63;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int tile = item / parts, part = item % parts;
+        // per-tile constants live in VGPRs (a VALU op with an SGPR operand issues at half rate on gfx950)
+        AugmentK K;
+        lasso_consts(M + 6 * (size_t)tile, lam, K.L);
+        vgpr(K.L);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) K.q[i][c] = in_vgpr((float)(-1.4426950408889634 * M[6 * (size_t)tile + 3 * i + c]));
+        K.al0 = in_vgpr(alpha_beta[4 * (size_t)tile + 0]); K.be0 = in_vgpr(alpha_beta[4 * (size_t)tile + 1]);
+        K.al1 = in_vgpr(alpha_beta[4 * (size_t)tile + 2]); K.be1 = in_vgpr(alpha_beta[4 * (size_t)tile + 3]);
+        K.ylimf = in_vgpr((float)y_lim - 2048.0f);
+        const int c0 = min(nch, part * span), c1 = min(nch, c0 + span);
+        if (c0 >= c1) continue;
+        const uint8_t* src = rgb + (size_t)tile * nbytes;
+        uint8_t* dst = out + (size_t)tile * nbytes;
+        const bool fast = (bool)__builtin_amdgcn_readfirstlane((int)(K.L.g12 >= 0.0f));    // every real stain matrix
+        if (augment_background) {
+            if (fast) augment_sweep<ALIGNED, true, true>(src, dst, P, c0, c1, tid, kAugThreads, T, K);
+            else augment_sweep<ALIGNED, true, false>(src, dst, P, c0, c1, tid, kAugThreads, T, K);
+        } else {
+            if (fast) augment_sweep<ALIGNED, false, true>(src, dst, P, c0, c1, tid, kAugThreads, T, K);
+            else augment_sweep<ALIGNED, false, false>(src, dst, P, c0, c1, tid, kAugThreads, T, K);
+        }
     }
 }
 
