@@ -112,3 +112,19 @@ def test_vahadane_schedules_agree():
         assert d.max() <= 1 and (d != 0).mean() < 1e-4
         if tol == 1e-12:
             assert a[3].max() > 5                                          # beyond first + fixed sweeps: the tail kernel ran
+
+
+@pytest.mark.parametrize("max_sweeps", [2, 3, 7])   # (after a single sweep the two atoms are still nearly collinear: the codes are ill-conditioned)
+def test_vahadane_sweep_budget_both_schedules(max_sweeps):
+    """dl_max_sweeps caps the FULL sweeps (the reference budgets wall-clock time instead); both schedules stop at the
+    same iterate, whether the cap falls inside the fixed launches or in the straggler kernel."""
+    from stainlib_amd import engine
+    tiles = [so.synth_tile(160, 224, 300 + s) for s in range(4)]
+    res = []
+    for schedule in (1, 2):
+        p = engine.make_params(dl_tol=1e-14, dl_max_sweeps=max_sweeps, schedule=schedule)
+        M, mc, st, sweeps = engine.vahadane_fit(to_dev(tiles), params=p)
+        assert (st.cpu().numpy() == 0).all() and (sweeps.cpu().numpy() == max_sweeps).all()
+        res.append((M.cpu().numpy(), mc.cpu().numpy()))
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(res[0][1], res[1][1], rtol=1e-6)
