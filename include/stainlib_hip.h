@@ -61,6 +61,7 @@ extern "C" {
 /* skimage semantics selector for sl_hed_augment */
 #define SL_HED_SKIMAGE_018 0 /* ln(max(rgb,1e-6))/ln(1e-6) @ hed_from_rgb  (golden-pinned) */
 #define SL_HED_SKIMAGE_019 1 /* as 0.18 + stains clamped at 0 after separation */
+#define SL_HED_SKIMAGE_017 2 /* <= 0.17 (environment.yml:107 pins 0.17.2): -log10(rgb+2) @ hed_from_rgb, 10^(-stains @ rgb_from_hed) - 2 */
 /* scikit-image 0.17 (the version pinned in the reference's environment.yml:107) is NOT offered: its
  * log10(rgb+2) formulation cannot be checked against any source or wheel available to this build. */
 

@@ -54,8 +54,9 @@ def _checked(title, rng, lowest):
 class HedColorAugmenter(ColorAugmenterBase):
     """Colour perturbation in HED space: value * (1 + sigma) + bias per channel (augmenter.py:86-344).
 
-    ``skimage_mode`` selects the rgb2hed/hed2rgb semantics: "0.18" (default, golden-pinned) or "0.19"
-    (stains clamped at zero after separation)."""
+    ``skimage_mode`` selects the rgb2hed/hed2rgb semantics: "0.18" (default, golden-pinned), "0.19"
+    (stains clamped at zero after separation) or "0.17" (the release the reference's environment.yml pins:
+    -log10(rgb + 2) and 10^x - 2; restated from memory, checked against the CPU restatement only)."""
 
     def __init__(self, haematoxylin_sigma_range, haematoxylin_bias_range, eosin_sigma_range, eosin_bias_range,
                  dab_sigma_range, dab_bias_range, cutoff_range, skimage_mode="0.18"):
@@ -69,9 +70,9 @@ class HedColorAugmenter(ColorAugmenterBase):
         self._biases = [r[0] if r is not None else 0.0 for r in self._bias_ranges]
         cut = _checked("Cutoff", cutoff_range, 0.0)
         self._cutoff_range = cut if cut is not None else [0.0, 1.0]
-        if skimage_mode not in ("0.18", "0.19"):
-            raise ValueError("skimage_mode must be '0.18' or '0.19'")
-        self._skimage_mode = 0 if skimage_mode == "0.18" else 1
+        if skimage_mode not in ("0.18", "0.19", "0.17"):
+            raise ValueError("skimage_mode must be '0.17', '0.18' or '0.19'")
+        self._skimage_mode = {"0.18": 0, "0.19": 1, "0.17": 2}[skimage_mode]
 
     def randomize(self):
         """Six draws from the global numpy stream: sigma H, E, D then bias H, E, D (augmenter.py:333-344)."""

@@ -7,7 +7,8 @@
 // so a pixel costs 3 LDS lookups, 9 FMA, 3 exp: the sweep is HBM-bound at 3 B read + 3 B written.
 // The cutoff test needs the tile mean BEFORE the transform; instead of a separate 3 B/px sweep the
 // transform runs speculatively while the same sweep sums the bytes, and a fix-up kernel copies the
-// (rare) tiles that fail the test.  >=0.19 semantics (stains clamped at 0) keep the two products apart.
+// (rare) tiles that fail the test.  >=0.19 semantics (stains clamped at 0) keep the two products apart;
+// <=0.17 semantics (the version environment.yml:107 pins: log10(rgb+2), 10^x - 2) fold the same way with another table.
 #include "apply_kernels.hpp"
 #include "sl_host.hpp"
 
@@ -25,7 +26,9 @@ static __global__ __launch_bounds__(kWG) void k_hed(const uint8_t* __restrict__ 
     const int tid = threadIdx.x;
     const int tile = blockIdx.x / parts, part = blockIdx.x % parts;
     const double Ladj = log(1e-6);
-    {
+    if (MODE == 2) {
+        s_x[tid] = (float)log2((double)tid / 255.0 + 2.0);                 // scikit-image <= 0.17: log10(rgb + 2), kept in base 2
+    } else {
         const double v = tid == 0 ? 1e-6 : fmax((double)tid / 255.0, 1e-6);
         s_x[tid] = (float)log(v);
     }
@@ -35,20 +38,22 @@ static __global__ __launch_bounds__(kWG) void k_hed(const uint8_t* __restrict__ 
     const double* sg = sigma + 3 * (size_t)tile;
     const double* bs = bias + 3 * (size_t)tile;
     const double kL2E = 1.4426950408889634;
-    if (MODE == 0) {
+    if (MODE == 0 || MODE == 2) {
+        // MODE 2 (<= 0.17): stains = -log10(x+2) @ H, rgb' = 10^(-stains' @ R) - 2, i.e. in base 2
+        //     log2(rgb'+2) = log2(x+2) @ (H diag(1+sigma) R) - log2(10) * (bias @ R)
 #pragma unroll
         for (int k = 0; k < 3; ++k)
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 double acc = 0;
                 for (int j = 0; j < 3; ++j) acc += hc.H[3 * k + j] * (1.0 + sg[j]) * hc.R[3 * j + c];
-                A[k][c] = in_vgpr((float)(acc * kL2E));
+                A[k][c] = in_vgpr((float)(MODE == 2 ? acc : acc * kL2E));
             }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             double acc = 0;
             for (int j = 0; j < 3; ++j) acc += bs[j] * hc.R[3 * j + c];
-            b[c] = in_vgpr((float)(Ladj * acc * kL2E));
+            b[c] = in_vgpr((float)(MODE == 2 ? -3.321928094887362 * acc : Ladj * acc * kL2E));
         }
     } else {
 #pragma unroll
@@ -90,7 +95,7 @@ static __global__ __launch_bounds__(kWG) void k_hed(const uint8_t* __restrict__ 
                 const float x0 = s_x[chunk_byte(in[u], 3 * px)], x1 = s_x[chunk_byte(in[u], 3 * px + 1)],
                             x2 = s_x[chunk_byte(in[u], 3 * px + 2)];
                 float l[3];
-                if (MODE == 0) {
+                if (MODE == 0 || MODE == 2) {
 #pragma unroll
                     for (int ch = 0; ch < 3; ++ch) l[ch] = fmaf(x2, A[2][ch], fmaf(x1, A[1][ch], fmaf(x0, A[0][ch], b[ch])));
                 } else {
@@ -105,9 +110,10 @@ static __global__ __launch_bounds__(kWG) void k_hed(const uint8_t* __restrict__ 
                     for (int ch = 0; ch < 3; ++ch) l[ch] = fmaf(st[2], Rs[2][ch], fmaf(st[1], Rs[1][ch], st[0] * Rs[0][ch]));
                 }
 #pragma unroll
-                for (int ch = 0; ch < 3; ++ch) tv[3 * px + ch] = 255.0f * __builtin_amdgcn_exp2f(l[ch]);
+                for (int ch = 0; ch < 3; ++ch)
+                    tv[3 * px + ch] = MODE == 2 ? fmaf(255.0f, __builtin_amdgcn_exp2f(l[ch]), -510.0f) : 255.0f * __builtin_amdgcn_exp2f(l[ch]);
             }
-            // clip [0,1], *255, astype(uint8) (augmenter.py:320-325): min(255 x, 255) truncated = the saturating pack
+            // clip [0,1], *255, astype(uint8) (augmenter.py:320-325): max(min(255 x, 255), 0) truncated = the saturating pack
             const Chunk o = pack_trunc_fast(tv);
             if (cc < c1) store_chunk<ALIGNED>(dst, nbytes, cc, o);
         }
@@ -161,7 +167,9 @@ static __global__ __launch_bounds__(kWG) void k_hed_f64(const double* __restrict
     for (int p = p0 + tid; p < p1; p += kWG) {
         const double r = src[3 * (size_t)p], g = src[3 * (size_t)p + 1], b = src[3 * (size_t)p + 2];
         acc += r + g + b;
-        const double x[3] = {log(fmax(r, 1e-6)) / Ladj, log(fmax(g, 1e-6)) / Ladj, log(fmax(b, 1e-6)) / Ladj};
+        double x[3];
+        if (MODE == 2) { x[0] = -log10(r + 2.0); x[1] = -log10(g + 2.0); x[2] = -log10(b + 2.0); }       // <= 0.17
+        else { x[0] = log(fmax(r, 1e-6)) / Ladj; x[1] = log(fmax(g, 1e-6)) / Ladj; x[2] = log(fmax(b, 1e-6)) / Ladj; }
         double st[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -171,8 +179,14 @@ static __global__ __launch_bounds__(kWG) void k_hed_f64(const double* __restrict
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const double lr = -(st[0] * (-Ladj)) * hc.R[c] - (st[1] * (-Ladj)) * hc.R[3 + c] - (st[2] * (-Ladj)) * hc.R[6 + c];
-            dst[3 * (size_t)p + c] = fmin(fmax(exp(lr), 0.0), 1.0);                 // combine_stains + clip
+            double v;
+            if (MODE == 2) {
+                v = pow(10.0, -(st[0] * hc.R[c] + st[1] * hc.R[3 + c] + st[2] * hc.R[6 + c])) - 2.0;
+            } else {
+                const double lr = -(st[0] * (-Ladj)) * hc.R[c] - (st[1] * (-Ladj)) * hc.R[3 + c] - (st[2] * (-Ladj)) * hc.R[6 + c];
+                v = exp(lr);
+            }
+            dst[3 * (size_t)p + c] = fmin(fmax(v, 0.0), 1.0);                       // combine_stains + clip
         }
     }
     acc = wave_sum(acc);
@@ -218,7 +232,7 @@ extern "C" int sl_hed_augment(const uint8_t* rgb, uint8_t* out, int n, int h, in
                               const double* bias, double cutoff_lo, double cutoff_hi, int skimage_mode,
                               int32_t* applied, void* workspace, size_t workspace_bytes, void* stream) {
     if (!rgb || !out || !sigma || !bias || n <= 0 || h <= 0 || w <= 0) return SL_ERR_BADARG;
-    if (skimage_mode != SL_HED_SKIMAGE_018 && skimage_mode != SL_HED_SKIMAGE_019) return SL_ERR_BADARG;
+    if (skimage_mode != SL_HED_SKIMAGE_018 && skimage_mode != SL_HED_SKIMAGE_019 && skimage_mode != SL_HED_SKIMAGE_017) return SL_ERR_BADARG;
     const long P = (long)h * w;
     if (P > (1L << 30)) return SL_ERR_BADARG;
     if (!workspace || workspace_bytes < sizeof(unsigned long long) * (size_t)n || ((uintptr_t)workspace & 7u))
@@ -235,8 +249,9 @@ extern "C" int sl_hed_augment(const uint8_t* rgb, uint8_t* out, int n, int h, in
     const dim3 grid((unsigned)((long)n * parts)), block(kWG);
     const bool al = aligned4(rgb, P) && aligned4(out, P);
 #define SL_GO(M, A) hipLaunchKernelGGL((k_hed<M, A>), grid, block, 0, s, rgb, out, (int)P, parts, sigma, bias, hc, sums)
-    if (skimage_mode == SL_HED_SKIMAGE_018) { if (al) SL_GO(0, true); else SL_GO(0, false); }
-    else                                    { if (al) SL_GO(1, true); else SL_GO(1, false); }
+    if (skimage_mode == SL_HED_SKIMAGE_018)      { if (al) SL_GO(0, true); else SL_GO(0, false); }
+    else if (skimage_mode == SL_HED_SKIMAGE_019) { if (al) SL_GO(1, true); else SL_GO(1, false); }
+    else                                         { if (al) SL_GO(2, true); else SL_GO(2, false); }
 #undef SL_GO
     if (al) hipLaunchKernelGGL((k_hed_fixup<true>), grid, block, 0, s, rgb, out, (int)P, parts, sums, cutoff_lo, cutoff_hi, applied);
     else    hipLaunchKernelGGL((k_hed_fixup<false>), grid, block, 0, s, rgb, out, (int)P, parts, sums, cutoff_lo, cutoff_hi, applied);
@@ -247,7 +262,7 @@ extern "C" int sl_hed_augment_f64(const double* rgb, double* out, int n, int h, 
                                   const double* bias, double cutoff_lo, double cutoff_hi, int skimage_mode,
                                   int32_t* applied, void* workspace, size_t workspace_bytes, void* stream) {
     if (!rgb || !out || !sigma || !bias || n <= 0 || h <= 0 || w <= 0) return SL_ERR_BADARG;
-    if (skimage_mode != SL_HED_SKIMAGE_018 && skimage_mode != SL_HED_SKIMAGE_019) return SL_ERR_BADARG;
+    if (skimage_mode != SL_HED_SKIMAGE_018 && skimage_mode != SL_HED_SKIMAGE_019 && skimage_mode != SL_HED_SKIMAGE_017) return SL_ERR_BADARG;
     const long P = (long)h * w;
     if (P > (1L << 30)) return SL_ERR_BADARG;
     if (!workspace || workspace_bytes < sizeof(double) * (size_t)n || ((uintptr_t)workspace & 7u)) return SL_ERR_WORKSPACE;
@@ -261,7 +276,8 @@ extern "C" int sl_hed_augment_f64(const double* rgb, double* out, int n, int h, 
     const int parts = parts_for(P);
     const dim3 grid((unsigned)((long)n * parts)), block(kWG);
     if (skimage_mode == SL_HED_SKIMAGE_018) hipLaunchKernelGGL((k_hed_f64<0>), grid, block, 0, s, rgb, out, (int)P, parts, sigma, bias, hc, sums);
-    else hipLaunchKernelGGL((k_hed_f64<1>), grid, block, 0, s, rgb, out, (int)P, parts, sigma, bias, hc, sums);
+    else if (skimage_mode == SL_HED_SKIMAGE_019) hipLaunchKernelGGL((k_hed_f64<1>), grid, block, 0, s, rgb, out, (int)P, parts, sigma, bias, hc, sums);
+    else hipLaunchKernelGGL((k_hed_f64<2>), grid, block, 0, s, rgb, out, (int)P, parts, sigma, bias, hc, sums);
     hipLaunchKernelGGL(k_hed_f64_fixup, grid, block, 0, s, rgb, out, (int)P, parts, sums, cutoff_lo, cutoff_hi, applied);
     return launch_status();
 }

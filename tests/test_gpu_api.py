@@ -108,6 +108,17 @@ def test_hed_batch_modes_and_ragged():
     out19, _ = engine.hed_augment(to_dev(tiles[:3]), sig[:3], bia[:3], skimage_mode=1)
     for i in range(3):
         u8_parity(out19[i].cpu().numpy(), so.hed_transform(tiles[i], sig[i], bia[i], mode="0.19"), max_rate=1e-4)
+    # scikit-image <= 0.17 semantics (the release environment.yml pins): -log10(rgb + 2), 10^x - 2
+    out17, _ = engine.hed_augment(to_dev(tiles[:3]), sig[:3], bia[:3], skimage_mode=2)
+    for i in range(3):
+        want = so.hed_transform(tiles[i], sig[i], bia[i], mode="0.17")
+        u8_parity(out17[i].cpu().numpy(), want, max_rate=1e-4)
+        assert not np.array_equal(want, so.hed_transform(tiles[i], sig[i], bia[i]))      # a different map, not a relabelling
+    a17 = sl.HedLightColorAugmenter(skimage_mode="0.17")
+    a17._sigmas, a17._biases = list(sig[0]), list(bia[0])
+    u8_parity(a17.transform(tiles[0]), so.hed_transform(tiles[0], sig[0], bia[0], mode="0.17"), max_rate=1e-4)
+    f = tiles[1].astype(np.float64) / 255.0
+    np.testing.assert_allclose(a17.transform(f), so.hed_transform(f, sig[0], bia[0], mode="0.17"), rtol=0, atol=1e-12)
     odd = [so.synth_tile(33, 47, 8)]
     o, _ = engine.hed_augment(to_dev(odd), [sig[0]], [bia[0]])
     u8_parity(o[0].cpu().numpy(), so.hed_transform(odd[0], sig[0], bia[0]), max_rate=1e-3)
