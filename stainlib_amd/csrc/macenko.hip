@@ -398,3 +398,10 @@ extern "C" void sl_debug_inner(unsigned long long* out, int reset) {
     if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; hipMemcpyToSymbol(HIP_SYMBOL(sl::g_dbg_inner), z, 32); }
 }
 #endif
+
+#ifdef SL_DEBUG_SUBCLK
+extern "C" void sl_debug_bclk(unsigned long long* out, int reset) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(sl::g_bclk), 128);
+    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(sl::g_bclk), z, 128); }
+}
+#endif

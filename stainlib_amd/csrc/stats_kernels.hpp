@@ -352,11 +352,20 @@ __device__ __forceinline__ void wg_minmax(int n, const KeyAt& key_at, uint32_t& 
 // integers (kAbsent = no key).  Bracket b is the pct[b]-th percentile of key set set_of[b].  The passes touch no
 // memory but the LDS histogram: the sample is read and its keys are evaluated once.
 constexpr uint32_t kAbsent = 0xffffffffu;
+#ifdef SL_DEBUG_SUBCLK
+__device__ unsigned long long g_bclk[16];      // development aid: wall-clock ticks per step of wg_brackets_regs, summed over calls
+#define SL_BCLK(j) { __syncthreads(); if (threadIdx.x == 0) { const long long now_ = wall_clock64(); atomicAdd(&g_bclk[j], (unsigned long long)(now_ - bclk_t_)); bclk_t_ = now_; } }
+#else
+#define SL_BCLK(j)
+#endif
 template <int NSETS, int KPT, int NBR>
 __device__ __forceinline__ void wg_brackets_regs(const uint32_t (&ord)[NSETS][KPT], const int (&set_of)[NBR],
                                                  const double (&pct)[NBR], float* lo, float* hi, SelScratch& S) {
     static_assert(2 * NBR <= 4, "four 256-bin refinement windows");
     uint32_t omin[NSETS], omax[NSETS], nv[NSETS];
+#ifdef SL_DEBUG_SUBCLK
+    long long bclk_t_ = wall_clock64();
+#endif
 #pragma unroll
     for (int s = 0; s < NSETS; ++s) {
         if (threadIdx.x == 0) { S.misc[4] = 0xffffffffu; S.misc[5] = 0; S.misc[6] = 0; }
@@ -377,6 +386,7 @@ __device__ __forceinline__ void wg_brackets_regs(const uint32_t (&ord)[NSETS][KP
         omin[s] = S.misc[4]; omax[s] = S.misc[5]; nv[s] = S.misc[6];
         __syncthreads();
     }
+    SL_BCLK(0);
     uint32_t rank[2 * NBR], wlo[2 * NBR], whi[2 * NBR], below[2 * NBR];
     bool open[2 * NBR];
 #pragma unroll
@@ -411,6 +421,7 @@ __device__ __forceinline__ void wg_brackets_regs(const uint32_t (&ord)[NSETS][KP
             if (o != kAbsent) atomicAdd(&S.hist[(o - omin[s]) >> s1[s]], 1u);
         }
         __syncthreads();
+        SL_BCLK(1);
 #pragma unroll
         for (int i = 0; i < 2 * NBR; ++i) {
             if (set_of[i >> 1] != s) continue;
@@ -422,6 +433,7 @@ __device__ __forceinline__ void wg_brackets_regs(const uint32_t (&ord)[NSETS][KP
             __syncthreads();
         }
     }
+    SL_BCLK(2);
     bool any_refine = false;
 #pragma unroll
     for (int s = 0; s < NSETS; ++s) any_refine = any_refine | (nv[s] > 0 && s1[s] > 0);
@@ -442,6 +454,7 @@ __device__ __forceinline__ void wg_brackets_regs(const uint32_t (&ord)[NSETS][KP
             }
         }
         __syncthreads();
+        SL_BCLK(3);
 #pragma unroll
         for (int i = 0; i < 2 * NBR; ++i) {
             const int s = set_of[i >> 1];
@@ -455,6 +468,7 @@ __device__ __forceinline__ void wg_brackets_regs(const uint32_t (&ord)[NSETS][KP
             __syncthreads();
         }
     }
+    SL_BCLK(4);
 #pragma unroll
     for (int b = 0; b < NBR; ++b) {
         const bool none = nv[set_of[b]] == 0;
@@ -812,20 +826,28 @@ struct SampleAngleKey {
     const uint32_t* sample; TabView tab; float V[6]; int cps_log2; int P; float ylimf;
     __device__ __forceinline__ float operator()(int b) const {
         if (sample_pixel((uint32_t)b, cps_log2) >= P) return nan_f();
-        const uint32_t s = sample[b];
-        const uint32_t r = s & 255u, g = (s >> 8) & 255u, bl = (s >> 16) & 255u;
-        if (!is_tissue_f(tab.gam(r), tab.gam(g), tab.gam(bl), ylimf)) return nan_f();
-        return angle_key(V, tab.odf(r), tab.odf(g), tab.odf(bl));
+        return of_word(sample[b]);
     }
+    // the key of a sample word already in a register; branch-free (NaN = not a tissue pixel)
+    __device__ __forceinline__ float of_word(uint32_t s) const {
+        const uint32_t r = s & 255u, g = (s >> 8) & 255u, bl = (s >> 16) & 255u;
+        const bool tissue = is_tissue_f(tab.gam(r), tab.gam(g), tab.gam(bl), ylimf);
+        const float k = angle_key(V, tab.odf(r), tab.odf(g), tab.odf(bl));
+        return tissue ? k : nan_f();
+    }
+    __device__ __forceinline__ bool present(int b, int n_sample) const { return b < n_sample && sample_pixel((uint32_t)b, cps_log2) < P; }
 };
 // concentration `col` of sample entry b (all pixels, tissue or not)
 struct SampleConcKey {
     const uint32_t* sample; TabView tab; LassoK L; int cps_log2; int P; int col;
     __device__ __forceinline__ void both(int b, float& c1, float& c2) const {      // NaN, NaN: entry absent
         if (sample_pixel((uint32_t)b, cps_log2) >= P) { c1 = c2 = nan_f(); return; }
-        const uint32_t s = sample[b];
+        of_word(sample[b], c1, c2);
+    }
+    __device__ __forceinline__ void of_word(uint32_t s, float& c1, float& c2) const {
         lasso2(L, tab.odf(s & 255u), tab.odf((s >> 8) & 255u), tab.odf((s >> 16) & 255u), c1, c2);
     }
+    __device__ __forceinline__ bool present(int b, int n_sample) const { return b < n_sample && sample_pixel((uint32_t)b, cps_log2) < P; }
     __device__ __forceinline__ float operator()(int b) const {
         float c1, c2;
         both(b, c1, c2);
@@ -1511,12 +1533,18 @@ __device__ __forceinline__ void angle_brackets(const SampleAngleKey& key, int n_
                                                SelScratch& S) {
     constexpr int KPT = kMaxSample / THREADS;
     uint32_t ord[1][KPT];
+#ifdef SL_DEBUG_SUBCLK
+    long long bclk_t_ = wall_clock64();
+#endif
+    // (loading all sample words up front, so that the loads overlap, saves ~20 us here but measured 1-2 % SLOWER end to
+    // end: the extra live registers shift the allocator's spills into the sweep prologues)
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
         const int b = j * THREADS + (int)threadIdx.x;
         const float k = b < n_sample ? key(b) : nan_f();
         ord[0][j] = k == k ? f2ord(k) : kAbsent;
     }
+    SL_BCLK(5);
     const int set_of[2] = {0, 0};
     const double p2[2] = {100.0 - pct, pct};          // minPhi, maxPhi (macenko_stain_extractor.py:33-34)
     wg_brackets_regs<1, KPT, 2>(ord, set_of, p2, lo, hi, S);
@@ -1526,6 +1554,9 @@ template <int THREADS>
 __device__ __forceinline__ void conc_brackets(const SampleConcKey& key, int n_sample, float* lo, float* hi, SelScratch& S) {
     constexpr int KPT = kMaxSample / THREADS;
     uint32_t ord[2][KPT];
+#ifdef SL_DEBUG_SUBCLK
+    long long bclk_t_ = wall_clock64();
+#endif
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
         const int b = j * THREADS + (int)threadIdx.x;
@@ -1534,6 +1565,7 @@ __device__ __forceinline__ void conc_brackets(const SampleConcKey& key, int n_sa
         ord[0][j] = c1 == c1 ? f2ord(c1) : kAbsent;
         ord[1][j] = c2 == c2 ? f2ord(c2) : kAbsent;
     }
+    SL_BCLK(6);
     const int set_of[2] = {0, 1};
     const double p2[2] = {99.0, 99.0};
     wg_brackets_regs<2, KPT, 2>(ord, set_of, p2, lo, hi, S);
@@ -1959,6 +1991,11 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
         int fallbacks = 0;
         int sweeps_used = 0;
 #define SL_PHASE(i) { if (a.phase_clock && tid == 0) a.phase_clock[(size_t)tile * 8 + (i)] = wall_clock64(); if (a.debug_stop == (i) + 1) { __syncthreads(); continue; } }
+#ifdef SL_DEBUG_SUBCLK
+#define SL_SUB(j) { __syncthreads(); if (a.phase_clock && tid == 0) a.phase_clock[(size_t)a.n_tiles * 8 + (size_t)tile * 16 + (j)] = wall_clock64(); }
+#else
+#define SL_SUB(j)
+#endif
         SL_PHASE(0);
         sh.tab.fill();                       // layout A for the moment / dictionary sweeps (all waves left the last tile's apply)
         __syncthreads();
@@ -1986,6 +2023,7 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
             __syncthreads();
             SL_PHASE(1);
             // ---------------- finish 1: eigenvectors, angle brackets
+            SL_SUB(0);
             if (tid == 0) {
                 double Vd[6];
                 float Vf[6];
@@ -1994,6 +2032,7 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
                 sh.n_raw = 0; sh.overflow = 0;
             }
             __syncthreads();
+            SL_SUB(1);
             if (sh.status == SL_TILE_OK) {                                    // block-uniform
                 {
                     SampleAngleKey key;
@@ -2029,19 +2068,23 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
                 const float los[2] = {sh.lo[0], sh.lo[1]}, his[2] = {sh.hi[0], sh.hi[1]};
                 const long long base[2] = {0, (long long)T - (long long)sh.n_raw};   // plain = tissue pixels not collected
                 uint32_t n_lt[2], n_in[2];
+                SL_SUB(2);
                 wg_refine((int)n_raw, rkey, los, his, cand0, cand1, (uint32_t)a.cap_list, n_lt, n_in, sh.S);
+                SL_SUB(3);
                 for (int li = 0; li < 2; ++li) {
                     float xa, xb;
                     stage_order_stats(li ? cand1 : cand0, n_in[li], (uint32_t)a.cap_list, complete, los[li], his[li], base[li] + n_lt[li], a.P, tkey,
                                       T, k[li], xa, xb, fallbacks, sh.S);
                     if (tid == 0) { sh.res[2 * li] = xa; sh.res[2 * li + 1] = xb; }
                     __syncthreads();
+                    SL_SUB(4 + li);
                 }
                 if (tid == 0) {
                     double M[6];
                     stain_matrix_from_angles(sh.Vd, sh.res, gfrac, M);
                     for (int i = 0; i < 6; ++i) sh.M[i] = M[i];
                 }
+                SL_SUB(6);
             }
         } else {
             // ---------------- Vahadane: class-moment dictionary learning
@@ -2070,6 +2113,7 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
                 sh.n_raw = 0; sh.overflow = 0;
             }
             __syncthreads();
+            SL_SUB(7);
             // ---------------- concentration brackets from the sample
             {
                 SampleConcKey ckey;
@@ -2103,7 +2147,9 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
                 const float los[2] = {sh.lo[0], sh.lo[1]}, his[2] = {sh.hi[0], sh.hi[1]};
                 const long long n_plain = (long long)a.P - (long long)sh.n_raw;        // plain = pixels not collected
                 uint32_t n_lt[2], n_in[2];
+                SL_SUB(8);
                 wg_refine((int)n_raw, rkey, los, his, cand0, cand1, (uint32_t)a.cap_list, n_lt, n_in, sh.S);
+                SL_SUB(9);
                 for (int col = 0; col < 2; ++col) {
                     tkey.col = col;
                     float xa, xb;
@@ -2111,6 +2157,7 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
                                       tkey, (uint32_t)a.P, k, xa, xb, fallbacks, sh.S);
                     if (tid == 0) { sh.res[2 * col] = xa; sh.res[2 * col + 1] = xb; }
                     __syncthreads();
+                    SL_SUB(10 + col);
                 }
                 if (tid == 0) {
                     sh.maxC[0] = np_lerp((double)sh.res[0], (double)sh.res[1], gfrac);   // normalizer.py:36,47
@@ -2145,6 +2192,7 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
         __syncthreads();     // sh.* is reused by the next tile
         SL_PHASE(7);
 #undef SL_PHASE
+#undef SL_SUB
     }
 }
 
