@@ -12,6 +12,22 @@ python tools/crossover.py 2>/dev/null | grep "^size" > "$out/${tag}_crossover.tx
 python tools/phase_times.py 512 1024 2>/dev/null | grep -A12 "per-tile" > "$out/${tag}_phase_times.txt"
 rm -rf /tmp/kt; timeout 600 rocprofv3 --kernel-trace -d /tmp/kt -o p -- python bench.py --steps 20 --warmup 3 > /dev/null 2>&1
 python tools/rocpd_stats.py "$(ls /tmp/kt/*/*.db /tmp/kt/*.db 2>/dev/null | head -1)" > "$out/${tag}_kernel_stats.md" 2>&1
+# Vahadane, 128 tiles (BASELINE configs[2]): per-kernel times of the one-launch-per-phase schedule
+cat > /tmp/vah128.py <<'PY'
+import sys, torch
+sys.path.insert(0, ".")
+from stainlib_amd import engine
+rgb = engine.synth_tiles(128, 1024, 1024, seed=5)
+tgt = engine.synth_tiles(1, 1024, 1024, seed=1001)
+out = torch.empty_like(rgb)
+p = engine.make_params(dl_tol=1e-6, dl_max_sweeps=100)
+Mt, mct, _, _ = engine.vahadane_fit(tgt, params=p)
+for _ in range(10):
+    engine.vahadane_transform(rgb, Mt[0], mct[0], params=p, out=out)
+torch.cuda.synchronize()
+PY
+rm -rf /tmp/ktv; timeout 600 rocprofv3 --kernel-trace -d /tmp/ktv -o p -- python /tmp/vah128.py > /dev/null 2>&1
+python tools/rocpd_stats.py "$(ls /tmp/ktv/*/*.db /tmp/ktv/*.db 2>/dev/null | head -1)" 2>&1 | grep -v "at::native\|rocclr\|Cijk" > "$out/${tag}_kernel_stats_vahadane128.md"
 for pass in "f:FETCH_SIZE" "w:WRITE_SIZE" "s1:SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA" "s2:SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"; do
   t=${pass%%:*}; c=${pass#*:}
   rm -rf /tmp/pmc_$t; timeout 400 rocprofv3 --pmc $c -d /tmp/pmc_$t -o p -- python tools/run_fused_once.py 512 > /dev/null 2>&1
