@@ -785,6 +785,14 @@ __device__ __forceinline__ void select_sweep(const uint8_t* src, int P, int c0, 
                 lasso_interior(K.L, g.v[3 * px], g.v[3 * px + 1], g.v[3 * px + 2], a1, a2);
                 const bool g1 = a1 >= clo0, g2 = a2 >= clo1;
                 m = __builtin_amdgcn_ballot_w64(g1) | __builtin_amdgcn_ballot_w64(g2);
+#ifdef SL_DEBUG_EXTRA_MATH
+                {   // development aid: the same arithmetic once more (a VALU-bound sweep slows down in proportion)
+                    float b1, b2;
+                    lasso_interior(K.L, g.v[3 * px + 1], g.v[3 * px + 2], g.v[3 * px], b1, b2);
+                    const bool h1 = b1 >= 1e30f, h2 = b2 >= 1e30f;
+                    m |= __builtin_amdgcn_ballot_w64(h1) | __builtin_amdgcn_ballot_w64(h2);
+                }
+#endif
             }
             if (TAIL) {
                 const bool inb = (cc < c1) & (ALIGNED | ((size_t)cc * 4 + px < (size_t)P));
@@ -1987,7 +1995,11 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
 
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         const size_t nbytes = (size_t)a.P * 3;
+#ifdef SL_DEBUG_SAMETILE
+        const uint8_t* src = a.rgb + (size_t)(tile & SL_DEBUG_SAMETILE) * nbytes;   // development aid: cache-resident input (0: one tile, 7: eight)
+#else
         const uint8_t* src = a.rgb + (size_t)tile * nbytes;
+#endif
         int fallbacks = 0;
         int sweeps_used = 0;
 #define SL_PHASE(i) { if (a.phase_clock && tid == 0) a.phase_clock[(size_t)tile * 8 + (i)] = wall_clock64(); if (a.debug_stop == (i) + 1) { __syncthreads(); continue; } }
