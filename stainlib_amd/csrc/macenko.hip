@@ -21,6 +21,8 @@ constexpr int kDictFusedMinTiles = 480;     // Vahadane: below it the dictionary
 constexpr int kDictFusedMinTilesSmall = 192;   // ... for tiles below 512 Ki pixels (512^2: 0.82 vs 1.34 ms at 64 tiles, 1.53 vs 1.46 at 256)
 constexpr int kDictFixedSweeps = 4;         // full sweeps launched after the sample stage; tiles that need more finish in k_dict_tail
 
+unsigned g_debug_dyn_lds = 0;          // development aid: extra dynamic LDS per sweep workgroup (occupancy experiments)
+
 struct Layout {
     int parts, stride_log2, n_sample, G, cap_raw, cap_list;
     bool fused;
@@ -105,20 +107,20 @@ int run_stats_group(const uint8_t* rgb, int g0, int m, long P, const SlParams& p
     SlProfile* prof = p.profile;
     {
         ProfScope ps(prof, SL_PROF_MOMENTS, m, s);
-        if (al) hipLaunchKernelGGL((k_moments<true>), gs, bs, 0, s, a);
-        else    hipLaunchKernelGGL((k_moments<false>), gs, bs, 0, s, a);
+        if (al) hipLaunchKernelGGL((k_moments<true>), gs, bs, g_debug_dyn_lds, s, a);
+        else    hipLaunchKernelGGL((k_moments<false>), gs, bs, g_debug_dyn_lds, s, a);
     }
     { ProfScope ps(prof, SL_PROF_FINISH, m, s); hipLaunchKernelGGL(k_finish_moments, gf, bf, 0, s, a); }
     {
         ProfScope ps(prof, SL_PROF_SELECT_ANGLE, m, s);
-        if (al) hipLaunchKernelGGL((k_select<kStageAngle, true>), gs, bs, 0, s, a);
-        else    hipLaunchKernelGGL((k_select<kStageAngle, false>), gs, bs, 0, s, a);
+        if (al) hipLaunchKernelGGL((k_select<kStageAngle, true>), gs, bs, g_debug_dyn_lds, s, a);
+        else    hipLaunchKernelGGL((k_select<kStageAngle, false>), gs, bs, g_debug_dyn_lds, s, a);
     }
     { ProfScope ps(prof, SL_PROF_FINISH, m, s); hipLaunchKernelGGL(k_finish_angle, gf, bf, 0, s, a); }
     {
         ProfScope ps(prof, SL_PROF_SELECT_CONC, m, s);
-        if (al) hipLaunchKernelGGL((k_select<kStageConc, true>), gs, bs, 0, s, a);
-        else    hipLaunchKernelGGL((k_select<kStageConc, false>), gs, bs, 0, s, a);
+        if (al) hipLaunchKernelGGL((k_select<kStageConc, true>), gs, bs, g_debug_dyn_lds, s, a);
+        else    hipLaunchKernelGGL((k_select<kStageConc, false>), gs, bs, g_debug_dyn_lds, s, a);
     }
     {
         ProfScope ps(prof, SL_PROF_FINISH, m, s);
@@ -391,6 +393,7 @@ extern "C" int sl_debug_layout(int n, int h, int w, size_t* off_state, size_t* s
 
 extern "C" void sl_debug_set_phase_clock(long long* device_buf) { g_phase_clock = device_buf; }
 extern "C" void sl_debug_set_stop(int phase) { g_debug_stop = phase; }
+extern "C" void sl_debug_set_dyn_lds(unsigned bytes) { g_debug_dyn_lds = bytes; }
 
 #ifdef SL_DEBUG_INNER
 extern "C" void sl_debug_inner(unsigned long long* out, int reset) {
