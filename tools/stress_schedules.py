@@ -10,6 +10,7 @@ sys.path.insert(0, ".")
 from stainlib_amd import engine  # noqa: E402
 
 rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+METHOD = sys.argv[3] if len(sys.argv) > 3 else "macenko"          # "vahadane": same cross-check, dictionary tolerance
 tgt = engine.synth_tiles(1, 256, 256, seed=1, M_true=[[0.55, 0.75, 0.35], [0.10, 0.95, 0.20]])
 Mt, mct, _ = engine.macenko_fit(tgt)
 bad = 0
@@ -33,7 +34,10 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     rgb = base[torch.arange(n, device="cuda") % base.shape[0]].contiguous()
     res = []
     for sched in (1, 2):
-        out, M, mc, st = engine.macenko_transform(rgb, Mt[0], mct[0], params=engine.make_params(schedule=sched))
+        if METHOD == "vahadane":
+            out, M, mc, st = engine.vahadane_transform(rgb, Mt[0], mct[0], params=engine.make_params(schedule=sched, dl_tol=1e-10))
+        else:
+            out, M, mc, st = engine.macenko_transform(rgb, Mt[0], mct[0], params=engine.make_params(schedule=sched))
         res.append((out.clone(), M.clone(), mc.clone(), st.clone()))
     (o1, M1, c1, s1), (o2, M2, c2, s2) = res
     ok = torch.equal(s1, s2)
@@ -42,7 +46,8 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     dc = float(((c1[good] - c2[good]).abs() / c1[good].abs()).max()) if good.any() else 0.0
     d = (o1.to(torch.int16) - o2.to(torch.int16)).abs()
     rate = float((d != 0).float().mean())
-    ok = ok and dM < 1e-9 and dc < 1e-9 and int(d.max()) <= 1 and rate < 1e-4
+    tolM = 1e-7 if METHOD == "vahadane" else 1e-9      # Vahadane: both stop within dl_tol of the same fixed point
+    ok = ok and dM < tolM and dc < (1e-5 if METHOD == "vahadane" else 1e-9) and int(d.max()) <= 1 and rate < (2e-3 if METHOD == "vahadane" else 1e-4)
     bad += not ok
     print(f"case {case:3d} n={n:4d} {h:4d}x{w:4d} kind={kind:.2f} status_equal={torch.equal(s1, s2)} nfail={int((s1 != 0).sum())} dM={dM:.1e} dmaxC={dc:.1e} "
           f"u8 mismatch={rate:.1e} max={int(d.max())} {'OK' if ok else 'MISMATCH'}", flush=True)
