@@ -106,9 +106,12 @@ def exact_rank_pairs(hist_fn, next_above_fn, ks, group=None):
     hist_fn(prefixes, prefix_bits) -> int64 (2, 256) tensor: per target THIS rank's histogram of the next 8 key bits
     among its keys whose top prefix_bits bits equal prefixes[t]; next_above_fn(keys) -> per target this rank's smallest
     key above keys[t] (0xffffffff if none).  Both targets advance in lockstep, so the four all-reduced histogram
-    rounds that pin one order statistic exactly pin both (one sweep over the tiles per round)."""
+    rounds that pin one order statistic exactly pin both (one sweep over the tiles per round).  The k+1-th key is
+    read off the last round's histogram (its bins are keys); the extra next_above sweep only runs when the k-th key
+    is the largest of its 256-key window and unique."""
     _, world = _world(group)
     prefix, below, in_bin, total, k = [0, 0], [0, 0], [0, 0], [None, None], [int(ks[0]), int(ks[1])]
+    succ = [None, None]          # the next larger key inside the last round's 256-key window, if there is one
     for bits in (0, 8, 16, 24):
         h = hist_fn(prefix, bits)
         if world > 1:
@@ -123,18 +126,24 @@ def exact_rank_pairs(hist_fn, next_above_fn, ks, group=None):
             acc = below[t]
             for b in range(256):
                 if k[t] < acc + hc[t][b]:
+                    if bits == 24:       # the bins of the last round ARE keys: the successor is the next non-empty bin
+                        nb = next((b2 for b2 in range(b + 1, 256) if hc[t][b2] > 0), None)
+                        succ[t] = None if nb is None else ((prefix[t] << 8) | nb)
                     prefix[t], below[t], in_bin[t] = (prefix[t] << 8) | b, acc, int(hc[t][b])
                     break
                 acc += hc[t][b]
     need = [not (k[t] + 1 < below[t] + in_bin[t] or k[t] + 1 >= total[t]) for t in range(2)]
     nxt = list(prefix)
+    for t in range(2):           # the sweep for the next larger key is only needed when the window holds none
+        if need[t] and succ[t] is not None:
+            nxt[t], need[t] = succ[t], False
     if any(need):
         got = next_above_fn(prefix)
         if world > 1:
             tt = torch.tensor(got, dtype=torch.int64, device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MIN, group=group)
             got = [int(x) for x in tt.tolist()]
-        nxt = [(got[t] if (need[t] and got[t] != 0xffffffff) else prefix[t]) for t in range(2)]
+        nxt = [(got[t] if (need[t] and got[t] != 0xffffffff) else nxt[t]) for t in range(2)]
     return [(prefix[t], nxt[t], total[t]) for t in range(2)]
 
 

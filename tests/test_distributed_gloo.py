@@ -91,7 +91,8 @@ def _f2ord(a):
 
 def _keys(rank, world, n=5000, seed=3):
     rng = np.random.RandomState(seed)
-    allk = np.concatenate([rng.randn(n).astype(np.float32), np.zeros(400, np.float32), np.float32([1.5] * 7)])  # ties + zeros
+    run = np.float32(2.0) + np.arange(40, dtype=np.float32) * np.spacing(np.float32(2.0))       # 40 consecutive binary32 values
+    allk = np.concatenate([rng.randn(n).astype(np.float32), np.zeros(400, np.float32), np.float32([1.5] * 7), run])  # ties + zeros
     rng.shuffle(allk)
     lo, hi = sd.shard_range(len(allk), rank, world)
     return allk, allk[lo:hi]
@@ -150,6 +151,35 @@ def test_exact_rank_pairs_world2_match_sorted_union():
             kk = min(k, len(srt[t]) - 1)
             assert total == len(srt[t])
             assert sd.ord_to_float(a) == srt[t][kk] and sd.ord_to_float(b) == srt[t][min(kk + 1, len(srt[t]) - 1)]
+
+
+def test_exact_rank_pairs_successor_inside_the_last_window():
+    """Ranks inside a run of consecutive binary32 values: the k+1-th key comes from the last histogram round (no
+    next_above sweep); checked against the sorted keys (single process: the rounds are the same without a group)."""
+    allk, _ = _keys(0, 1)
+    srt = [np.sort(allk), np.sort(-allk)]
+    k2 = int(np.searchsorted(srt[0], np.float32(2.0)))
+    calls = []
+    o = [_f2ord(allk).astype(np.uint64), _f2ord(-allk).astype(np.uint64)]
+
+    def hist_fn(prefixes, bits):
+        rows = []
+        for t in range(2):
+            sel = o[t] if bits == 0 else o[t][(o[t] >> np.uint64(32 - bits)) == np.uint64(prefixes[t])]
+            rows.append(np.bincount(((sel >> np.uint64(24 - bits)) & np.uint64(255)).astype(np.int64), minlength=256).astype(np.int64))
+        return torch.from_numpy(np.stack(rows))
+
+    def next_above_fn(keys):
+        calls.append(tuple(keys))
+        return [int(o[t][o[t] > np.uint64(keys[t])].min()) if (o[t] > np.uint64(keys[t])).any() else 0xffffffff for t in range(2)]
+    n = len(allk)
+    for k in (k2 + 3, k2 + 17, k2 + 38):
+        kneg = n - 1 - (k + 1)                       # the same pair of values seen from the negated keys
+        res = sd.exact_rank_pairs(hist_fn, next_above_fn, (k, kneg))
+        for t, kk in enumerate((k, kneg)):
+            a, b, total = res[t]
+            assert total == n and sd.ord_to_float(a) == srt[t][kk] and sd.ord_to_float(b) == srt[t][kk + 1]
+    assert calls == []                               # every successor sat inside the 256-key window
 
 
 def test_percentile_position_and_lerp_follow_numpy():
