@@ -211,6 +211,10 @@ int sl_tile_moments(const uint8_t* rgb, int n, int h, int w, const SlParams* par
 int sl_slide_key_histogram(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int keyset,
                            const double* basis, const uint32_t* prefixes, int prefix_bits,
                            unsigned long long* hist, void* stream);
+/* The last two rounds in one sweep: hist16 (device, 2 x 65536 uint64, ACCUMULATED into) counts the LOW 16 key bits
+ * over the keys whose top 16 bits equal prefixes16[t] (HOST pointer, 2 values). */
+int sl_slide_key_histogram16(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int keyset,
+                             const double* basis, const uint32_t* prefixes16, unsigned long long* hist16, void* stream);
 /* min_out[t] (device uint32 x 2, set to 0xffffffff by the caller) = min(min_out[t], smallest key of target t
  * above key_ords[t]) (key_ords: HOST pointer, 2 values). */
 int sl_slide_key_next_above(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int keyset,

@@ -7,7 +7,9 @@
 //   sl_tile_moments            per-tile {n, sum od, sum od od^T}            -> summed over tiles and ranks -> V
 //   sl_slide_key_histogram     256-bin histogram of the next 8 key bits among the keys that match a prefix
 //                              -> all-reduced; 4 rounds pin one exact order statistic of the binary32 key
-//   sl_slide_key_next_above    smallest key above a given key (the k+1-th value when the k-th is unique)
+//   sl_slide_key_histogram16   the low 16 bits under a 16-bit prefix in one sweep (2 x 65536 bins, global atomics:
+//                              only ~0.2 % of the pixels match) -> 8 + 8 + 16 bits = three sweeps per stage
+//   sl_slide_key_next_above    smallest key above a given key (only when the last histogram holds no successor)
 // Keys are the ones the per-tile path selects on: the pseudo-angle of the projected OD (tissue pixels) and the
 // two lasso concentrations (all pixels), as order-preserving uint32 of their binary32 value.  Nothing
 // per-pixel is stored: every round is one more sweep over the uint8 tiles.
@@ -45,8 +47,13 @@ struct BinRun {
     __device__ __forceinline__ void flush(uint32_t* hist) { if (run) atomicAdd(&hist[bin], run); run = 0; }
 };
 
-template <int KEYSET, bool NEXT_ABOVE, bool ALIGNED>
+// MODE 0: 256-bin histogram of the next 8 bits (LDS, merged into hist at the end); 1: smallest key above a.above;
+// 2: the LOW 16 bits of the keys whose top 16 bits match, counted straight into hist[2][65536] with global atomics
+// (a 16-bit prefix leaves ~0.2 % of the pixels: two rounds in one sweep)
+template <int KEYSET, int MODE, bool ALIGNED>
 __global__ __launch_bounds__(kSweepThreads, 4) void k_slide_keys(SlideArgs a, unsigned long long* hist, uint32_t* min_out) {
+    constexpr bool NEXT_ABOVE = MODE == 1;
+    constexpr bool LOW16 = MODE == 2;
     __shared__ RowTab s_tab;
     __shared__ uint32_t s_hist[2][256];
     __shared__ uint32_t s_min[2];
@@ -100,6 +107,9 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_slide_keys(SlideArgs a, un
                     if (NEXT_ABOVE) {
                         if (o0 > a.above[0]) best0 = min(best0, o0);
                         if (o1 > a.above[1]) best1 = min(best1, o1);
+                    } else if (LOW16) {
+                        if ((o0 >> 16) == p0) atomicAdd(&hist[o0 & 0xffffu], 1ull);
+                        if ((o1 >> 16) == p1) atomicAdd(&hist[65536u + (o1 & 0xffffu)], 1ull);
                     } else {
                         if (all || (o0 >> hs) == p0) r0.add(s_hist[0], (o0 >> sh) & 255u);
                         if (all || (o1 >> hs) == p1) r1.add(s_hist[1], (o1 >> sh) & 255u);
@@ -116,7 +126,7 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_slide_keys(SlideArgs a, un
         if ((tid & 63) == 0) { atomicMin(&s_min[0], best0); atomicMin(&s_min[1], best1); }
         __syncthreads();
         if (tid < 2 && s_min[tid] != 0xffffffffu) atomicMin(&min_out[tid], s_min[tid]);
-    } else {
+    } else if (!LOW16) {
         r0.flush(s_hist[0]); r1.flush(s_hist[1]);
         __syncthreads();
         for (int i = tid; i < 512; i += blockDim.x) {
@@ -185,7 +195,7 @@ int fill_args(SlideArgs& a, const uint8_t* rgb, int n, int h, int w, const SlPar
     return SL_OK;
 }
 
-template <bool NEXT>
+template <int NEXT>
 void launch_keys(const SlideArgs& a, bool al, unsigned long long* hist, uint32_t* min_out, hipStream_t s) {
     const dim3 g((unsigned)(a.n_items < 512 ? a.n_items : 512)), b(kSweepThreads);
     if (a.keyset == SL_KEYSET_ANGLE) {
@@ -231,7 +241,18 @@ extern "C" int sl_slide_key_histogram(const uint8_t* rgb, int n, int h, int w, c
     if (rc) return rc;
     if (!hist || !prefixes || (prefix_bits != 0 && prefix_bits != 8 && prefix_bits != 16 && prefix_bits != 24)) return SL_ERR_BADARG;
     a.prefix[0] = prefixes[0]; a.prefix[1] = prefixes[1]; a.prefix_bits = prefix_bits;
-    launch_keys<false>(a, aligned4(rgb, (long)h * w), hist, nullptr, (hipStream_t)stream);
+    launch_keys<0>(a, aligned4(rgb, (long)h * w), hist, nullptr, (hipStream_t)stream);
+    return launch_status();
+}
+
+extern "C" int sl_slide_key_histogram16(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int keyset,
+                                        const double* basis, const uint32_t* prefixes16, unsigned long long* hist16, void* stream) {
+    SlideArgs a;
+    const int rc = fill_args(a, rgb, n, h, w, params, keyset, basis);
+    if (rc) return rc;
+    if (!hist16 || !prefixes16) return SL_ERR_BADARG;
+    a.prefix[0] = prefixes16[0]; a.prefix[1] = prefixes16[1]; a.prefix_bits = 16;
+    launch_keys<2>(a, aligned4(rgb, (long)h * w), hist16, nullptr, (hipStream_t)stream);
     return launch_status();
 }
 
@@ -242,6 +263,6 @@ extern "C" int sl_slide_key_next_above(const uint8_t* rgb, int n, int h, int w, 
     if (rc) return rc;
     if (!min_out || !key_ords) return SL_ERR_BADARG;
     a.above[0] = key_ords[0]; a.above[1] = key_ords[1];
-    launch_keys<true>(a, aligned4(rgb, (long)h * w), nullptr, min_out, (hipStream_t)stream);
+    launch_keys<1>(a, aligned4(rgb, (long)h * w), nullptr, min_out, (hipStream_t)stream);
     return launch_status();
 }

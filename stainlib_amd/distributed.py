@@ -99,39 +99,42 @@ def np_lerp(a: float, b: float, t: float) -> float:
     return b - d * (1.0 - t) if t >= 0.5 else a + d * t
 
 
-def exact_rank_pairs(hist_fn, next_above_fn, ks, group=None):
+def exact_rank_pairs(hist_fn, next_above_fn, ks, group=None, hist16_fn=None):
     """For each of TWO targets t: the keys of ranks ks[t] and min(ks[t]+1, N_t-1) (0-based, ascending) of the union of
     every rank's keys of that target, as ordered uint32: [(key_k, key_k1, N_t), ...].
 
     hist_fn(prefixes, prefix_bits) -> int64 (2, 256) tensor: per target THIS rank's histogram of the next 8 key bits
     among its keys whose top prefix_bits bits equal prefixes[t]; next_above_fn(keys) -> per target this rank's smallest
-    key above keys[t] (0xffffffff if none).  Both targets advance in lockstep, so the four all-reduced histogram
-    rounds that pin one order statistic exactly pin both (one sweep over the tiles per round).  The k+1-th key is
-    read off the last round's histogram (its bins are keys); the extra next_above sweep only runs when the k-th key
-    is the largest of its 256-key window and unique."""
+    key above keys[t] (0xffffffff if none).  Both targets advance in lockstep, so the all-reduced histogram rounds that
+    pin one order statistic exactly pin both (one sweep over the tiles per round).  With hist16_fn(prefixes16) ->
+    int64 (2, 65536) (the low 16 bits of the keys under a 16-bit prefix) the last two rounds are one sweep: 8 + 8 + 16
+    bits.  The k+1-th key is read off the last round's histogram (its bins are keys); the extra next_above sweep only
+    runs when the k-th key is the largest of its window and unique."""
+    import numpy as np
     _, world = _world(group)
     prefix, below, in_bin, total, k = [0, 0], [0, 0], [0, 0], [None, None], [int(ks[0]), int(ks[1])]
-    succ = [None, None]          # the next larger key inside the last round's 256-key window, if there is one
-    for bits in (0, 8, 16, 24):
-        h = hist_fn(prefix, bits)
+    succ = [None, None]          # the next larger key inside the last round's window, if there is one
+    rounds = [(0, 8), (8, 8), (16, 16)] if hist16_fn is not None else [(0, 8), (8, 8), (16, 8), (24, 8)]
+    for bits, width in rounds:
+        h = hist16_fn(prefix) if width == 16 else hist_fn(prefix, bits)
         if world > 1:
             dist.all_reduce(h, group=group)
-        hc = h.detach().cpu().tolist()
+        hc = h.detach().cpu().numpy().astype(np.int64)
+        last = bits + width == 32
         for t in range(2):
             if total[t] is None:
-                total[t] = int(sum(hc[t]))
+                total[t] = int(hc[t].sum())
                 if total[t] == 0:
                     raise ValueError("no pixel carries this key")
                 k[t] = min(max(k[t], 0), total[t] - 1)
-            acc = below[t]
-            for b in range(256):
-                if k[t] < acc + hc[t][b]:
-                    if bits == 24:       # the bins of the last round ARE keys: the successor is the next non-empty bin
-                        nb = next((b2 for b2 in range(b + 1, 256) if hc[t][b2] > 0), None)
-                        succ[t] = None if nb is None else ((prefix[t] << 8) | nb)
-                    prefix[t], below[t], in_bin[t] = (prefix[t] << 8) | b, acc, int(hc[t][b])
-                    break
-                acc += hc[t][b]
+            cum = np.cumsum(hc[t])
+            b = int(np.searchsorted(cum, k[t] - below[t], side="right"))     # first bin with below + cum[b] > k
+            if last:                 # the bins of the last round ARE keys: the successor is the next non-empty bin
+                nz = np.nonzero(hc[t][b + 1:])[0]
+                succ[t] = None if len(nz) == 0 else ((prefix[t] << width) | (b + 1 + int(nz[0])))
+            below[t] += int(cum[b] - hc[t][b])
+            in_bin[t] = int(hc[t][b])
+            prefix[t] = (prefix[t] << width) | b
     need = [not (k[t] + 1 < below[t] + in_bin[t] or k[t] + 1 >= total[t]) for t in range(2)]
     nxt = list(prefix)
     for t in range(2):           # the sweep for the next larger key is only needed when the window holds none
@@ -184,7 +187,8 @@ class PooledSlideStatistics:
         # ---- exact angular percentiles over those pixels (:29-34): both in the same four sweeps
         def pairs(keyset, basis, ks):
             res = exact_rank_pairs(lambda pre, bits: engine.slide_key_histogram(tiles_local, keyset, basis, pre, bits, params=params),
-                                   lambda o: engine.slide_key_next_above(tiles_local, keyset, basis, o, params=params), ks, self.group)
+                                   lambda o: engine.slide_key_next_above(tiles_local, keyset, basis, o, params=params), ks, self.group,
+                                   hist16_fn=lambda pre: engine.slide_key_histogram16(tiles_local, keyset, basis, pre, params=params))
             return [(ord_to_float(a), ord_to_float(b)) for a, b, _ in res]
 
         def angle_of_pseudo(p):

@@ -279,6 +279,20 @@ def slide_key_histogram(rgb, keyset, basis, prefixes, prefix_bits, hist=None, pa
     return hist
 
 
+def slide_key_histogram16(rgb, keyset, basis, prefixes16, hist=None, params=None):
+    """Accumulate into hist ((2, 65536) int64, device), for both targets, the LOW 16 key bits of this process's pixels
+    whose key's top 16 bits equal prefixes16[t] (the last two radix rounds in one sweep)."""
+    n, h, w = _check_tiles(rgb)
+    p = params if params is not None else _ffi.default_params()
+    if hist is None:
+        hist = torch.zeros((2, 65536), dtype=torch.int64, device=rgb.device)
+    keep, bp = _basis6(basis)
+    pre = (C.c_uint32 * 2)(int(prefixes16[0]) & 0xffff, int(prefixes16[1]) & 0xffff)
+    _ffi.check(_ffi.lib().sl_slide_key_histogram16(_ptr(rgb), n, h, w, C.byref(p), int(keyset), bp, pre, _ptr(hist), _stream()),
+               "sl_slide_key_histogram16")
+    return hist
+
+
 def slide_key_next_above(rgb, keyset, basis, key_ords, params=None):
     """Per target: smallest key (ordered uint32, Python ints) above key_ords[t] among this process's pixels; 0xffffffff if none."""
     n, h, w = _check_tiles(rgb)

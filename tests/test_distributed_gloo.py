@@ -98,7 +98,7 @@ def _keys(rank, world, n=5000, seed=3):
     return allk, allk[lo:hi]
 
 
-def _rank_pairs_with_numpy_histograms(mine, ks):
+def _rank_pairs_with_numpy_histograms(mine, ks, wide=False):
     """Stand-in for the device kernels: histograms / next-above of THIS rank's keys with numpy; target 0 = the keys,
     target 1 = their negation (so the two targets walk different prefixes in lockstep)."""
     o = [_f2ord(mine).astype(np.uint64), _f2ord(-mine).astype(np.uint64)]
@@ -117,25 +117,32 @@ def _rank_pairs_with_numpy_histograms(mine, ks):
             g = o[t][o[t] > np.uint64(keys[t])]
             out.append(int(g.min()) if len(g) else 0xffffffff)
         return out
-    return sd.exact_rank_pairs(hist_fn, next_above_fn, ks)
+    def hist16_fn(prefixes):                       # the last two rounds in one: low 16 bits under a 16-bit prefix
+        rows = []
+        for t in range(2):
+            sel = o[t][(o[t] >> np.uint64(16)) == np.uint64(prefixes[t])]
+            rows.append(np.bincount((sel & np.uint64(0xffff)).astype(np.int64), minlength=65536).astype(np.int64))
+        return torch.from_numpy(np.stack(rows))
+    return sd.exact_rank_pairs(hist_fn, next_above_fn, ks, hist16_fn=hist16_fn if wide else None)
 
 
-def _worker_rank_pair(rank, world, port, ks, q):
+def _worker_rank_pair(rank, world, port, ks, q, wide=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     _, mine = _keys(rank, world)
-    q.put((rank, [_rank_pairs_with_numpy_histograms(mine, (k, k2)) for k, k2 in ks]))
+    q.put((rank, [_rank_pairs_with_numpy_histograms(mine, (k, k2), wide) for k, k2 in ks]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_exact_rank_pairs_world2_match_sorted_union():
+@pytest.mark.parametrize("wide", [False, True])      # True: 8 + 8 + 16 bits (three rounds), False: four 8-bit rounds
+def test_exact_rank_pairs_world2_match_sorted_union(wide):
     ks = [(0, 5406), (53, 2699), (2500, 2500), (5399, 17), (10 ** 9, 0)]   # incl. inside the block of ties and beyond the end
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_rank_pair, args=(r, 2, port, ks, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_rank_pair, args=(r, 2, port, ks, q, wide)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
