@@ -215,6 +215,15 @@ int sl_slide_key_histogram(const uint8_t* rgb, int n, int h, int w, const SlPara
  * over the keys whose top 16 bits equal prefixes16[t] (HOST pointer, 2 values). */
 int sl_slide_key_histogram16(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int keyset,
                              const double* basis, const uint32_t* prefixes16, unsigned long long* hist16, void* stream);
+/* sl_slide_key_histogram over a stratified pixel sample: one 64-chunk row in 2^sample_log2 (0 <= sample_log2 <= 12). */
+int sl_slide_key_histogram_sampled(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int keyset,
+                                   const double* basis, const uint32_t* prefixes, int prefix_bits, int sample_log2,
+                                   unsigned long long* hist, void* stream);
+/* One sweep for an order statistic whose neighbourhood is known: hist_below (device, 2 x 65536 + 2 uint64, ACCUMULATED
+ * into) = per target the histogram of key - window_lo[t] over the keys in [window_lo[t], window_lo[t] + 65536), followed
+ * by the two counts of keys below window_lo[t] (HOST pointer, 2 ordered-uint32 values). */
+int sl_slide_key_window(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int keyset,
+                        const double* basis, const uint32_t* window_lo, unsigned long long* hist_below, void* stream);
 /* min_out[t] (device uint32 x 2, set to 0xffffffff by the caller) = min(min_out[t], smallest key of target t
  * above key_ords[t]) (key_ords: HOST pointer, 2 values). */
 int sl_slide_key_next_above(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int keyset,

@@ -79,6 +79,10 @@ _SIGNATURES = {
                                            C.POINTER(C.c_uint32), _P, _P]),
     "sl_slide_key_histogram16": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(SlParams), C.c_int, C.POINTER(C.c_double),
                                             C.POINTER(C.c_uint32), _P, _P]),
+    "sl_slide_key_histogram_sampled": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(SlParams), C.c_int, C.POINTER(C.c_double),
+                                                  C.POINTER(C.c_uint32), C.c_int, C.c_int, _P, _P]),
+    "sl_slide_key_window": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(SlParams), C.c_int, C.POINTER(C.c_double),
+                                       C.POINTER(C.c_uint32), _P, _P]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

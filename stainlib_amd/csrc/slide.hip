@@ -5,6 +5,9 @@
 // The statistics of that tall image are sums and order statistics over all its pixels, so each rank reduces
 // its own tiles to a few numbers and the host combines them with small all-reduces (stainlib_amd/distributed.py):
 //   sl_tile_moments            per-tile {n, sum od, sum od od^T}            -> summed over tiles and ranks -> V
+//   sl_slide_key_histogram_sampled + sl_slide_key_window   the fast path: estimate the key on a 1/64 pixel sample,
+//                              then ONE sweep counts the keys below a 65536-key window around the estimate and
+//                              histograms the keys inside it (exact; falls back to the rounds below on a miss)
 //   sl_slide_key_histogram     256-bin histogram of the next 8 key bits among the keys that match a prefix
 //                              -> all-reduced; 4 rounds pin one exact order statistic of the binary32 key
 //   sl_slide_key_histogram16   the low 16 bits under a 16-bit prefix in one sweep (2 x 65536 bins, global atomics:
@@ -33,6 +36,8 @@ struct SlideArgs {
     uint32_t prefix[2];
     int prefix_bits;
     uint32_t above[2];       // next_above: keys strictly greater than these
+    uint32_t window_lo[2];   // window mode: histogram of key - window_lo over [window_lo, window_lo + 65536), count of keys below
+    uint32_t sample_mask;    // 0: every pixel; 2^s - 1: one 64-chunk row in 2^s (stratified over rows and items)
 };
 
 // One target's bookkeeping of a lane: matching keys are counted in runs (neighbouring pixels mostly fall into the
@@ -49,11 +54,15 @@ struct BinRun {
 
 // MODE 0: 256-bin histogram of the next 8 bits (LDS, merged into hist at the end); 1: smallest key above a.above;
 // 2: the LOW 16 bits of the keys whose top 16 bits match, counted straight into hist[2][65536] with global atomics
-// (a 16-bit prefix leaves ~0.2 % of the pixels: two rounds in one sweep)
+// (a 16-bit prefix leaves ~0.2 % of the pixels: two rounds in one sweep); 3: a 65536-key WINDOW at an arbitrary
+// position (hist[2][65536] of key - window_lo) plus the number of keys below it (hist[2 * 65536 + t]): with the
+// window centred on an estimate from a pixel sample, one sweep pins an order statistic
 template <int KEYSET, int MODE, bool ALIGNED>
 __global__ __launch_bounds__(kSweepThreads, 4) void k_slide_keys(SlideArgs a, unsigned long long* hist, uint32_t* min_out) {
     constexpr bool NEXT_ABOVE = MODE == 1;
     constexpr bool LOW16 = MODE == 2;
+    constexpr bool WINDOW = MODE == 3;
+    unsigned long long nb0 = 0, nb1 = 0;             // window mode: keys below the window (per lane)
     __shared__ RowTab s_tab;
     __shared__ uint32_t s_hist[2][256];
     __shared__ uint32_t s_min[2];
@@ -83,11 +92,16 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_slide_keys(SlideArgs a, un
         int c0, c1;
         part_range((a.P + 3) >> 2, a.parts, part, c0, c1);
         for (int c = c0 + tid; c < c1; c += kSweepThreads * 2) {
+            // sampling (wave-uniform: c0 and the wave's first chunk are multiples of 64)
+            const bool take0 = ((((uint32_t)c >> 6) ^ (uint32_t)item) & a.sample_mask) == 0u;
+            const bool take1 = (((((uint32_t)c + kSweepThreads) >> 6) ^ (uint32_t)item) & a.sample_mask) == 0u;
+            if (!(take0 | take1)) continue;
             Chunk in[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) in[u] = load_chunk_clamped<ALIGNED>(src, nbytes, c + u * kSweepThreads, c1);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
+                if (!(u ? take1 : take0)) continue;
                 const int cc = c + u * kSweepThreads;
 #pragma unroll
                 for (int px = 0; px < 4; ++px) {
@@ -110,6 +124,12 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_slide_keys(SlideArgs a, un
                     } else if (LOW16) {
                         if ((o0 >> 16) == p0) atomicAdd(&hist[o0 & 0xffffu], 1ull);
                         if ((o1 >> 16) == p1) atomicAdd(&hist[65536u + (o1 & 0xffffu)], 1ull);
+                    } else if (WINDOW) {
+                        const uint32_t d0 = o0 - a.window_lo[0], d1 = o1 - a.window_lo[1];
+                        nb0 += o0 < a.window_lo[0] ? 1u : 0u;
+                        nb1 += o1 < a.window_lo[1] ? 1u : 0u;
+                        if (o0 >= a.window_lo[0] && d0 < 65536u) atomicAdd(&hist[d0], 1ull);
+                        if (o1 >= a.window_lo[1] && d1 < 65536u) atomicAdd(&hist[65536u + d1], 1ull);
                     } else {
                         if (all || (o0 >> hs) == p0) r0.add(s_hist[0], (o0 >> sh) & 255u);
                         if (all || (o1 >> hs) == p1) r1.add(s_hist[1], (o1 >> sh) & 255u);
@@ -126,6 +146,9 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_slide_keys(SlideArgs a, un
         if ((tid & 63) == 0) { atomicMin(&s_min[0], best0); atomicMin(&s_min[1], best1); }
         __syncthreads();
         if (tid < 2 && s_min[tid] != 0xffffffffu) atomicMin(&min_out[tid], s_min[tid]);
+    } else if (WINDOW) {
+        nb0 = wave_sum(nb0); nb1 = wave_sum(nb1);
+        if ((tid & 63) == 0) { if (nb0) atomicAdd(&hist[2u * 65536u], nb0); if (nb1) atomicAdd(&hist[2u * 65536u + 1u], nb1); }
     } else if (!LOW16) {
         r0.flush(s_hist[0]); r1.flush(s_hist[1]);
         __syncthreads();
@@ -192,6 +215,7 @@ int fill_args(SlideArgs& a, const uint8_t* rgb, int n, int h, int w, const SlPar
     a.lam = p.lasso_lambda;
     for (int i = 0; i < 6; ++i) { a.V[i] = (float)basis_host[i]; a.M[i] = basis_host[i]; }
     a.prefix[0] = a.prefix[1] = 0; a.prefix_bits = 0; a.above[0] = a.above[1] = 0;
+    a.window_lo[0] = a.window_lo[1] = 0; a.sample_mask = 0;
     return SL_OK;
 }
 
@@ -253,6 +277,33 @@ extern "C" int sl_slide_key_histogram16(const uint8_t* rgb, int n, int h, int w,
     if (!hist16 || !prefixes16) return SL_ERR_BADARG;
     a.prefix[0] = prefixes16[0]; a.prefix[1] = prefixes16[1]; a.prefix_bits = 16;
     launch_keys<2>(a, aligned4(rgb, (long)h * w), hist16, nullptr, (hipStream_t)stream);
+    return launch_status();
+}
+
+// The sampled variants of the two histogram entry points: the same counts over one 64-chunk row in 2^sample_log2
+// (an unbiased, stratified pixel sample), for estimating where an order statistic lies.
+extern "C" int sl_slide_key_histogram_sampled(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int keyset,
+                                              const double* basis, const uint32_t* prefixes, int prefix_bits, int sample_log2,
+                                              unsigned long long* hist, void* stream) {
+    SlideArgs a;
+    const int rc = fill_args(a, rgb, n, h, w, params, keyset, basis);
+    if (rc) return rc;
+    if (!hist || !prefixes || sample_log2 < 0 || sample_log2 > 12) return SL_ERR_BADARG;
+    if (prefix_bits != 0 && prefix_bits != 8 && prefix_bits != 16 && prefix_bits != 24) return SL_ERR_BADARG;
+    a.prefix[0] = prefixes[0]; a.prefix[1] = prefixes[1]; a.prefix_bits = prefix_bits;
+    a.sample_mask = (1u << sample_log2) - 1u;
+    launch_keys<0>(a, aligned4(rgb, (long)h * w), hist, nullptr, (hipStream_t)stream);
+    return launch_status();
+}
+
+extern "C" int sl_slide_key_window(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int keyset,
+                                   const double* basis, const uint32_t* window_lo, unsigned long long* hist_below, void* stream) {
+    SlideArgs a;
+    const int rc = fill_args(a, rgb, n, h, w, params, keyset, basis);
+    if (rc) return rc;
+    if (!hist_below || !window_lo) return SL_ERR_BADARG;
+    a.window_lo[0] = window_lo[0]; a.window_lo[1] = window_lo[1];
+    launch_keys<3>(a, aligned4(rgb, (long)h * w), hist_below, nullptr, (hipStream_t)stream);
     return launch_status();
 }
 

@@ -99,7 +99,7 @@ def np_lerp(a: float, b: float, t: float) -> float:
     return b - d * (1.0 - t) if t >= 0.5 else a + d * t
 
 
-def exact_rank_pairs(hist_fn, next_above_fn, ks, group=None, hist16_fn=None):
+def exact_rank_pairs(hist_fn, next_above_fn, ks, group=None, hist16_fn=None, fractions=None, stop_bits=32):
     """For each of TWO targets t: the keys of ranks ks[t] and min(ks[t]+1, N_t-1) (0-based, ascending) of the union of
     every rank's keys of that target, as ordered uint32: [(key_k, key_k1, N_t), ...].
 
@@ -116,6 +116,9 @@ def exact_rank_pairs(hist_fn, next_above_fn, ks, group=None, hist16_fn=None):
     succ = [None, None]          # the next larger key inside the last round's window, if there is one
     rounds = [(0, 8), (8, 8), (16, 16)] if hist16_fn is not None else [(0, 8), (8, 8), (16, 8), (24, 8)]
     for bits, width in rounds:
+        if bits >= stop_bits:        # an estimate is enough: the remaining low bits are set to the middle of their range
+            rest = 32 - bits
+            return [((prefix[t] << rest) | (1 << (rest - 1)), (prefix[t] << rest) | (1 << (rest - 1)), total[t]) for t in range(2)]
         h = hist16_fn(prefix) if width == 16 else hist_fn(prefix, bits)
         if world > 1:
             dist.all_reduce(h, group=group)
@@ -126,6 +129,8 @@ def exact_rank_pairs(hist_fn, next_above_fn, ks, group=None, hist16_fn=None):
                 total[t] = int(hc[t].sum())
                 if total[t] == 0:
                     raise ValueError("no pixel carries this key")
+                if fractions is not None:          # the rank as a fraction of however many keys there turn out to be
+                    k[t] = int(fractions[t] * (total[t] - 1))
                 k[t] = min(max(k[t], 0), total[t] - 1)
             cum = np.cumsum(hc[t])
             b = int(np.searchsorted(cum, k[t] - below[t], side="right"))     # first bin with below + cum[b] > k
@@ -140,7 +145,7 @@ def exact_rank_pairs(hist_fn, next_above_fn, ks, group=None, hist16_fn=None):
     for t in range(2):           # the sweep for the next larger key is only needed when the window holds none
         if need[t] and succ[t] is not None:
             nxt[t], need[t] = succ[t], False
-    if any(need):
+    if any(need) and next_above_fn is not None:
         got = next_above_fn(prefix)
         if world > 1:
             tt = torch.tensor(got, dtype=torch.int64, device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
@@ -150,12 +155,49 @@ def exact_rank_pairs(hist_fn, next_above_fn, ks, group=None, hist16_fn=None):
     return [(prefix[t], nxt[t], total[t]) for t in range(2)]
 
 
+def window_rank_pairs(sample_hist_fn, window_fn, ks, totals, group=None):
+    """The same result as exact_rank_pairs in ONE sweep over the tiles (plus four over a 1/64 pixel sample), or None.
+
+    sample_hist_fn(prefixes, prefix_bits) -> (2, 256) int64: this rank's histogram over its pixel SAMPLE; the exact
+    order statistic of the union of the samples at the same fraction estimates the key.  window_fn(lo) -> (2 * 65536 + 2,)
+    int64: per target this rank's histogram of key - lo[t] inside [lo[t], lo[t] + 65536) and its count of keys below
+    lo[t].  The window is centred on the estimate; if the wanted ranks k and k + 1 (totals[t] keys in all) do not both
+    fall inside it -- the estimate was off by more than 32768 consecutive binary32 values -- the answer is None and the
+    caller takes the radix rounds.  Everything is all-reduced, so all ranks decide alike."""
+    import numpy as np
+    _, world = _world(group)
+    fr = [(int(ks[t]) / (totals[t] - 1)) if totals[t] > 1 else 0.0 for t in range(2)]
+    try:
+        est = exact_rank_pairs(sample_hist_fn, None, (0, 0), group, fractions=[min(max(f, 0.0), 1.0) for f in fr], stop_bits=24)
+    except ValueError:
+        return None
+    lo = [min(max(est[t][0] - 32768, 0), 0xffffffff - 65535) for t in range(2)]
+    buf = window_fn(lo)
+    if world > 1:
+        dist.all_reduce(buf, group=group)
+    b = buf.detach().cpu().numpy().astype(np.int64)
+    out = []
+    for t in range(2):
+        hist, below, n = b[t * 65536:(t + 1) * 65536], int(b[2 * 65536 + t]), int(totals[t])
+        k = min(max(int(ks[t]), 0), n - 1)
+        k1 = min(k + 1, n - 1)
+        inside = int(hist.sum())
+        if not (below <= k and k1 < below + inside):
+            return None
+        cum = np.cumsum(hist)
+        i0 = int(np.searchsorted(cum, k - below, side="right"))
+        i1 = int(np.searchsorted(cum, k1 - below, side="right"))
+        out.append((lo[t] + i0, lo[t] + i1, n))
+    return out
+
+
 class PooledSlideStatistics:
     """Stain matrix and 99th-percentile concentrations of the tall image made of every tile on every rank."""
 
     def __init__(self, group=None, luminosity_threshold=0.8, angular_percentile=99.0, lasso_lambda=0.01):
         self.group = group
         self.thr, self.pct, self.lam = luminosity_threshold, angular_percentile, lasso_lambda
+        self.last_path = []          # per stage of the last call: "window" (one sweep) or "radix" (the fallback rounds)
 
     def __call__(self, tiles_local: torch.Tensor):
         import math
@@ -163,6 +205,7 @@ class PooledSlideStatistics:
         from . import engine, _ffi
         from .utils.excepts import TissueMaskException
         params = engine.make_params(luminosity_threshold=self.thr, angular_percentile=self.pct, lasso_lambda=self.lam)
+        self.last_path = []
         _, world = _world(self.group)
         n_local, h, w, _ = tiles_local.shape
         # ---- covariance of the optical density over every tissue pixel (macenko_stain_extractor.py:18-27)
@@ -173,6 +216,8 @@ class PooledSlideStatistics:
             dist.all_reduce(npx, group=self.group)
         m = mom.cpu().numpy()
         T, n_pixels = int(round(m[0])), int(round(float(npx.item())))
+        # the sample: ~4 M pixels of the slide or more (one row in 2**slog), everything for small slides
+        slog = min(6, max(0, int(math.floor(math.log2(max(n_pixels, 1) / 4.0e6))))) if n_pixels > 4.0e6 else 0
         if T < 1:
             raise TissueMaskException("Empty tissue mask computed")
         mean = m[1:4] / T
@@ -185,7 +230,13 @@ class PooledSlideStatistics:
                 V[:, i] *= -1.0
         Vf = V.astype(np.float32).astype(np.float64)                # the keys are evaluated in binary32
         # ---- exact angular percentiles over those pixels (:29-34): both in the same four sweeps
-        def pairs(keyset, basis, ks):
+        def pairs(keyset, basis, ks, totals):
+            # one sweep, with the window centred on an estimate from a 1/64 pixel sample; the radix rounds if it missed
+            res = window_rank_pairs(lambda pre, bits: engine.slide_key_histogram_sampled(tiles_local, keyset, basis, pre, bits, slog, params=params),
+                                    lambda lo: engine.slide_key_window(tiles_local, keyset, basis, lo, params=params), ks, totals, self.group)
+            self.last_path.append("window" if res is not None else "radix")
+            if res is not None:
+                return [(ord_to_float(a), ord_to_float(b)) for a, b, _ in res]
             res = exact_rank_pairs(lambda pre, bits: engine.slide_key_histogram(tiles_local, keyset, basis, pre, bits, params=params),
                                    lambda o: engine.slide_key_next_above(tiles_local, keyset, basis, o, params=params), ks, self.group,
                                    hist16_fn=lambda pre: engine.slide_key_histogram16(tiles_local, keyset, basis, pre, params=params))
@@ -197,7 +248,7 @@ class PooledSlideStatistics:
             pp = 2.0 - p if p > 0 else -2.0 - p
             return math.atan2(pp, -(1.0 - abs(pp)))
         (k_lo, g_lo), (k_hi, g_hi) = percentile_position(T, 100.0 - self.pct), percentile_position(T, self.pct)
-        (xa0, xb0), (xa1, xb1) = pairs(_ffi.KEYSET_ANGLE, Vf.reshape(6), (k_lo, k_hi))
+        (xa0, xb0), (xa1, xb1) = pairs(_ffi.KEYSET_ANGLE, Vf.reshape(6), (k_lo, k_hi), (T, T))
         phis = [np_lerp(angle_of_pseudo(xa0), angle_of_pseudo(xb0), g_lo), np_lerp(angle_of_pseudo(xa1), angle_of_pseudo(xb1), g_hi)]
         v1 = V @ np.array([math.cos(phis[0]), math.sin(phis[0])])          # :36-37
         v2 = V @ np.array([math.cos(phis[1]), math.sin(phis[1])])
@@ -205,7 +256,7 @@ class PooledSlideStatistics:
         M = M / np.linalg.norm(M, axis=1, keepdims=True)                    # :44
         # ---- 99th percentile of each concentration over every pixel (normalizer.py:36,47): both columns per sweep
         k, g = percentile_position(n_pixels, 99.0)
-        (ca0, cb0), (ca1, cb1) = pairs(_ffi.KEYSET_CONC, M.reshape(6), (k, k))
+        (ca0, cb0), (ca1, cb1) = pairs(_ffi.KEYSET_CONC, M.reshape(6), (k, k), (n_pixels, n_pixels))
         maxC = [np_lerp(float(ca0), float(cb0), g), np_lerp(float(ca1), float(cb1), g)]
         return M, np.asarray(maxC, dtype=np.float64)
 
@@ -227,7 +278,9 @@ class SlideNormalizer:
         """tiles_local: this rank's (n_local,H,W,3) uint8 device tensor.  Returns (out, M_slide, maxC_slide, status_local)."""
         from . import engine
         if self.mode == "pooled":
-            M_np, maxC_np = PooledSlideStatistics(self.group)(tiles_local)
+            stats = PooledSlideStatistics(self.group)
+            M_np, maxC_np = stats(tiles_local)
+            self.last_path = stats.last_path             # per stage: "window" (one sweep) or "radix" (fallback rounds)
             dev = tiles_local.device
             n = tiles_local.shape[0]
             M_s = torch.as_tensor(M_np, dtype=torch.float64, device=dev)

@@ -293,6 +293,31 @@ def slide_key_histogram16(rgb, keyset, basis, prefixes16, hist=None, params=None
     return hist
 
 
+def slide_key_histogram_sampled(rgb, keyset, basis, prefixes, prefix_bits, sample_log2, params=None):
+    """slide_key_histogram over a stratified pixel sample (one 64-chunk row in 2**sample_log2); returns a fresh (2, 256) int64."""
+    n, h, w = _check_tiles(rgb)
+    p = params if params is not None else _ffi.default_params()
+    hist = torch.zeros((2, 256), dtype=torch.int64, device=rgb.device)
+    keep, bp = _basis6(basis)
+    pre = (C.c_uint32 * 2)(int(prefixes[0]) & 0xffffffff, int(prefixes[1]) & 0xffffffff)
+    _ffi.check(_ffi.lib().sl_slide_key_histogram_sampled(_ptr(rgb), n, h, w, C.byref(p), int(keyset), bp, pre, int(prefix_bits),
+                                                         int(sample_log2), _ptr(hist), _stream()), "sl_slide_key_histogram_sampled")
+    return hist
+
+
+def slide_key_window(rgb, keyset, basis, window_lo, params=None):
+    """Per target: histogram of key - window_lo[t] over this process's keys inside [window_lo[t], window_lo[t] + 65536) and the
+    number of its keys below the window.  Returns one (2 * 65536 + 2,) int64 device tensor: hist[0], hist[1], below[0], below[1]."""
+    n, h, w = _check_tiles(rgb)
+    p = params if params is not None else _ffi.default_params()
+    buf = torch.zeros((2 * 65536 + 2,), dtype=torch.int64, device=rgb.device)
+    keep, bp = _basis6(basis)
+    lo = (C.c_uint32 * 2)(int(window_lo[0]) & 0xffffffff, int(window_lo[1]) & 0xffffffff)
+    _ffi.check(_ffi.lib().sl_slide_key_window(_ptr(rgb), n, h, w, C.byref(p), int(keyset), bp, lo, _ptr(buf), _stream()),
+               "sl_slide_key_window")
+    return buf
+
+
 def slide_key_next_above(rgb, keyset, basis, key_ords, params=None):
     """Per target: smallest key (ordered uint32, Python ints) above key_ords[t] among this process's pixels; 0xffffffff if none."""
     n, h, w = _check_tiles(rgb)

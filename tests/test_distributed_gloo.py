@@ -189,6 +189,72 @@ def test_exact_rank_pairs_successor_inside_the_last_window():
     assert calls == []                               # every successor sat inside the 256-key window
 
 
+def _window_fns(mine):
+    """numpy stand-ins for sl_slide_key_histogram_sampled (every 4th key as the sample) and sl_slide_key_window."""
+    o = [_f2ord(mine).astype(np.uint64), _f2ord(-mine).astype(np.uint64)]
+    smp = [x[::4] for x in o]
+
+    def sample_hist_fn(prefixes, bits):
+        rows = []
+        for t in range(2):
+            sel = smp[t] if bits == 0 else smp[t][(smp[t] >> np.uint64(32 - bits)) == np.uint64(prefixes[t])]
+            rows.append(np.bincount(((sel >> np.uint64(24 - bits)) & np.uint64(255)).astype(np.int64), minlength=256).astype(np.int64))
+        return torch.from_numpy(np.stack(rows))
+
+    def window_fn(lo):
+        out = np.zeros(2 * 65536 + 2, np.int64)
+        for t in range(2):
+            d = o[t].astype(np.int64) - int(lo[t])
+            out[2 * 65536 + t] = int((d < 0).sum())
+            out[t * 65536:(t + 1) * 65536] = np.bincount(d[(d >= 0) & (d < 65536)], minlength=65536)
+        return torch.from_numpy(out)
+    return sample_hist_fn, window_fn
+
+
+def _worker_window(rank, world, port, ks, n_total, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _, mine = _keys(rank, world)
+    sf, wf = _window_fns(mine)
+    q.put((rank, [sd.window_rank_pairs(sf, wf, kk, (n_total, n_total)) for kk in ks]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_window_rank_pairs_world2():
+    """One-sweep selection: exact when the window (centred on the sample estimate) holds ranks k and k+1, None otherwise
+    -- identically on every rank.  The keys are N(0,1): 65536 consecutive binary32 values span ~0.8 % of a value, so
+    central ranks of 5447 keys miss the window (None -> the caller's radix rounds) while the block of 400 zeros
+    and the run of consecutive values around 2.0 are hit."""
+    allk, _ = _keys(0, 1)
+    n = len(allk)
+    srt = [np.sort(allk), np.sort(-allk)]
+    kz = int(np.searchsorted(srt[0], np.float32(0.0))) + 100          # inside the zeros (ties)
+    k2 = int(np.searchsorted(srt[0], np.float32(2.0))) + 5            # inside the run of consecutive values
+    ks = [(kz, n - 1 - kz - 1), (k2, n - 1 - k2 - 1), (10, 10)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_window, args=(r, 2, port, ks, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1]
+    hits = 0
+    for kk, pair in zip(ks, res[0][1]):
+        if pair is None:
+            continue
+        hits += 1
+        for t, k in enumerate(kk):
+            a, b, total = pair[t]
+            assert total == n and sd.ord_to_float(a) == srt[t][k] and sd.ord_to_float(b) == srt[t][min(k + 1, n - 1)]
+    assert hits >= 2 and res[0][1][2] is None or hits == 3
+
+
 def test_percentile_position_and_lerp_follow_numpy():
     rng = np.random.RandomState(0)
     x = np.sort(rng.rand(1001))

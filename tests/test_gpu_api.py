@@ -202,9 +202,34 @@ def test_pooled_slide_mode_matches_reference_on_concatenated_tiles():
     M_want = so.macenko_stain_matrix(tall)
     maxC_want = np.percentile(so.get_concentrations(tall, M_want), 99, axis=0)
     dev = to_dev(tiles)
-    M_got, maxC_got = PooledSlideStatistics()(dev)
+    stats = PooledSlideStatistics()
+    M_got, maxC_got = stats(dev)
     np.testing.assert_allclose(M_got, M_want, rtol=0, atol=2e-6)
     np.testing.assert_allclose(maxC_got, maxC_want, rtol=2e-6)
+    assert stats.last_path == ["window", "window"]                        # one sweep per stage
+    # the exact fallback (a window that misses): force it and compare -- the two paths select the same keys
+    from stainlib_amd import distributed as sd
+    real = sd.window_rank_pairs
+    sd.window_rank_pairs = lambda *a, **k: None
+    try:
+        stats2 = PooledSlideStatistics()
+        M_rad, maxC_rad = stats2(dev)
+    finally:
+        sd.window_rank_pairs = real
+    assert stats2.last_path == ["radix", "radix"]
+    assert np.array_equal(M_rad, M_got) and np.array_equal(maxC_rad, maxC_got)
+    # a larger slide, where the sample really is a sample (1 row in 4): still the window path, same keys as the rounds
+    from stainlib_amd import engine
+    big = engine.synth_tiles(40, 512, 512, seed=9)
+    s3, s4 = PooledSlideStatistics(), PooledSlideStatistics()
+    M3, c3 = s3(big)
+    sd.window_rank_pairs = lambda *a, **k: None
+    try:
+        M4, c4 = s4(big)
+    finally:
+        sd.window_rank_pairs = real
+    assert s3.last_path == ["window", "window"] and s4.last_path == ["radix", "radix"]
+    assert np.array_equal(M3, M4) and np.array_equal(c3, c4)
     tgt = so.synth_tile(128, 128, 1001, so.M_TRUE_TGT)
     n = sl.MacenkoNormalizer()
     n.fit(tgt)

@@ -53,7 +53,7 @@ res["cfg5_slide_mode_512x1024"] = {"tiles_per_s": 512 / t, "ms": 1e3 * t}
 snp = SlideNormalizer(n, mode="pooled")
 t = timeit(lambda: snp.transform_shard(rgb512, out=out512), reps=3, warm=1)
 res["cfg5_slide_mode_pooled_512x1024"] = {"tiles_per_s": 512 / t, "ms": 1e3 * t,
-                                          "note": "exact statistics of the concatenated slide: 1 moment sweep + 6 key sweeps + apply"}
+                                          "note": "exact statistics of the concatenated slide: 1 moment sweep + 2 window sweeps (+ 6 over a 1/64 sample) + apply"}
 del rgb512, out512, rgb, out
 
 # cfg4 ------------------------------------------------------------------------------------------
