@@ -86,55 +86,102 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_slide_keys(SlideArgs a, un
     BinRun r0, r1;
     uint32_t best0 = 0xffffffffu, best1 = 0xffffffffu;
     const size_t nbytes = (size_t)a.P * 3;
-    for (int item = blockIdx.x; item < a.n_items; item += gridDim.x) {
-        const int tile = item / a.parts, part = item % a.parts;
-        const uint8_t* src = a.rgb + (size_t)tile * nbytes;
-        int c0, c1;
-        part_range((a.P + 3) >> 2, a.parts, part, c0, c1);
-        for (int c = c0 + tid; c < c1; c += kSweepThreads * 2) {
-            // sampling (wave-uniform: c0 and the wave's first chunk are multiples of 64)
-            const bool take0 = ((((uint32_t)c >> 6) ^ (uint32_t)item) & a.sample_mask) == 0u;
-            const bool take1 = (((((uint32_t)c + kSweepThreads) >> 6) ^ (uint32_t)item) & a.sample_mask) == 0u;
-            if (!(take0 | take1)) continue;
-            Chunk in[2];
+    // one chunk (4 pixels) of a lane: keys, then the mode's bookkeeping
+    auto process = [&](const Chunk& in, int cc, int c1) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) in[u] = load_chunk_clamped<ALIGNED>(src, nbytes, c + u * kSweepThreads, c1);
+        for (int px = 0; px < 4; ++px) {
+            bool have = (cc < c1) & (ALIGNED | ((size_t)cc * 4 + px < (size_t)a.P));
+            uint32_t o0, o1;
+            if (KEYSET == SL_KEYSET_ANGLE) {
+                const float2 er = T.gam_odf(T.addr(in, 3 * px)), eg = T.gam_odf(T.addr(in, 3 * px + 1)), eb = T.gam_odf(T.addr(in, 3 * px + 2));
+                have = have & is_tissue_f(er.x, eg.x, eb.x, a.ylimf);
+                o0 = o1 = f2ord(angle_key(V, er.y, eg.y, eb.y));
+            } else {
+                float c1f, c2f;
+                lasso2(L, T.odf(T.addr(in, 3 * px)), T.odf(T.addr(in, 3 * px + 1)), T.odf(T.addr(in, 3 * px + 2)), c1f, c2f);
+                o0 = f2ord(c1f); o1 = f2ord(c2f);
+            }
+            if (!have) continue;
+            if (NEXT_ABOVE) {
+                if (o0 > a.above[0]) best0 = min(best0, o0);
+                if (o1 > a.above[1]) best1 = min(best1, o1);
+            } else if (LOW16) {
+                if ((o0 >> 16) == p0) atomicAdd(&hist[o0 & 0xffffu], 1ull);
+                if ((o1 >> 16) == p1) atomicAdd(&hist[65536u + (o1 & 0xffffu)], 1ull);
+            } else if (WINDOW) {
+                const uint32_t d0 = o0 - a.window_lo[0], d1 = o1 - a.window_lo[1];
+                nb0 += o0 < a.window_lo[0] ? 1u : 0u;
+                nb1 += o1 < a.window_lo[1] ? 1u : 0u;
+                if (o0 >= a.window_lo[0] && d0 < 65536u) atomicAdd(&hist[d0], 1ull);
+                if (o1 >= a.window_lo[1] && d1 < 65536u) atomicAdd(&hist[65536u + d1], 1ull);
+            } else {
+                if (all || (o0 >> hs) == p0) r0.add(s_hist[0], (o0 >> sh) & 255u);
+                if (all || (o1 >> hs) == p1) r1.add(s_hist[1], (o1 >> sh) & 255u);
+            }
+        }
+    };
+    if (a.sample_mask == 63u) {
+        // 1/64 sample: every wave owns at most ONE 64-chunk row per (tile, part) item, so the loads of four items are
+        // issued together (one row at a time is a chain of exposed memory latencies: 3x slower)
+        const int wave = tid >> 6, lane = tid & 63;
+        for (int it0 = blockIdx.x; it0 < a.n_items; it0 += 4 * (int)gridDim.x) {
+            Chunk ch[4];
+            int ccs[4], c1s[4];
+            bool ok[4];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (!(u ? take1 : take0)) continue;
-                const int cc = c + u * kSweepThreads;
-#pragma unroll
-                for (int px = 0; px < 4; ++px) {
-                    bool have = (cc < c1) & (ALIGNED | ((size_t)cc * 4 + px < (size_t)a.P));
-                    uint32_t o0, o1;
-                    if (KEYSET == SL_KEYSET_ANGLE) {
-                        const float2 er = T.gam_odf(T.addr(in[u], 3 * px)), eg = T.gam_odf(T.addr(in[u], 3 * px + 1)),
-                                     eb = T.gam_odf(T.addr(in[u], 3 * px + 2));
-                        have = have & is_tissue_f(er.x, eg.x, eb.x, a.ylimf);
-                        o0 = o1 = f2ord(angle_key(V, er.y, eg.y, eb.y));
-                    } else {
-                        float c1f, c2f;
-                        lasso2(L, T.odf(T.addr(in[u], 3 * px)), T.odf(T.addr(in[u], 3 * px + 1)), T.odf(T.addr(in[u], 3 * px + 2)), c1f, c2f);
-                        o0 = f2ord(c1f); o1 = f2ord(c2f);
-                    }
-                    if (!have) continue;
-                    if (NEXT_ABOVE) {
-                        if (o0 > a.above[0]) best0 = min(best0, o0);
-                        if (o1 > a.above[1]) best1 = min(best1, o1);
-                    } else if (LOW16) {
-                        if ((o0 >> 16) == p0) atomicAdd(&hist[o0 & 0xffffu], 1ull);
-                        if ((o1 >> 16) == p1) atomicAdd(&hist[65536u + (o1 & 0xffffu)], 1ull);
-                    } else if (WINDOW) {
-                        const uint32_t d0 = o0 - a.window_lo[0], d1 = o1 - a.window_lo[1];
-                        nb0 += o0 < a.window_lo[0] ? 1u : 0u;
-                        nb1 += o1 < a.window_lo[1] ? 1u : 0u;
-                        if (o0 >= a.window_lo[0] && d0 < 65536u) atomicAdd(&hist[d0], 1ull);
-                        if (o1 >= a.window_lo[1] && d1 < 65536u) atomicAdd(&hist[65536u + d1], 1ull);
-                    } else {
-                        if (all || (o0 >> hs) == p0) r0.add(s_hist[0], (o0 >> sh) & 255u);
-                        if (all || (o1 >> hs) == p1) r1.add(s_hist[1], (o1 >> sh) & 255u);
-                    }
+            for (int j = 0; j < 4; ++j) {
+                const int item = it0 + j * (int)gridDim.x;
+                ok[j] = item < a.n_items;                                       // workgroup-uniform
+                ccs[j] = 0; c1s[j] = 0;
+                if (ok[j]) {
+                    const int tile = item / a.parts, part = item % a.parts;
+                    int c0, c1;
+                    part_range((a.P + 3) >> 2, a.parts, part, c0, c1);
+                    const int r0 = c0 >> 6;
+                    const int row = r0 + ((item - r0) & 63) + wave * 64;        // rows with (row ^ item) & 63 == 0
+                    ok[j] = row * 64 < c1;                                      // wave-uniform
+                    ccs[j] = row * 64 + lane; c1s[j] = c1;
+                    if (ok[j]) ch[j] = load_chunk_clamped<ALIGNED>(a.rgb + (size_t)tile * nbytes, nbytes, ccs[j], c1);
                 }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (ok[j]) process(ch[j], ccs[j], c1s[j]);
+        }
+    } else {
+        for (int item = blockIdx.x; item < a.n_items; item += gridDim.x) {
+            const int tile = item / a.parts, part = item % a.parts;
+            const uint8_t* src = a.rgb + (size_t)tile * nbytes;
+            int c0, c1;
+            part_range((a.P + 3) >> 2, a.parts, part, c0, c1);
+            if (a.sample_mask == 0u) {
+                // every pixel: the next trip's two chunks are requested before this trip's arithmetic
+                if (c0 >= c1) continue;
+                Chunk nxt[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) nxt[u] = load_chunk_clamped<ALIGNED>(src, nbytes, c0 + tid + u * kSweepThreads, c1);
+                for (int c = c0 + tid; c < c1; c += kSweepThreads * 2) {
+                    Chunk in[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        in[u] = nxt[u];
+                        nxt[u] = load_chunk_clamped<ALIGNED>(src, nbytes, c + (2 + u) * kSweepThreads, c1);
+                    }
+                    process(in[0], c, c1);
+                    process(in[1], c + kSweepThreads, c1);
+                }
+                continue;
+            }
+            for (int c = c0 + tid; c < c1; c += kSweepThreads * 2) {
+                // sampling (wave-uniform: c0 and the wave's first chunk are multiples of 64)
+                const bool take0 = ((((uint32_t)c >> 6) ^ (uint32_t)item) & a.sample_mask) == 0u;
+                const bool take1 = (((((uint32_t)c + kSweepThreads) >> 6) ^ (uint32_t)item) & a.sample_mask) == 0u;
+                if (!(take0 | take1)) continue;
+                Chunk in[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) in[u] = load_chunk_clamped<ALIGNED>(src, nbytes, c + u * kSweepThreads, c1);
+                if (take0) process(in[0], c, c1);
+                if (take1) process(in[1], c + kSweepThreads, c1);
             }
         }
     }
