@@ -39,6 +39,8 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 def _world(group=None):
+    if group is False:           # "this process only": no collective even when a process group exists
+        return 0, 1
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(group), dist.get_world_size(group)
     return 0, 1
