@@ -33,11 +33,15 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
         base[0] = 255                                 # an empty tile
     rgb = base[torch.arange(n, device="cuda") % base.shape[0]].contiguous()
     res = []
+    extra = {}
+    if rng.rand() < 0.4:                              # non-default parameters of the reference's extractors
+        extra = dict(luminosity_threshold=float(rng.uniform(0.55, 0.95)), angular_percentile=float(rng.choice([90.0, 95.0, 99.0, 99.9])),
+                     lasso_lambda=float(rng.choice([0.0, 0.01, 0.1])))
     for sched in (1, 2):
         if METHOD == "vahadane":
-            out, M, mc, st = engine.vahadane_transform(rgb, Mt[0], mct[0], params=engine.make_params(schedule=sched, dl_tol=1e-10))
+            out, M, mc, st = engine.vahadane_transform(rgb, Mt[0], mct[0], params=engine.make_params(schedule=sched, dl_tol=1e-10, **{k: v for k, v in extra.items() if k != 'angular_percentile'}))
         else:
-            out, M, mc, st = engine.macenko_transform(rgb, Mt[0], mct[0], params=engine.make_params(schedule=sched))
+            out, M, mc, st = engine.macenko_transform(rgb, Mt[0], mct[0], params=engine.make_params(schedule=sched, **extra))
         res.append((out.clone(), M.clone(), mc.clone(), st.clone()))
     (o1, M1, c1, s1), (o2, M2, c2, s2) = res
     ok = torch.equal(s1, s2)
@@ -50,6 +54,6 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     ok = ok and dM < tolM and dc < (1e-5 if METHOD == "vahadane" else 1e-9) and int(d.max()) <= 1 and rate < (2e-3 if METHOD == "vahadane" else 1e-4)
     bad += not ok
     print(f"case {case:3d} n={n:4d} {h:4d}x{w:4d} kind={kind:.2f} status_equal={torch.equal(s1, s2)} nfail={int((s1 != 0).sum())} dM={dM:.1e} dmaxC={dc:.1e} "
-          f"u8 mismatch={rate:.1e} max={int(d.max())} {'OK' if ok else 'MISMATCH'}", flush=True)
+          f"u8 mismatch={rate:.1e} max={int(d.max())} {'params ' if extra else ''}{'OK' if ok else 'MISMATCH'}", flush=True)
 print("mismatching cases:", bad)
 sys.exit(1 if bad else 0)
