@@ -32,6 +32,24 @@ class TilePipeline:
         self.e_in = [torch.cuda.Event() for _ in range(depth)]    # H2D of slot done
         self.e_run = [torch.cuda.Event() for _ in range(depth)]   # kernels of slot done
         self.e_out = [torch.cuda.Event() for _ in range(depth)]   # D2H of slot done
+        self.copy_threads = 16                                # host threads staging pageable input into pinned memory
+        self._pool = None
+
+    def _host_copy(self, dst: torch.Tensor, b) -> None:
+        """pageable batch -> pinned slot.  A single-threaded memcpy moves ~8 GB/s, a sixth of what the link takes:
+        the batch is copied in slices by a few threads (numpy releases the GIL for large copies)."""
+        src = np.ascontiguousarray(b) if isinstance(b, np.ndarray) else b.contiguous().numpy()
+        out = dst.numpy()
+        n = src.shape[0]
+        k = min(self.copy_threads, n)
+        if k <= 1 or src.nbytes < (1 << 24):
+            np.copyto(out, src)
+            return
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=self.copy_threads)
+        bounds = [n * i // k for i in range(k + 1)]
+        list(self._pool.map(lambda i: np.copyto(out[bounds[i]:bounds[i + 1]], src[bounds[i]:bounds[i + 1]]), range(k)))
 
     def run(self, batches: Iterable[np.ndarray]) -> Iterator[np.ndarray]:
         """Yields one normalised uint8 array per input batch, in order.  A short last batch is allowed; a batch
@@ -47,8 +65,8 @@ class TilePipeline:
             n = b.shape[0]
             if isinstance(b, torch.Tensor) and b.is_pinned():
                 src = b                                       # producer already wrote pinned memory: no staging copy
-            else:                                             # pageable input: one host memcpy into the pinned slot
-                self.h_in[slot][:n].copy_(torch.from_numpy(np.ascontiguousarray(b)) if isinstance(b, np.ndarray) else b)
+            else:                                             # pageable input: one host copy into the pinned slot
+                self._host_copy(self.h_in[slot][:n], b)
                 src = self.h_in[slot][:n]
             with torch.cuda.stream(self.s_h2d):
                 self.s_h2d.wait_event(self.e_run[slot])       # previous kernels reading d_in[slot] are done
