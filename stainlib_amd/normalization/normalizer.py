@@ -54,10 +54,22 @@ class ExtractiveStainNormalizer(object):
         M, maxC, status, _ = engine.vahadane_fit(tiles)
         return M, maxC, status
 
+    def _target_on(self, device):
+        """The 8 target doubles as device tensors, uploaded once per fit: as numpy arguments they are a small pageable
+        copy per call, which queues behind any large upload in flight (see pipeline.py)."""
+        import torch
+        key = (str(device), id(self.stain_matrix_target), id(self.maxC_target))
+        if getattr(self, "_target_dev_key", None) != key:
+            self._target_dev = (torch.as_tensor(np.asarray(self.stain_matrix_target, dtype=np.float64), device=device).reshape(2, 3).contiguous(),
+                                torch.as_tensor(np.asarray(self.maxC_target, dtype=np.float64), device=device).reshape(2).contiguous())
+            self._target_dev_key = key
+        return self._target_dev
+
     def _transform_tiles(self, tiles, out=None):
         from .. import engine
         fn = engine.macenko_transform if self.method == "macenko" else engine.vahadane_transform
-        return fn(tiles, self.stain_matrix_target, self.maxC_target.reshape(2), out=out)
+        M_t, c_t = self._target_on(tiles.device)
+        return fn(tiles, M_t, c_t, out=out)
 
     def _big_image_statistics(self, dev):
         """(M (2,3), maxC (2,)) of one large image through the pooled statistics, or None when that path does not apply
