@@ -58,7 +58,8 @@ class ExtractiveStainNormalizer(object):
         """The 8 target doubles as device tensors, uploaded once per fit: as numpy arguments they are a small pageable
         copy per call, which queues behind any large upload in flight (see pipeline.py)."""
         import torch
-        key = (str(device), id(self.stain_matrix_target), id(self.maxC_target))
+        key = (str(device), np.asarray(self.stain_matrix_target, dtype=np.float64).tobytes(),
+               np.asarray(self.maxC_target, dtype=np.float64).tobytes())        # by value: the attributes are public
         if getattr(self, "_target_dev_key", None) != key:
             self._target_dev = (torch.as_tensor(np.asarray(self.stain_matrix_target, dtype=np.float64), device=device).reshape(2, 3).contiguous(),
                                 torch.as_tensor(np.asarray(self.maxC_target, dtype=np.float64), device=device).reshape(2).contiguous())
