@@ -658,7 +658,7 @@ struct HalfGather { TabEntry e[6]; };
 // n_tissue is wave-uniform (a scalar popcount per pixel row).  Per pixel: 4 slow-pipe + 9 binary64 + 3 fast-pipe
 // instructions.  The LDS gathers run one stage (two pixels) ahead of the arithmetic: a wave has only three
 // partners on its SIMD to hide the ~100-cycle gather latency, so it must overlap its own.
-template <bool ALIGNED, int kTrip, class TR>
+template <bool ALIGNED, int kTrip, class TR, bool STREAM = false>
 __device__ __forceinline__ void moments_sweep(const uint8_t* src, int P, int c0, int c1, int t, int nthreads,
                                               const TR& T, float ylimf, int stride_log2, uint32_t* samp,
                                               Moments& mo, uint32_t& n_tissue) {
@@ -666,7 +666,7 @@ __device__ __forceinline__ void moments_sweep(const uint8_t* src, int P, int c0,
     const int lane = t & 63;
     const int cps_log2 = stride_log2 - 2;          // chunks per sampling block
     const int w0 = __builtin_amdgcn_readfirstlane(c0 + (t & ~63));
-    auto fetch = [&](int cc) { return load_chunk_clamped<ALIGNED>(src, nbytes, cc, c1); };   // dead lanes: see `live`
+    auto fetch = [&](int cc) { return load_chunk_clamped<ALIGNED, STREAM>(src, nbytes, cc, c1); };   // dead lanes: see `live`
     auto gather = [&](const Chunk& ch, int half) {
         HalfGather g;
 #pragma unroll
@@ -745,7 +745,7 @@ template <int STAGE> struct SelGather;
 template <> struct SelGather<kStageAngle> { float2 v[12]; };      // {gamma, od32} per byte
 template <> struct SelGather<kStageConc> { float v[12]; };        // od32 per byte
 
-template <int STAGE, bool ALIGNED, int kTrip, class TR, class Sink>
+template <int STAGE, bool ALIGNED, int kTrip, bool STREAM = false, class TR, class Sink>
 __device__ __forceinline__ void select_sweep(const uint8_t* src, int P, int c0, int c1, int t, int nthreads,
                                              const TR& T, float ylimf, const SelConsts& K, Sink& sink) {
     const size_t nbytes = (size_t)P * 3;
@@ -755,7 +755,7 @@ __device__ __forceinline__ void select_sweep(const uint8_t* src, int P, int c0, 
     const bool conc_ok = (K.L.g12 >= 0.0f) & (K.lo0 > 0.0f) & (K.lo1 > 0.0f);
     const float clo0 = conc_ok ? K.lo0 : -INFINITY, clo1 = conc_ok ? K.lo1 : -INFINITY;
     const int w0 = __builtin_amdgcn_readfirstlane(c0 + (t & ~63));
-    auto fetch = [&](int cc) { return load_chunk_clamped<ALIGNED>(src, nbytes, cc, c1); };   // dead lanes: see `live`
+    auto fetch = [&](int cc) { return load_chunk_clamped<ALIGNED, STREAM>(src, nbytes, cc, c1); };   // dead lanes: see `live`
     auto gather = [&](const Chunk& ch) {
         SelGather<STAGE> g;
 #pragma unroll
@@ -1109,7 +1109,7 @@ struct ClsAcc {
 
 // classify every tissue pixel of chunks [c0,c1) under the dictionary L and accumulate the moments of classes
 // both / only-1 / only-2; n_tissue (wave-uniform) counts all tissue pixels.  c0 must be a multiple of 64.
-template <bool ALIGNED, bool SAMPLE>
+template <bool ALIGNED, bool SAMPLE, bool STREAM = false>
 __device__ __forceinline__ void dict_sweep(const uint8_t* src, int P, int c0, int c1, int t, int nthreads, const TabReader& T,
                                            float ylimf, int stride_log2, const LassoK64& L, uint32_t* samp,
                                            ClsAcc (&acc)[3], uint32_t& n_tissue) {
@@ -1122,7 +1122,7 @@ __device__ __forceinline__ void dict_sweep(const uint8_t* src, int P, int c0, in
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int cc = cb + lane + u * nthreads;
-            in[u] = load_chunk_clamped<ALIGNED>(src, nbytes, cc, c1);
+            in[u] = load_chunk_clamped<ALIGNED, STREAM>(src, nbytes, cc, c1);
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -1452,7 +1452,7 @@ __device__ __forceinline__ bool dict_advance(DictIter& it, DictProgress& pr, dou
 // a sweep), then full sweeps from that warm start until the dictionary moves by less than tol: ~4 full sweeps instead
 // of ~9.  T must be a layout-A reader; red/sum are workgroup scratch.  Ends with a barrier.  SAMPLE_ONLY: only the
 // sample stage (the per-phase schedule runs the full sweeps as launches of their own).
-template <bool ALIGNED, int NT, bool SAMPLE_ONLY = false>
+template <bool ALIGNED, int NT, bool SAMPLE_ONLY = false, bool STREAM = false>
 __device__ __forceinline__ void dict_learn(const uint8_t* src, int P, int nch, int tid, const TabReader& T, float ylimf,
                                            int stride_log2, uint32_t* samp, int n_sample, double lam, double tol, int max_sweeps,
                                            DictIter& it, double (*red)[32], double* sum, DictProgress& pr) {
@@ -1464,11 +1464,11 @@ __device__ __forceinline__ void dict_learn(const uint8_t* src, int P, int nch, i
         ClsAcc acc[3];
         uint32_t n_tissue = 0;
         if (!SAMPLE_ONLY && pr.stage == 0)
-            dict_sweep<ALIGNED, true>(src, P, 0, nch, tid, NT, T, ylimf, stride_log2, Ld, samp, acc, n_tissue);
+            dict_sweep<ALIGNED, true, STREAM>(src, P, 0, nch, tid, NT, T, ylimf, stride_log2, Ld, samp, acc, n_tissue);
         else if (SAMPLE_ONLY || pr.stage == 1)
             dict_sweep_sample(samp, n_sample, stride_log2, P, tid, NT, T, ylimf, Ld, acc, n_tissue);
         else
-            dict_sweep<ALIGNED, false>(src, P, 0, nch, tid, NT, T, ylimf, stride_log2, Ld, samp, acc, n_tissue);
+            dict_sweep<ALIGNED, false, STREAM>(src, P, 0, nch, tid, NT, T, ylimf, stride_log2, Ld, samp, acc, n_tissue);
         double v[31];
         acc[0].to_array(v); acc[1].to_array(v + 10); acc[2].to_array(v + 20);
         v[30] = lane == 0 ? (double)n_tissue : 0.0;      // n_tissue is wave-uniform
@@ -1983,11 +1983,13 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
     float* cand1 = a.cand + ((size_t)blockIdx.x * 2 + 1) * a.cap_list;
 
     // sweeps 2/3 share this: classify against sh.lo/hi with constants K; plain count and raw candidates into sh.*
+    const bool stream = (size_t)a.P * 3 >= kStreamBytes;       // non-temporal tile accesses (uniform; see kStreamBytes)
     auto run_select = [&](auto stage_tag, const uint8_t* src, SelConsts& K) {
         constexpr int STAGE = decltype(stage_tag)::value;
         K.lo0 = uni(sh.lo[0]); K.hi0 = uni(sh.hi[0]); K.lo1 = uni(sh.lo[1]); K.hi1 = uni(sh.hi[1]);
         RawSink sink{lds_address(sh.stage[wave]), 0u, rawl, &sh.n_raw, &sh.overflow, (uint32_t)a.cap_raw};
-        select_sweep<STAGE, ALIGNED, kFusedTrip>(src, a.P, 0, nch, tid, NT, TB, a.ylimf, K, sink);
+        if (stream) select_sweep<STAGE, ALIGNED, kFusedTrip, true>(src, a.P, 0, nch, tid, NT, TB, a.ylimf, K, sink);
+        else select_sweep<STAGE, ALIGNED, kFusedTrip, false>(src, a.P, 0, nch, tid, NT, TB, a.ylimf, K, sink);
         sink.flush(lane);
         __threadfence_block();
         __syncthreads();
@@ -2017,7 +2019,8 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
             {
                 Moments mo;
                 uint32_t n_tissue = 0;
-                moments_sweep<ALIGNED, kFusedTrip>(src, a.P, 0, nch, tid, NT, T, a.ylimf, a.stride_log2, samp, mo, n_tissue);
+                if (stream) moments_sweep<ALIGNED, kFusedTrip, TabReader, true>(src, a.P, 0, nch, tid, NT, T, a.ylimf, a.stride_log2, samp, mo, n_tissue);
+                else moments_sweep<ALIGNED, kFusedTrip, TabReader, false>(src, a.P, 0, nch, tid, NT, T, a.ylimf, a.stride_log2, samp, mo, n_tissue);
                 double v[10];
                 mo.to_array(v, n_tissue, lane);
 #pragma unroll
@@ -2106,8 +2109,10 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
             }
             __syncthreads();
             DictProgress pr{0, 0, 0, 0};
-            dict_learn<ALIGNED, NT>(src, a.P, nch, tid, T, a.ylimf, a.stride_log2, samp, a.n_sample, a.dl_lambda, a.dl_tol,
-                                    a.dl_max_sweeps, sh.it, sh.red, sh.sum, pr);
+            if (stream) dict_learn<ALIGNED, NT, false, true>(src, a.P, nch, tid, T, a.ylimf, a.stride_log2, samp, a.n_sample, a.dl_lambda,
+                                                             a.dl_tol, a.dl_max_sweeps, sh.it, sh.red, sh.sum, pr);
+            else dict_learn<ALIGNED, NT, false, false>(src, a.P, nch, tid, T, a.ylimf, a.stride_log2, samp, a.n_sample, a.dl_lambda,
+                                                       a.dl_tol, a.dl_max_sweeps, sh.it, sh.red, sh.sum, pr);
             sweeps_used = pr.sweeps_used;
             if (tid == 0) {
                 sh.status = sh.it.status;
@@ -2197,8 +2202,13 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
             } else {
                 ApplyK K;
                 apply_consts(sh.M, sh.maxC, a.M_tgt, a.maxC_tgt, a.lam, K);
-                if (K.fast) apply_sweep<ALIGNED, true>(src, dst, a.P, 0, nch, tid, NT, TB, K);
-                else apply_sweep<ALIGNED, false>(src, dst, a.P, 0, nch, tid, NT, TB, K);
+                if (stream) {
+                    if (K.fast) apply_sweep<ALIGNED, true, TabReaderB, true>(src, dst, a.P, 0, nch, tid, NT, TB, K);
+                    else apply_sweep<ALIGNED, false, TabReaderB, true>(src, dst, a.P, 0, nch, tid, NT, TB, K);
+                } else {
+                    if (K.fast) apply_sweep<ALIGNED, true, TabReaderB, false>(src, dst, a.P, 0, nch, tid, NT, TB, K);
+                    else apply_sweep<ALIGNED, false, TabReaderB, false>(src, dst, a.P, 0, nch, tid, NT, TB, K);
+                }
             }
         }
         __syncthreads();     // sh.* is reused by the next tile
