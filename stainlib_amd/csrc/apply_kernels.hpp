@@ -275,7 +275,7 @@ static __global__ __launch_bounds__(kWG) void k_apply(const uint8_t* __restrict_
     }
 
     // software pipeline: the next trip's chunks are requested before this trip's arithmetic (measured +5 %)
-    auto fetch = [&](int cc) { return load_chunk_clamped<ALIGNED>(src, nbytes, cc, c1); };
+    auto fetch = [&](int cc) { return load_chunk_clamped<ALIGNED, true>(src, nbytes, cc, c1); };    // single pass: non-temporal
     auto sweep = [&](auto fast_tag) {
         constexpr bool FAST = decltype(fast_tag)::value;
         Chunk nxt[kUApply];
@@ -309,7 +309,7 @@ static __global__ __launch_bounds__(kWG) void k_apply(const uint8_t* __restrict_
                     }
                 }
                 const Chunk o = FAST ? pack_trunc_fast(t) : pack_trunc_general(t);
-                if (cc < c1) store_chunk<ALIGNED>(dst, nbytes, cc, o);
+                if (cc < c1) store_chunk<ALIGNED, true>(dst, nbytes, cc, o);
             }
         }
     };
@@ -331,7 +331,7 @@ __device__ __forceinline__ void augment_sweep(const uint8_t* src, uint8_t* dst, 
                                               const TR& T, const AugmentK& K) {
     const size_t nbytes = (size_t)P * 3;
     struct G { float2 v[12]; };
-    auto fetch = [&](int cc) { return load_chunk_clamped<ALIGNED>(src, nbytes, cc, c1); };
+    auto fetch = [&](int cc) { return load_chunk_clamped<ALIGNED, true>(src, nbytes, cc, c1); };
     auto gather = [&](const Chunk& ch) {
         G g;
 #pragma unroll
@@ -366,7 +366,7 @@ __device__ __forceinline__ void augment_sweep(const uint8_t* src, uint8_t* dst, 
             for (int ch = 0; ch < 3; ++ch) tv[3 * px + ch] = 255.0f * __builtin_amdgcn_exp2f(fmaf(a1, K.q[0][ch], a2 * K.q[1][ch]));
         }
         const Chunk o = pack_trunc_fast(tv);        // values are >= 0; > 255 saturates = np.clip(.., 0, 255)
-        if (cc < c1) store_chunk<ALIGNED>(dst, nbytes, cc, o);
+        if (cc < c1) store_chunk<ALIGNED, true>(dst, nbytes, cc, o);
     };
     constexpr int N = 2;                                       // chunks per lane and trip; the next trip is in flight
     Chunk cur[N], nx[N];

@@ -80,7 +80,7 @@ static __global__ __launch_bounds__(kWG) void k_hed(const uint8_t* __restrict__ 
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
             const int cc = c + u * kWG;
-            in[u] = load_chunk_clamped<ALIGNED>(src, nbytes, cc, c1);   // no predicated load (see load_chunk_clamped); dead lanes masked below
+            in[u] = load_chunk_clamped<ALIGNED, true>(src, nbytes, cc, c1);   // single pass: non-temporal; no predicated load (see load_chunk_clamped); dead lanes masked below
         }
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
@@ -115,7 +115,7 @@ static __global__ __launch_bounds__(kWG) void k_hed(const uint8_t* __restrict__ 
             }
             // clip [0,1], *255, astype(uint8) (augmenter.py:320-325): max(min(255 x, 255), 0) truncated = the saturating pack
             const Chunk o = pack_trunc_fast(tv);
-            if (cc < c1) store_chunk<ALIGNED>(dst, nbytes, cc, o);
+            if (cc < c1) store_chunk<ALIGNED, true>(dst, nbytes, cc, o);
         }
     }
     unsigned long long ws = wave_sum((unsigned long long)bsum);
