@@ -1518,7 +1518,10 @@ static __global__ __launch_bounds__(kSweepThreads, 4) void k_moments(StatsArgs a
         part_range((a.P + 3) >> 2, a.parts, part, c0, c1);
         Moments mo;
         uint32_t n_tissue = 0;
-        moments_sweep<ALIGNED, kPhaseTrip>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, a.stride_log2, samp, mo, n_tissue);
+        if ((size_t)a.P * 3 >= kStreamBytes)      // uniform: non-temporal tile loads for big tiles (see kStreamBytes)
+            moments_sweep<ALIGNED, kPhaseTrip, TabReader, true>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, a.stride_log2, samp, mo, n_tissue);
+        else
+            moments_sweep<ALIGNED, kPhaseTrip, TabReader, false>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, a.stride_log2, samp, mo, n_tissue);
         double v[10];
         mo.to_array(v, n_tissue, lane);
 #pragma unroll
@@ -1640,7 +1643,8 @@ static __global__ __launch_bounds__(kSweepThreads, 4) void k_select(StatsArgs a)
         int c0, c1;
         part_range((a.P + 3) >> 2, a.parts, part, c0, c1);
         RawSink sink{lds_address(s_stage[wave]), 0u, a.raw + (size_t)tile * a.cap_raw, &st.n_raw, &st.overflow, (uint32_t)a.cap_raw};
-        select_sweep<STAGE, ALIGNED, kPhaseTrip>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, K, sink);
+        if ((size_t)a.P * 3 >= kStreamBytes) select_sweep<STAGE, ALIGNED, kPhaseTrip, true>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, K, sink);
+        else select_sweep<STAGE, ALIGNED, kPhaseTrip, false>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, K, sink);
         sink.flush(lane);
     }
 }
@@ -1806,7 +1810,8 @@ static __global__ __launch_bounds__(kSweepThreads, 4) void k_dict(StatsArgs a) {
         part_range((a.P + 3) >> 2, a.parts, part, c0, c1);
         ClsAcc acc[3];
         uint32_t n_tissue = 0;
-        dict_sweep<ALIGNED, FIRST>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, a.stride_log2, Ld, samp, acc, n_tissue);
+        if ((size_t)a.P * 3 >= kStreamBytes) dict_sweep<ALIGNED, FIRST, true>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, a.stride_log2, Ld, samp, acc, n_tissue);
+        else dict_sweep<ALIGNED, FIRST, false>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, a.stride_log2, Ld, samp, acc, n_tissue);
         double v[31];
         acc[0].to_array(v); acc[1].to_array(v + 10); acc[2].to_array(v + 20);
         v[30] = lane == 0 ? (double)n_tissue : 0.0;
