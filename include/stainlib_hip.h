@@ -42,7 +42,8 @@ extern "C" {
 /* per-tile status[i] */
 #define SL_TILE_OK 0
 #define SL_TILE_EMPTY_MASK 1     /* stain_utils.py:46-47 -> TissueMaskException */
-#define SL_TILE_DEGENERATE_COV 2 /* fewer than 2 tissue pixels: np.cov is NaN in the reference */
+#define SL_TILE_DEGENERATE_COV 2 /* fewer than 2 tissue pixels (np.cov is NaN in the reference), or tissue of a single colour:
+                                    two parallel stain vectors, inf/NaN concentrations in the reference */
 #define SL_TILE_ZERO_MAXC 3      /* 99th percentile of a concentration is 0: normalizer.py:48 divides by it */
 
 /* ops for sl_workspace_bytes */

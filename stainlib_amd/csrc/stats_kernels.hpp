@@ -587,6 +587,25 @@ __device__ __forceinline__ int eigvecs_from_moments(const double* sum, double* V
     if (w1 > w2) SL_SWAP_COL(w1, w2, v1, v2);
     if (w0 > w1) SL_SWAP_COL(w0, w1, v0, v1);
 #undef SL_SWAP_COL
+    // Rank-deficient covariance (tissue of one or two distinct colours): the eigenvectors of the null space are whatever
+    // round-off makes them -- in numpy as much as here -- and the two kernel schedules, which sum the moments in different
+    // orders, would disagree completely.  Pick them canonically instead (the outputs stay finite like the reference's,
+    // and are reproducible): no spread at all -> the first two axes; a line -> the unit vector orthogonal to it that is
+    // closest to the coordinate axis the line is least aligned with.
+    if (status == SL_TILE_OK) {
+        const double scale = (sum[4] + sum[7] + sum[9]) / n;            // mean squared optical density: the round-off floor of cov is ~1e-15 of it
+        if (!(w2 > 1e-12 * scale)) {
+            v2[0] = 1; v2[1] = 0; v2[2] = 0; v1[0] = 0; v1[1] = 1; v1[2] = 0;
+        } else if (!(w1 > 1e-12 * scale)) {
+            int ax = 0;
+            if (fabs(v2[1]) < fabs(v2[ax])) ax = 1;
+            if (fabs(v2[2]) < fabs(v2[ax])) ax = 2;
+            double u[3] = {-v2[ax] * v2[0], -v2[ax] * v2[1], -v2[ax] * v2[2]};
+            u[ax] += 1.0;
+            const double nu = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+            for (int i = 0; i < 3; ++i) v1[i] = u[i] / nu;
+        }
+    }
     const double s2 = v2[0] < 0 ? -1.0 : 1.0, s1 = v1[0] < 0 ? -1.0 : 1.0;      // :26-27
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -594,6 +613,15 @@ __device__ __forceinline__ int eigvecs_from_moments(const double* sum, double* V
         Vd[c * 2 + 1] = s1 * v1[c]; Vf[c * 2 + 1] = (float)(s1 * v1[c]);
     }
     return status;
+}
+
+// Two (numerically) parallel stain vectors -- tissue of a single colour, or a collapsed dictionary: the Gram matrix is
+// singular, the concentrations are inf/NaN in the reference and depend on the last bit here.  Such a tile is reported as
+// degenerate (status 2, passed through unchanged) instead of producing round-off-dependent output.
+__device__ __forceinline__ bool stain_matrix_singular(const double* M) {
+    const double g11 = M[0] * M[0] + M[1] * M[1] + M[2] * M[2], g22 = M[3] * M[3] + M[4] * M[4] + M[5] * M[5];
+    const double g12 = M[0] * M[3] + M[1] * M[4] + M[2] * M[5];
+    return !(g11 * g22 - g12 * g12 > 1e-8 * g11 * g22);
 }
 
 // pseudo-angle order statistics -> stain matrix (macenko_stain_extractor.py:33-44)
@@ -1693,14 +1721,18 @@ static __global__ __launch_bounds__(kFinishThreads) void k_finish_angle(StatsArg
     if (tid == 0) {
         double M[6];
         stain_matrix_from_angles(st.Vd, s_res, gfrac, M);
-        for (int i = 0; i < 6; ++i) st.M[i] = M[i];
+        const bool singular = stain_matrix_singular(M);
+        if (singular) st.status = SL_TILE_DEGENERATE_COV;
+        for (int i = 0; i < 6; ++i) st.M[i] = singular ? nan_d() : M[i];
         st.fallbacks += fallbacks;
         LassoK L;
         lasso_consts(M, a.lam, L);
         s_L = L;
+        s_res[0] = singular ? 1.0f : 0.0f;
         st.n_raw = 0; st.overflow = 0;
     }
     __syncthreads();
+    if (s_res[0] != 0.0f) return;                        // block-uniform: the concentration stage skips this tile
     SampleConcKey ckey;
     ckey.sample = a.sample + (size_t)tile * a.n_sample;
     ckey.tab = view_of(s_tab);
@@ -1831,8 +1863,11 @@ static __global__ __launch_bounds__(kSweepThreads, 4) void k_dict(StatsArgs a) {
 
 __device__ __forceinline__ void dict_finalize(const DictIter& it, TileState& st) {
     st.status = it.status;
-    if (it.status == SL_TILE_OK) dict_iter_stain_matrix(it, st.M);
-    else for (int i = 0; i < 6; ++i) st.M[i] = nan_d();
+    if (it.status == SL_TILE_OK) {
+        dict_iter_stain_matrix(it, st.M);
+        if (stain_matrix_singular(st.M)) st.status = SL_TILE_DEGENERATE_COV;
+    }
+    if (st.status != SL_TILE_OK) for (int i = 0; i < 6; ++i) st.M[i] = nan_d();
 }
 
 static __global__ __launch_bounds__(kFinishThreads) void k_dict_finish(StatsArgs a, int first) {
@@ -2103,6 +2138,7 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
                     double M[6];
                     stain_matrix_from_angles(sh.Vd, sh.res, gfrac, M);
                     for (int i = 0; i < 6; ++i) sh.M[i] = M[i];
+                    if (stain_matrix_singular(M)) sh.status = SL_TILE_DEGENERATE_COV;
                 }
                 SL_SUB(6);
             }
@@ -2121,7 +2157,10 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
             sweeps_used = pr.sweeps_used;
             if (tid == 0) {
                 sh.status = sh.it.status;
-                if (sh.status == SL_TILE_OK) dict_iter_stain_matrix(sh.it, sh.M);
+                if (sh.status == SL_TILE_OK) {
+                    dict_iter_stain_matrix(sh.it, sh.M);
+                    if (stain_matrix_singular(sh.M)) sh.status = SL_TILE_DEGENERATE_COV;
+                }
             }
             sh.tab.fill_b();                 // the dictionary sweeps are over: layout B from here on
         }

@@ -39,8 +39,9 @@ def raise_for_status(status: int) -> None:
     if status == _ffi.TILE_EMPTY_MASK:
         raise TissueMaskException("Empty tissue mask computed")          # stain_utils.py:47
     if status == _ffi.TILE_DEGENERATE_COV:
-        # the reference computes np.cov of a single row (NaN) and fails inside eigh
-        raise np.linalg.LinAlgError("fewer than two tissue pixels: covariance undefined")
+        # fewer than two tissue pixels: the reference computes np.cov of a single row (NaN) and fails inside eigh.
+        # tissue of a single colour: its two stain vectors coincide and its concentrations are inf/NaN; reported too
+        raise np.linalg.LinAlgError("degenerate tile: fewer than two tissue pixels, or tissue of a single colour (singular stain matrix)")
 
 
 class ABCStainExtractor(ABC):

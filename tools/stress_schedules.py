@@ -53,6 +53,11 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     tolM = 1e-7 if METHOD == "vahadane" else 1e-9      # Vahadane: both stop within dl_tol of the same fixed point
     ok = ok and dM < tolM and dc < (1e-5 if METHOD == "vahadane" else 1e-9) and int(d.max()) <= 1 and rate < (2e-3 if METHOD == "vahadane" else 1e-4)
     bad += not ok
+    if not ok:                                        # keep the input: the contents are drawn afresh on every run
+        import os
+        os.makedirs("gpurun_out", exist_ok=True)
+        np.savez_compressed(f"gpurun_out/stress_mismatch_{METHOD}_{case}.npz", base=base.cpu().numpy(), n=n, extra=str(extra),
+                            M1=M1.cpu().numpy(), M2=M2.cpu().numpy(), s1=s1.cpu().numpy(), s2=s2.cpu().numpy())
     print(f"case {case:3d} n={n:4d} {h:4d}x{w:4d} kind={kind:.2f} status_equal={torch.equal(s1, s2)} nfail={int((s1 != 0).sum())} dM={dM:.1e} dmaxC={dc:.1e} "
           f"u8 mismatch={rate:.1e} max={int(d.max())} {'params ' if extra else ''}{'OK' if ok else 'MISMATCH'}", flush=True)
 print("mismatching cases:", bad)
