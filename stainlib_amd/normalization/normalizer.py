@@ -85,6 +85,9 @@ class ExtractiveStainNormalizer(object):
             return None
         if not (np.isfinite(M).all() and np.isfinite(maxC).all() and (maxC > 0).all()):
             return None
+        G = M @ M.T
+        if not (G[0, 0] * G[1, 1] - G[0, 1] ** 2 > 1e-8 * G[0, 0] * G[1, 1]):     # parallel stain vectors: the per-tile path reports it (status 2)
+            return None
         return M, maxC
 
     # -- reference API -----------------------------------------------------------------------------
