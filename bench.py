@@ -145,6 +145,7 @@ def main():
 
     from oracle import stain_oracle as so
     from stainlib_amd import _ffi, engine
+    from tools.synth import synth_tiles
 
     backend = os.environ.get("SL_BENCH_BACKEND", "nccl")      # "gloo" only for single-GPU dry runs of the N>1 logic
     dev_index = local_rank % max(torch.cuda.device_count(), 1)
@@ -167,10 +168,10 @@ def main():
     h = w = a.size
     P = h * w
     B = a.tiles
-    rgb = engine.synth_tiles(B, h, w, seed=1000 * rank + 7, device=dev)
+    rgb = synth_tiles(B, h, w, seed=1000 * rank + 7, device=dev)
     out = torch.empty_like(rgb)
     # fit once, outside the timed region: target tile with the target stain matrix
-    tgt = engine.synth_tiles(1, h, w, seed=1, device=dev, M_true=so.M_TRUE_TGT.tolist())
+    tgt = synth_tiles(1, h, w, seed=1, device=dev, M_true=so.M_TRUE_TGT.tolist())
     Mt, mct, st = engine.macenko_fit(tgt)
     assert int(st[0]) == 0
     Mt, mct = Mt[0].contiguous(), mct[0].contiguous()

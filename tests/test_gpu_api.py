@@ -219,8 +219,8 @@ def test_pooled_slide_mode_matches_reference_on_concatenated_tiles():
     assert stats2.last_path == ["radix", "radix"]
     assert np.array_equal(M_rad, M_got) and np.array_equal(maxC_rad, maxC_got)
     # a larger slide, where the sample really is a sample (1 row in 4): still the window path, same keys as the rounds
-    from stainlib_amd import engine
-    big = engine.synth_tiles(40, 512, 512, seed=9)
+    from tools.synth import synth_tiles
+    big = synth_tiles(40, 512, 512, seed=9)
     s3, s4 = PooledSlideStatistics(), PooledSlideStatistics()
     M3, c3 = s3(big)
     sd.window_rank_pairs = lambda *a, **k: None

@@ -7,10 +7,11 @@ import torch
 
 sys.path.insert(0, ".")
 from stainlib_amd import engine  # noqa: E402
+from tools.synth import synth_tiles  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 h = w = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
-rgb = engine.synth_tiles(n, h, w, seed=1)
+rgb = synth_tiles(n, h, w, seed=1)
 M = torch.tensor([[0.626, 0.727, 0.283], [0.106, 0.987, 0.122]], dtype=torch.float64, device="cuda")
 M = (M / M.norm(dim=1, keepdim=True)).expand(n, 2, 3).contiguous()
 mc = torch.tensor([1.9, 1.5], dtype=torch.float64, device="cuda").expand(n, 2).contiguous()

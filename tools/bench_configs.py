@@ -13,6 +13,7 @@ import torch
 sys.path.insert(0, ".")
 import stainlib_amd as sl  # noqa: E402
 from stainlib_amd import engine  # noqa: E402
+from tools.synth import synth_tiles  # noqa: E402
 from stainlib_amd.distributed import SlideNormalizer  # noqa: E402
 
 
@@ -28,10 +29,10 @@ def timeit(fn, reps=5, warm=2):
 
 
 res = {}
-tgt = engine.synth_tiles(1, 1024, 1024, seed=1, M_true=[[0.55, 0.75, 0.35], [0.10, 0.95, 0.20]])
+tgt = synth_tiles(1, 1024, 1024, seed=1, M_true=[[0.55, 0.75, 0.35], [0.10, 0.95, 0.20]])
 
 # cfg3 ------------------------------------------------------------------------------------------
-rgb = engine.synth_tiles(128, 1024, 1024, seed=5)
+rgb = synth_tiles(128, 1024, 1024, seed=5)
 out = torch.empty_like(rgb)
 Mt, mct, st, sw = engine.vahadane_fit(tgt, params=engine.make_params(dl_tol=1e-6, dl_max_sweeps=100))
 p = engine.make_params(dl_tol=1e-6, dl_max_sweeps=100)
@@ -39,7 +40,7 @@ t = timeit(lambda: engine.vahadane_transform(rgb, Mt[0], mct[0], params=p, out=o
 _, _, _, sweeps = engine.vahadane_fit(rgb, params=p)
 res["cfg3_vahadane_128x1024"] = {"tiles_per_s": 128 / t, "ms": 1e3 * t, "mean_dictionary_sweeps": float(sweeps.float().mean()),
                                   "max_dictionary_sweeps": int(sweeps.max()), "tol": 1e-6}
-rgb512 = engine.synth_tiles(512, 1024, 1024, seed=6)
+rgb512 = synth_tiles(512, 1024, 1024, seed=6)
 out512 = torch.empty_like(rgb512)
 t = timeit(lambda: engine.vahadane_transform(rgb512, Mt[0], mct[0], params=p, out=out512), reps=3, warm=1)
 res["vahadane_512x1024"] = {"tiles_per_s": 512 / t, "ms": 1e3 * t}
@@ -58,7 +59,7 @@ del rgb512, out512, rgb, out
 
 # cfg4 ------------------------------------------------------------------------------------------
 N = 1250
-t5 = engine.synth_tiles(N, 512, 512, seed=7)
+t5 = synth_tiles(N, 512, 512, seed=7)
 o5 = torch.empty_like(t5)
 a = sl.HedLighterColorAugmenter()
 np.random.seed(0)

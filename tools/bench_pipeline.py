@@ -4,11 +4,12 @@ import numpy as np, torch
 sys.path.insert(0, ".")
 import stainlib_amd as sl
 from stainlib_amd import engine
+from tools.synth import synth_tiles
 from stainlib_amd.pipeline import normalizer_pipeline
 B, nb = 128, 12
 n = sl.MacenkoNormalizer()
-n.fit(engine.synth_tiles(1, 1024, 1024, seed=1, M_true=[[0.55, 0.75, 0.35], [0.10, 0.95, 0.20]])[0].cpu().numpy())
-host = engine.synth_tiles(B, 1024, 1024, seed=9).cpu().numpy()
+n.fit(synth_tiles(1, 1024, 1024, seed=1, M_true=[[0.55, 0.75, 0.35], [0.10, 0.95, 0.20]])[0].cpu().numpy())
+host = synth_tiles(B, 1024, 1024, seed=9).cpu().numpy()
 pipe = normalizer_pipeline(n, (B, 1024, 1024, 3))
 res = {}
 for name, src in (("pageable_numpy_in", host), ("pinned_in", torch.from_numpy(host).pin_memory())):

@@ -1,7 +1,8 @@
 import sys, time, torch
 sys.path.insert(0, ".")
 from stainlib_amd import engine
-big = engine.synth_tiles(128, 2048, 2048, seed=4)
+from tools.synth import synth_tiles
+big = synth_tiles(128, 2048, 2048, seed=4)
 for _ in range(2):
     M2, mc2, st2 = engine.macenko_fit(big)
 torch.cuda.synchronize(); t0 = time.time()

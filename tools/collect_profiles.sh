@@ -17,8 +17,9 @@ cat > /tmp/vah128.py <<'PY'
 import sys, torch
 sys.path.insert(0, ".")
 from stainlib_amd import engine
-rgb = engine.synth_tiles(128, 1024, 1024, seed=5)
-tgt = engine.synth_tiles(1, 1024, 1024, seed=1001)
+from tools.synth import synth_tiles
+rgb = synth_tiles(128, 1024, 1024, seed=5)
+tgt = synth_tiles(1, 1024, 1024, seed=1001)
 out = torch.empty_like(rgb)
 p = engine.make_params(dl_tol=1e-6, dl_max_sweeps=100)
 Mt, mct, _, _ = engine.vahadane_fit(tgt, params=p)

@@ -1,11 +1,12 @@
 import sys, time, torch
 sys.path.insert(0, ".")
 from stainlib_amd import engine
-tgt = engine.synth_tiles(1, 1024, 1024, seed=1, M_true=[[0.55, 0.75, 0.35], [0.10, 0.95, 0.20]])
+from tools.synth import synth_tiles
+tgt = synth_tiles(1, 1024, 1024, seed=1, M_true=[[0.55, 0.75, 0.35], [0.10, 0.95, 0.20]])
 Mt, mct, st = engine.macenko_fit(tgt)
 for size in (1024, 256):
     for n in (16, 32, 64, 128, 256, 512):
-        rgb = engine.synth_tiles(n, size, size, seed=3)
+        rgb = synth_tiles(n, size, size, seed=3)
         out = torch.empty_like(rgb)
         r = []
         for sched in (1, 2):

@@ -3,7 +3,8 @@ import numpy as np
 import torch
 sys.path.insert(0, ".")
 from stainlib_amd import engine
-rgb = engine.synth_tiles(128, 1024, 1024, seed=5)
+from tools.synth import synth_tiles
+rgb = synth_tiles(128, 1024, 1024, seed=5)
 p = engine.make_params(dl_tol=1e-6, dl_max_sweeps=100)
 M, mc, st, sw = engine.vahadane_fit(rgb, params=p)
 sw = sw.cpu().numpy()

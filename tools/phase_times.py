@@ -7,11 +7,12 @@ import torch
 
 sys.path.insert(0, ".")
 from stainlib_amd import _ffi, engine  # noqa: E402
+from tools.synth import synth_tiles  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 size = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
-rgb = engine.synth_tiles(n, size, size, seed=3)
-tgt = engine.synth_tiles(1, size, size, seed=1, M_true=[[0.55, 0.75, 0.35], [0.10, 0.95, 0.20]])
+rgb = synth_tiles(n, size, size, seed=3)
+tgt = synth_tiles(1, size, size, seed=1, M_true=[[0.55, 0.75, 0.35], [0.10, 0.95, 0.20]])
 Mt, mct, st = engine.macenko_fit(tgt)
 buf = torch.zeros((n, 8), dtype=torch.int64, device="cuda")
 lib = _ffi.lib()

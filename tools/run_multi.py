@@ -3,9 +3,10 @@ import sys
 import torch
 sys.path.insert(0, ".")
 from stainlib_amd import engine
+from tools.synth import synth_tiles
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-rgb = engine.synth_tiles(n, 1024, 1024, seed=3)
-tgt = engine.synth_tiles(1, 1024, 1024, seed=1, M_true=[[0.55, 0.75, 0.35], [0.10, 0.95, 0.20]])
+rgb = synth_tiles(n, 1024, 1024, seed=3)
+tgt = synth_tiles(1, 1024, 1024, seed=1, M_true=[[0.55, 0.75, 0.35], [0.10, 0.95, 0.20]])
 Mt, mct, st = engine.macenko_fit(tgt)
 out = torch.empty_like(rgb)
 for _ in range(3):

@@ -8,10 +8,11 @@ import torch
 
 sys.path.insert(0, ".")
 from stainlib_amd import engine  # noqa: E402
+from tools.synth import synth_tiles  # noqa: E402
 
 rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 METHOD = sys.argv[3] if len(sys.argv) > 3 else "macenko"          # "vahadane": same cross-check, dictionary tolerance
-tgt = engine.synth_tiles(1, 256, 256, seed=1, M_true=[[0.55, 0.75, 0.35], [0.10, 0.95, 0.20]])
+tgt = synth_tiles(1, 256, 256, seed=1, M_true=[[0.55, 0.75, 0.35], [0.10, 0.95, 0.20]])
 Mt, mct, _ = engine.macenko_fit(tgt)
 bad = 0
 for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
@@ -21,7 +22,7 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     n = int(rng.choice([1, 2, 3, 7, 33, 65, 130, 520, 700]))
     while n * h * w > 300e6:
         n = max(1, n // 2)
-    base = engine.synth_tiles(min(n, 9), h, w, seed=int(rng.randint(1 << 30)))
+    base = synth_tiles(min(n, 9), h, w, seed=int(rng.randint(1 << 30)))
     kind = rng.rand()
     if kind < 0.15:                                   # few distinct colours: heavy ties
         pal = base.reshape(-1, 3)[torch.randint(0, base.numel() // 3, (7,), device="cuda")]
