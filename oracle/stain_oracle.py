@@ -100,6 +100,124 @@ def y_index_threshold(luminosity_threshold: float = 0.8) -> int:
     return int(idx.max()) if idx.size else -1
 
 
+# --------------------------------------------------------------------------
+# OpenCV 8-bit Lab, all three channels and the way back
+# third-party: opencv-python 4.4.0.46; call sites stain_utils.py:62,66,152,183
+# (cv.cvtColor COLOR_RGB2LAB / COLOR_LAB2RGB on uint8 images).  Restated from
+# OpenCV's published modules/imgproc/src/color_lab.cpp: RGB2Lab_b (integer
+# tables above) and Lab2RGBinteger (LabToYF_b, abToXZ_b, sRGBInvGammaTab_b).
+# OpenCV builds these tables with its own binary32 soft-float (softfloat pow /
+# cbrt); here the power laws are evaluated in binary64 and rounded to binary32,
+# which can differ from OpenCV by one unit in isolated table entries.
+# PARITY UNPINNED like the L channel: tools/pin_cv2.py checks every function
+# below against a real cv2 over all 2^24 colours wherever OpenCV is installed.
+# --------------------------------------------------------------------------
+_f32 = np.float32
+_D65 = (0.950456, 1.0, 1.088754)
+_SRGB2XYZ = ((0.412453, 0.357580, 0.180423), (0.212671, 0.715160, 0.072169), (0.019334, 0.119193, 0.950227))
+_XYZ2SRGB = ((3.240479, -1.53715, -0.498535), (-0.969256, 1.875991, 0.041556), (0.055648, -0.204043, 1.057311))
+# RGB2Lab_b: coeffs[i][j] = cvRound((1 << lab_shift) * sRGB2XYZ[i][j] / whitePt[i])
+LAB_FWD_COEFFS = np.array([[int(np.rint(4096.0 * c / _D65[i])) for c in row] for i, row in enumerate(_SRGB2XYZ)], dtype=np.int64)
+# Lab2RGBinteger: coeffs[i][j] = cvRound((1 << lab_shift) * XYZ2sRGB[i][j] * whitePt[j])
+LAB_INV_COEFFS = np.array([[int(np.rint(4096.0 * c * _D65[j])) for j, c in enumerate(row)] for row in _XYZ2SRGB], dtype=np.int64)
+assert LAB_FWD_COEFFS.tolist() == [[1777, 1541, 778], [871, 2929, 296], [73, 448, 3575]]
+assert LAB_INV_COEFFS.tolist() == [[12615, -6296, -2223], [-3773, 7684, 185], [217, -836, 4715]]
+_LAB_BASE_SHIFT = 14
+_LAB_BASE = 1 << _LAB_BASE_SHIFT
+_INV_GAMMA_SHIFT = 12
+_MIN_AB = -8145
+
+
+def _lab_to_yf_tab_b() -> np.ndarray:
+    """OpenCV ``LabToYF_b``: for L8 = 0..255 the pair (Y, f(Y)) scaled by 2^14, binary32 arithmetic."""
+    out = np.zeros((256, 2), dtype=np.int64)
+    base = _LAB_BASE
+    for i in range(256):
+        if i <= 20:                                                   # 8 * 255 / 100 == 20.4: the linear segment
+            y = np.rint(_f32(i * base * 20 * 9) / _f32(17 * 24389))
+            ify = np.rint(_f32(base) * (_f32(16) / _f32(116) + _f32(i * 5) / _f32(3 * 17 * 29)))
+        else:
+            fy = _f32(i * 100 * base) / _f32(255 * 116) + _f32(16 * base) / _f32(116)
+            ify = np.rint(fy)
+            y = np.rint(fy * fy * fy / _f32(base * base))
+        out[i] = (int(y), int(ify))
+    return out
+
+
+def _ab_to_xz_tab_b() -> np.ndarray:
+    """OpenCV ``abToXZ_b``: f^-1 on the 2^14 scale for arguments _MIN_AB .. _MIN_AB + 9 * 2^14 / 4 - 1, C integer arithmetic
+    (division truncates toward zero)."""
+    n = _LAB_BASE * 9 // 4
+    i = np.arange(_MIN_AB, _MIN_AB + n, dtype=np.int64)
+    tdiv = lambda a, b: np.sign(a) * (np.abs(a) // b)                 # noqa: E731  C-style truncation
+    lin = tdiv(i * 108, 841) - (_LAB_BASE * 16 // 116 * 108 // 841)
+    cub = (i * i // _LAB_BASE) * i // _LAB_BASE                       # only used for i > 3390 > 0
+    return np.where(i <= 3390, lin, cub)
+
+
+def _srgb_inv_gamma_tab_b() -> np.ndarray:
+    """OpenCV ``sRGBInvGammaTab_b``: round(255 * sRGB-gamma(i / 4095)), 4096 entries."""
+    x = _f32(1.0) * np.arange(1 << _INV_GAMMA_SHIFT, dtype=np.float32) / _f32((1 << _INV_GAMMA_SHIFT) - 1)
+    thr = _f32(7827) / _f32(2500000)                                  # 0.0031308
+    low = _f32(323) / _f32(25)                                        # 12.92
+    xs = _f32(11) / _f32(200)                                         # 0.055
+    p = (x.astype(np.float64) ** (1.0 / (_f32(12) / _f32(5)).astype(np.float64))).astype(np.float32)
+    y = np.where(x <= thr, x * low, p * (_f32(1) + xs) - xs).astype(np.float32)
+    return np.rint(_f32(255) * y).astype(np.int64)
+
+
+LAB_TO_YF_TAB = _lab_to_yf_tab_b()
+AB_TO_XZ_TAB = _ab_to_xz_tab_b()
+SRGB_INV_GAMMA_TAB = _srgb_inv_gamma_tab_b()
+assert AB_TO_XZ_TAB.min() == -1335 and AB_TO_XZ_TAB.max() == 88231     # the bounds OpenCV's source comments state
+
+
+def rgb2lab_u8(I: np.ndarray) -> np.ndarray:
+    """``cv2.cvtColor(I, cv2.COLOR_RGB2LAB)`` for uint8 RGB (OpenCV RGB2Lab_b): L*255/100, a+128, b+128, saturated."""
+    g = SRGB_GAMMA_TAB
+    R, G, B = g[I[..., 0]], g[I[..., 1]], g[I[..., 2]]
+    half = 1 << (_LAB_SHIFT - 1)
+    C = LAB_FWD_COEFFS
+    fX = LAB_CBRT_TAB[(R * C[0, 0] + G * C[0, 1] + B * C[0, 2] + half) >> _LAB_SHIFT]
+    fY = LAB_CBRT_TAB[(R * C[1, 0] + G * C[1, 1] + B * C[1, 2] + half) >> _LAB_SHIFT]
+    fZ = LAB_CBRT_TAB[(R * C[2, 0] + G * C[2, 1] + B * C[2, 2] + half) >> _LAB_SHIFT]
+    h2 = 1 << (_LAB_SHIFT2 - 1)
+    L = (_LSCALE * fY + _LSHIFT + h2) >> _LAB_SHIFT2
+    a = (500 * (fX - fY) + 128 * (1 << _LAB_SHIFT2) + h2) >> _LAB_SHIFT2
+    b = (200 * (fY - fZ) + 128 * (1 << _LAB_SHIFT2) + h2) >> _LAB_SHIFT2
+    return np.clip(np.stack([L, a, b], axis=-1), 0, 255).astype(np.uint8)
+
+
+def lab2rgb_u8(LAB: np.ndarray) -> np.ndarray:
+    """``cv2.cvtColor(LAB, cv2.COLOR_LAB2RGB)`` for uint8 Lab (OpenCV Lab2RGBinteger::process)."""
+    LL = LAB[..., 0].astype(np.int64)
+    aa = LAB[..., 1].astype(np.int64)
+    bb = LAB[..., 2].astype(np.int64)
+    y = LAB_TO_YF_TAB[LL, 0]
+    ify = LAB_TO_YF_TAB[LL, 1]
+    adiv = ((5 * aa * 53687 + (1 << 7)) >> 13) - 128 * _LAB_BASE // 500
+    bdiv = ((bb * 41943 + (1 << 4)) >> 9) - 128 * _LAB_BASE // 200 + 1
+    x = AB_TO_XZ_TAB[ify + adiv - _MIN_AB]
+    z = AB_TO_XZ_TAB[ify - bdiv - _MIN_AB]
+    shift = _LAB_SHIFT + (_LAB_BASE_SHIFT - _INV_GAMMA_SHIFT)
+    C = LAB_INV_COEFFS
+    top = (1 << _INV_GAMMA_SHIFT) - 1
+    chans = []
+    for r in range(3):
+        v = (C[r, 0] * x + C[r, 1] * y + C[r, 2] * z + (1 << (shift - 1))) >> shift
+        chans.append(SRGB_INV_GAMMA_TAB[np.clip(v, 0, top)])
+    return np.clip(np.stack(chans, axis=-1), 0, 255).astype(np.uint8)
+
+
+def mean_std_dev(x: np.ndarray):
+    """``cv2.meanStdDev`` of a single-channel array: double sums, population variance clamped at 0 -> two (1,1) float64."""
+    v = np.asarray(x, dtype=np.float64).ravel()
+    n = v.size
+    mean = v.sum() / n
+    var = max((v * v).sum() / n - mean * mean, 0.0)
+    return np.array([[mean]]), np.array([[np.sqrt(var)]])
+
+
 class TissueMaskException(Exception):
     """Oracle-side twin of stainlib/utils/excepts.py:22."""
 
@@ -307,6 +425,85 @@ class ExtractiveStainNormalizer:
         return truncate_u8(tmp).reshape(I.shape)                                 # :50
 
 
+# --------------------------------------------------------------------------
+# LAB helpers, ReinhardStainNormalizer, LuminosityStandardizer
+# stainlib/utils/stain_utils.py:50-67,114-124,146-194; normalization/normalizer.py:54-94
+# All of these sit on cv2's 8-bit Lab (rgb2lab_u8 / lab2rgb_u8 above): PARITY UNPINNED.
+# --------------------------------------------------------------------------
+def od_to_rgb(OD: np.ndarray) -> np.ndarray:
+    """convert_OD_to_RGB, stain_utils.py:114-124."""
+    assert OD.min() >= 0, "Negative optical density."                            # :122
+    OD = np.maximum(OD, 1e-6)                                                    # :123
+    return (255 * np.exp(-1 * OD)).astype(np.uint8)                              # :124
+
+
+def standardize_brightness(I: np.ndarray) -> np.ndarray:
+    """standardize_brightness, stain_utils.py:188-194: divide by the 90th percentile of ALL byte values."""
+    p = np.percentile(I, 90)                                                     # :193
+    return np.clip(I * 255.0 / p, 0, 255).astype(np.uint8)                       # :194
+
+
+def lab_split(I: np.ndarray):
+    """lab_split, stain_utils.py:146-158: binary32 channels L/2.55, a-128, b-128."""
+    lab = rgb2lab_u8(I).astype(np.float32)                                       # :152-153
+    I1, I2, I3 = lab[..., 0].copy(), lab[..., 1].copy(), lab[..., 2].copy()      # :154 (cv.split)
+    I1 /= 2.55                                                                   # :155
+    I2 -= 128.0                                                                  # :156
+    I3 -= 128.0                                                                  # :157
+    return I1, I2, I3
+
+
+def merge_back(I1, I2, I3) -> np.ndarray:
+    """merge_back, stain_utils.py:160-172 (operates on copies; the reference scales its arguments in place)."""
+    I1 = I1 * 2.55                                                               # :168
+    I2 = I2 + 128.0                                                              # :169
+    I3 = I3 + 128.0                                                              # :170
+    lab = np.clip(np.stack([I1, I2, I3], axis=-1), 0, 255).astype(np.uint8)      # :171 (cv.merge, clip, truncate)
+    return lab2rgb_u8(lab)                                                       # :172
+
+
+def get_mean_std(I: np.ndarray):
+    """get_mean_std, stain_utils.py:174-186: cv.meanStdDev per Lab channel -> ((m1,m2,m3), (sd1,sd2,sd3)), (1,1) float64 each."""
+    chans = lab_split(I)
+    ms = [mean_std_dev(c) for c in chans]
+    return tuple(m for m, _ in ms), tuple(sd for _, sd in ms)
+
+
+class ReinhardStainNormalizer:
+    """normalization/normalizer.py:54-94."""
+
+    def __init__(self, target_means=0, target_stds=0):
+        self.target_means, self.target_stds = target_means, target_stds          # :61-62
+
+    def fit(self, target):
+        target = standardize_brightness(target)                                  # :65
+        self.target_means, self.target_stds = get_mean_std(target)               # :66-68
+
+    def transform(self, I, mask_background=False, luminosity_threshold=0.8):
+        I = standardize_brightness(I)                                            # :78
+        I1, I2, I3 = lab_split(I)                                                # :79
+        means, stds = get_mean_std(I)                                            # :80
+        norm1 = ((I1 - means[0]) * (self.target_stds[0] / stds[0])) + self.target_means[0]   # :81 (binary64 from here)
+        norm2 = ((I2 - means[1]) * (self.target_stds[1] / stds[1])) + self.target_means[1]   # :82
+        norm3 = ((I3 - means[2]) * (self.target_stds[2] / stds[2])) + self.target_means[2]   # :83
+        if mask_background:
+            mask = tissue_mask(I, luminosity_threshold)                          # :86-87
+            background = np.array(~mask * 254).astype(np.uint8)                  # :88
+            norm1, norm2, norm3 = np.multiply(mask, norm1), np.multiply(mask, norm2), np.multiply(mask, norm3)  # :89
+            return merge_back(background + norm1, norm2, norm3)                  # :90
+        return merge_back(norm1, norm2, norm3)                                   # :92
+
+
+def luminosity_standardize(I: np.ndarray, percentile=95) -> np.ndarray:
+    """LuminosityStandardizer.standardize, stain_utils.py:52-67."""
+    assert is_uint8_image(I), "Image should be RGB uint8."                       # :61
+    lab = rgb2lab_u8(I)                                                          # :62
+    L_float = lab[:, :, 0].astype(float)                                         # :63
+    p = np.percentile(L_float, percentile)                                       # :64
+    lab[:, :, 0] = np.clip(255 * L_float / p, 0, 255).astype(np.uint8)           # :65
+    return lab2rgb_u8(lab)                                                       # :66
+
+
 def truncate_u8(x: np.ndarray) -> np.ndarray:
     """``.astype(np.uint8)`` of normalizer.py:50 -- truncation toward zero, no clip.
 
@@ -453,3 +650,29 @@ def synth_tile(h: int, w: int, seed: int, M_true: np.ndarray = M_TRUE_SRC) -> np
     OD = C @ M + rng.normal(0.0, 0.01, size=(P, 3))
     rgb = np.clip(255.0 * np.exp(-OD), 0, 255)
     return rgb.astype(np.uint8).reshape(h, w, 3)
+
+
+def structured_tile(kind: str, h: int, w: int, seed: int) -> np.ndarray:
+    """Synthetic tiles WITH spatial structure and colour ties (the i.i.d. generator above has neither):
+      white_bg   saturated (255,255,255) background: a band on the left and a disc, ~35 % of the pixels
+      palette12  11 tissue colours + white in 4x4 blocks (heavy ties in every order statistic)
+      quantized  colours snapped to multiples of 4 plus 2 (JPEG-like ties), white band on top"""
+    base = synth_tile(h, w, seed)
+    rng = np.random.RandomState(seed + 7919)
+    yy, xx = np.mgrid[0:h, 0:w]
+    if kind == "white_bg":
+        out = base.copy()
+        hole = (xx < w // 5) | ((yy - 0.6 * h) ** 2 + (xx - 0.65 * w) ** 2 < (0.22 * min(h, w)) ** 2)
+        out[hole] = 255
+        return out
+    if kind == "palette12":
+        flat = base.reshape(-1, 3)
+        tissue = flat[tissue_mask(base).ravel()]
+        pal = np.concatenate([tissue[:: max(1, len(tissue) // 11)][:11], np.array([[255, 255, 255]], np.uint8)])
+        idx = rng.choice(len(pal), size=((h + 3) // 4, (w + 3) // 4), p=np.r_[np.full(len(pal) - 1, 0.8 / (len(pal) - 1)), 0.2])
+        return pal[np.kron(idx, np.ones((4, 4), dtype=np.int64))[:h, :w]].astype(np.uint8)
+    if kind == "quantized":
+        out = (base & 0xFC) | 2
+        out[: h // 8] = 255
+        return out.astype(np.uint8)
+    raise ValueError(kind)

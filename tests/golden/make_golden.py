@@ -10,12 +10,15 @@ The reference cannot be imported as-is: ``import cv2`` and ``import spams``
 (stainlib/utils/stain_utils.py:2-3) name wheels that exist nowhere in this image.
 Two stand-in modules are therefore injected into ``sys.modules`` *before* the import:
 
-  * ``cv2.cvtColor(I, COLOR_RGB2LAB)``  -> L channel from the OpenCV 8-bit fixed-point
-    restatement in oracle/stain_oracle.py (the SAME code the oracle uses: the tissue
-    mask is therefore NOT independently pinned -- "parity unpinned", see DESIGN.md);
+  * ``cv2.cvtColor(I, COLOR_RGB2LAB / COLOR_LAB2RGB)``, ``cv2.split/merge/meanStdDev`` -> the OpenCV
+    8-bit fixed-point restatement in oracle/stain_oracle.py (the SAME code the oracle uses: the tissue
+    mask, ReinhardStainNormalizer and LuminosityStandardizer are therefore NOT independently pinned --
+    "parity unpinned", see DESIGN.md; tools/pin_cv2.py closes that gap wherever a real cv2 exists);
   * ``spams.lasso(mode=2, pos=True)``   -> scikit-learn's coordinate-descent
     ``Lasso(positive=True)`` run to 1e-14 -- an implementation INDEPENDENT of the
-    oracle's closed form, so the goldens do pin the oracle's lasso;
+    oracle's closed form, so the goldens do pin the oracle's lasso (images above 256 x 256 use a
+    vectorised cyclic coordinate descent written here, iterated until nothing moves: also independent
+    of the closed form, and fast enough for a megapixel);
   * ``spams.trainDL``                   -> not used for the goldens written here.
 
 Everything else -- convert_RGB_to_OD, np.cov/eigh, arctan2, percentiles, rescale,
@@ -45,12 +48,14 @@ def _install_standins():
     cv2.COLOR_LAB2RGB = 57
 
     def cvtColor(I, code):
-        assert code == cv2.COLOR_RGB2LAB
-        out = np.zeros_like(I)
-        out[:, :, 0] = so.lab_l8(I)
-        out[:, :, 1:] = 128
-        return out
+        if code == cv2.COLOR_RGB2LAB:
+            return so.rgb2lab_u8(np.asarray(I)[:, :, :3])
+        assert code == cv2.COLOR_LAB2RGB
+        return so.lab2rgb_u8(np.asarray(I))
 
+    cv2.split = lambda I: [np.ascontiguousarray(I[:, :, k]) for k in range(I.shape[2])]
+    cv2.merge = lambda chans: np.stack(chans, axis=-1)
+    cv2.meanStdDev = so.mean_std_dev
     cv2.cvtColor = cvtColor
     sys.modules["cv2"] = cv2
 
@@ -58,11 +63,25 @@ def _install_standins():
 
     def lasso(X, D, mode, lambda1, pos):
         assert mode == 2 and pos
+        X, D = np.asarray(X), np.asarray(D)
+        if X.shape[1] > 256 * 256:
+            # cyclic coordinate descent on min_a>=0 1/2|x - D a|^2 + lam 1'a, all columns at once, to a fixed point
+            G = D.T @ D
+            B = D.T @ X - lambda1
+            A = np.zeros((D.shape[1], X.shape[1]))
+            for it in range(100000):
+                prev = A.copy()
+                for j in range(D.shape[1]):
+                    r = B[j] - sum(G[j, k] * A[k] for k in range(D.shape[1]) if k != j)
+                    A[j] = np.maximum(r / G[j, j], 0.0)
+                if np.abs(A - prev).max() < 1e-15:
+                    break
+            return scipy.sparse.csc_matrix(A)
         # sklearn minimises 1/(2 n) ||y - Xw||^2 + alpha ||w||_1 with n = 3 rows
         n = X.shape[0]
         est = Lasso(alpha=lambda1 / n, fit_intercept=False, positive=True, tol=1e-14,
                     max_iter=1000000, precompute=False)
-        est.fit(np.asarray(D), np.asarray(X))
+        est.fit(D, X)
         return scipy.sparse.csc_matrix(est.coef_.T)
 
     def trainDL(**kw):
@@ -78,7 +97,7 @@ sys.path.insert(0, "/root/reference")
 import stainlib  # noqa: E402
 from stainlib.augmentation.augmenter import HedLighterColorAugmenter, StainAugmentor  # noqa: E402
 from stainlib.extraction.macenko_stain_extractor import MacenkoStainExtractor  # noqa: E402
-from stainlib.normalization.normalizer import ExtractiveStainNormalizer  # noqa: E402
+from stainlib.normalization.normalizer import ExtractiveStainNormalizer, ReinhardStainNormalizer  # noqa: E402
 from stainlib.utils import stain_utils as su  # noqa: E402
 from stainlib.utils.excepts import TissueMaskException  # noqa: E402
 
@@ -87,10 +106,12 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-def macenko_case(size, seed):
-    I = so.synth_tile(size, size, seed)
+def macenko_case(size, seed, kind=None):
+    """kind = None: the i.i.d. generator; otherwise oracle.structured_tile(kind, ...).  Tiles above 256^2 keep the SHA-256 of
+    the output and every 997th pixel instead of the whole image."""
+    I = so.synth_tile(size, size, seed) if kind is None else so.structured_tile(kind, size, size, seed)
     tgt = so.synth_tile(size, size, 1000 + seed, so.M_TRUE_TGT)
-    rec = {"size": size, "seed": seed, "input_sha": sha(I), "target_sha": sha(tgt)}
+    rec = {"size": size, "seed": seed, "input_sha": sha(I), "target_sha": sha(tgt), "kind": "" if kind is None else kind}
     if size <= 64:
         rec["input"] = I
         rec["target"] = tgt
@@ -124,15 +145,19 @@ def macenko_case(size, seed):
     rec["M_target"] = nrm.stain_matrix_target
     rec["maxC_target"] = nrm.maxC_target
     out = nrm.transform(I)
-    rec["out"] = out
+    if size <= 256:
+        rec["out"] = out
+    else:
+        rec["out_sub997"] = out.reshape(-1, 3)[::997]
     rec["out_sha"] = sha(out)
     Cs = C * (nrm.maxC_target / rec["maxC"])
     pre = 255 * np.exp(-1 * np.dot(Cs, nrm.stain_matrix_target))
     rec["prequant_sub"] = pre[::97]
     # self-transform (fit on the tile itself)
-    nrm2 = ExtractiveStainNormalizer("macenko")
-    nrm2.fit(I)
-    rec["out_self"] = nrm2.transform(I)
+    if size <= 256:
+        nrm2 = ExtractiveStainNormalizer("macenko")
+        nrm2.fit(I)
+        rec["out_self"] = nrm2.transform(I)
     return rec
 
 
@@ -140,12 +165,18 @@ def hed_case(size, seed, npseed):
     I = so.synth_tile(size, size, seed)
     aug = HedLighterColorAugmenter()
     rec = {"size": size, "seed": seed, "npseed": npseed, "input_sha": sha(I)}
-    rec["out_unrandomized"] = aug.transform(I)          # sigma = beta = -0.03 (augmenter.py:194-198)
+    big = size > 256
+    keep = (lambda a: a.reshape(-1, 3)[::97]) if big else (lambda a: a)
+    unr = aug.transform(I)                              # sigma = beta = -0.03 (augmenter.py:194-198)
+    rec["out_unrandomized"] = keep(unr)
+    rec["out_unrandomized_sha"] = sha(unr)
     np.random.seed(npseed)
     aug.randomize()
     rec["sigmas"] = np.array(aug._sigmas)
     rec["biases"] = np.array(aug._biases)
-    rec["out"] = aug.transform(I)
+    o = aug.transform(I)
+    rec["out"] = keep(o)
+    rec["out_sha"] = sha(o)
     rec["hed_sub"] = __import__("skimage.color").color.rgb2hed(I).reshape(-1, 3)[::97]
     white = np.full((16, 16, 3), 255, np.uint8)
     rec["white_is_same_object"] = bool(aug.transform(white) is white)
@@ -188,6 +219,33 @@ def grayscale_case(size, seed, npseed):
     return rec
 
 
+def reinhard_case(size, seed, kind=None):
+    """ReinhardStainNormalizer / LuminosityStandardizer / LAB helpers (normalizer.py:54-94, stain_utils.py:50-67,146-194)
+    through the reference's own code on top of the cv2 stand-in."""
+    I = so.synth_tile(size, size, seed) if kind is None else so.structured_tile(kind, size, size, seed)
+    tgt = so.synth_tile(size, size, 1000 + seed, so.M_TRUE_TGT)
+    rec = {"size": size, "seed": seed, "kind": "" if kind is None else kind, "input_sha": sha(I), "target_sha": sha(tgt)}
+    rec["standardized"] = su.standardize_brightness(I)
+    I1, I2, I3 = su.lab_split(I)
+    rec["lab_split_sub"] = np.stack([I1, I2, I3], axis=-1).reshape(-1, 3)[::97]
+    means, stds = su.get_mean_std(I)
+    rec["means"] = np.array([float(m) for m in means])
+    rec["stds"] = np.array([float(v) for v in stds])
+    rec["merge_back"] = su.merge_back(*su.lab_split(I))                      # the Lab round trip of the helpers
+    nrm = ReinhardStainNormalizer()
+    nrm.fit(tgt)
+    rec["target_means"] = np.array([float(m) for m in nrm.target_means])
+    rec["target_stds"] = np.array([float(v) for v in nrm.target_stds])
+    rec["out"] = nrm.transform(I)
+    rec["out_masked"] = nrm.transform(I, mask_background=True)
+    rec["out_masked_06"] = nrm.transform(I, mask_background=True, luminosity_threshold=0.6)
+    rec["lum_std"] = stainlib.LuminosityStandardizer.standardize(I)
+    rec["lum_std_80"] = stainlib.LuminosityStandardizer.standardize(I, percentile=80)
+    OD = np.random.RandomState(seed).uniform(0.0, 3.0, size=(32, 32, 3))
+    rec["od_to_rgb"] = su.convert_OD_to_RGB(OD)
+    return rec
+
+
 def errors_case():
     rec = {}
     try:
@@ -208,6 +266,20 @@ def errors_case():
     except AssertionError as e:
         rec["float_raises"] = True
         rec["float_msg"] = str(e)
+    rgba = np.full((8, 8, 4), 120, np.uint8)
+    rec["rgba_passes_guard"] = bool(su.is_uint8_image(rgba))                  # stain_utils.py:126-144: channels unchecked
+    try:
+        MacenkoStainExtractor.get_stain_matrix(rgba)
+        rec["rgba_fails_later"] = False
+    except Exception as e:  # noqa: BLE001
+        rec["rgba_fails_later"] = True
+        rec["rgba_exception"] = type(e).__name__
+    try:
+        su.convert_OD_to_RGB(np.full((2, 2, 3), -0.5))
+        rec["neg_od_raises"] = False
+    except AssertionError as e:
+        rec["neg_od_raises"] = True
+        rec["neg_od_msg"] = str(e)
     return rec
 
 
@@ -222,11 +294,17 @@ def main():
     for size in (64, 256):
         for seed in (1, 2, 3):
             save("macenko_%d_s%d" % (size, seed), macenko_case(size, seed))
+    save("macenko_1024_s1", macenko_case(1024, 1))                        # BASELINE configs[1] tile size
+    for kind in ("white_bg", "palette12", "quantized"):
+        save("macenko_128_%s_s4" % kind, macenko_case(128, 4, kind))
+    save("hed_512_s4_np5", hed_case(512, 4, 5))                           # BASELINE configs[3] tile size
     save("hed_128_s2_np0", hed_case(128, 2, 0))
     save("hed_128_s3_np123", hed_case(128, 3, 123))
     save("stainaug_128_s2_np7", stainaug_case(128, 2, 7, False))
     save("stainaug_128_s3_np7_bg", stainaug_case(128, 3, 7, True))
     save("grayscale_128_s2_np11", grayscale_case(128, 2, 11))
+    save("reinhard_128_s2", reinhard_case(128, 2))
+    save("reinhard_128_white_bg_s4", reinhard_case(128, 4, "white_bg"))
     save("errors", errors_case())
 
 

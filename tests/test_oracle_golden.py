@@ -21,11 +21,16 @@ def sha(a):
 MACENKO = sorted(glob.glob(os.path.join(GOLDEN, "macenko_*.npz")))
 
 
+def _case_input(g):
+    size, seed, kind = int(g["size"]), int(g["seed"]), str(g["kind"]) if "kind" in g.files else ""
+    return so.synth_tile(size, size, seed) if not kind else so.structured_tile(kind, size, size, seed)
+
+
 @pytest.mark.parametrize("path", MACENKO, ids=[os.path.basename(p)[:-4] for p in MACENKO])
 def test_macenko_stages(path):
     g = np.load(path)
     size, seed = int(g["size"]), int(g["seed"])
-    I = so.synth_tile(size, size, seed)
+    I = _case_input(g)
     tgt = so.synth_tile(size, size, 1000 + seed, so.M_TRUE_TGT)
     assert sha(I) == str(g["input_sha"]) and sha(tgt) == str(g["target_sha"])
     if "input" in g.files:
@@ -37,7 +42,7 @@ def test_macenko_stages(path):
     np.testing.assert_allclose(so.rgb_to_od(I).reshape(-1, 3)[::97], g["od_sub"], rtol=4e-16, atol=0)
     d = {}
     M = so.macenko_stain_matrix(I, details=d)
-    np.testing.assert_allclose(d["cov"], g["cov"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(d["cov"], g["cov"], rtol=0, atol=1e-14)     # (summation order of np.cov differs between numpy 1.26 and 2.x)
     np.testing.assert_allclose(d["V"], g["V"], rtol=0, atol=1e-12)
     np.testing.assert_allclose([d["minPhi"], d["maxPhi"]], g["phi_pct"], rtol=0, atol=1e-13)
     np.testing.assert_allclose(M, g["M"], rtol=0, atol=1e-13)
@@ -52,7 +57,7 @@ def test_macenko_stages(path):
 def test_macenko_fit_transform(path):
     g = np.load(path)
     size, seed = int(g["size"]), int(g["seed"])
-    I = so.synth_tile(size, size, seed)
+    I = _case_input(g)
     tgt = so.synth_tile(size, size, 1000 + seed, so.M_TRUE_TGT)
     n = so.ExtractiveStainNormalizer("macenko")
     n.fit(tgt)
@@ -64,10 +69,15 @@ def test_macenko_fit_transform(path):
     np.testing.assert_allclose(d["prequant"].reshape(-1, 3)[::97], g["prequant_sub"], rtol=1e-8)
     # the lasso stand-in used for the goldens converges to ~1e-12, so a byte can flip only
     # if a pre-quantisation value sits within 1e-9 of an integer: demand bit-identity.
-    assert np.array_equal(out, g["out"])
-    n2 = so.ExtractiveStainNormalizer("macenko")
-    n2.fit(I)
-    assert np.array_equal(n2.transform(I), g["out_self"])
+    assert sha(out) == str(g["out_sha"])
+    if "out" in g.files:
+        assert np.array_equal(out, g["out"])
+    else:                                               # 1024^2: SHA-256 above + every 997th pixel
+        assert np.array_equal(out.reshape(-1, 3)[::997], g["out_sub997"])
+    if "out_self" in g.files:
+        n2 = so.ExtractiveStainNormalizer("macenko")
+        n2.fit(I)
+        assert np.array_equal(n2.transform(I), g["out_self"])
 
 
 HED = sorted(glob.glob(os.path.join(GOLDEN, "hed_*.npz")))
@@ -81,12 +91,15 @@ def test_hed(path):
     assert sha(I) == str(g["input_sha"])
     np.testing.assert_allclose(so.rgb2hed(I).reshape(-1, 3)[::97], g["hed_sub"], rtol=0, atol=1e-14)
     t = 0.03
-    assert np.array_equal(so.hed_transform(I, [-t] * 3, [-t] * 3), g["out_unrandomized"])
+    keep = (lambda a: a.reshape(-1, 3)[::97]) if size > 256 else (lambda a: a)
+    unr = so.hed_transform(I, [-t] * 3, [-t] * 3)
+    assert sha(unr) == str(g["out_unrandomized_sha"]) and np.array_equal(keep(unr), g["out_unrandomized"])
     np.random.seed(npseed)
     s, b = so.hed_randomize(t)
     np.testing.assert_array_equal(s, g["sigmas"])
     np.testing.assert_array_equal(b, g["biases"])
-    assert np.array_equal(so.hed_transform(I, s, b), g["out"])
+    o = so.hed_transform(I, s, b)
+    assert sha(o) == str(g["out_sha"]) and np.array_equal(keep(o), g["out"])
     white = np.full((16, 16, 3), 255, np.uint8)
     assert bool(g["white_is_same_object"]) and so.hed_transform(white, s, b) is white
     dark = np.full((16, 16, 3), 3, np.uint8)
@@ -125,6 +138,12 @@ def test_error_contract():
     assert str(g["float_msg"]) == "Image should be RGB uint8."
     with pytest.raises(AssertionError, match="Image should be RGB uint8."):
         so.macenko_stain_matrix(np.zeros((8, 8, 3), np.float32))
+    # a 4-channel uint8 image passes the reference's guard and fails later (stain_utils.py:126-144)
+    assert bool(g["rgba_passes_guard"]) and bool(g["rgba_fails_later"])
+    assert so.is_uint8_image(np.zeros((8, 8, 4), np.uint8))
+    assert bool(g["neg_od_raises"]) and str(g["neg_od_msg"]) == "Negative optical density."
+    with pytest.raises(AssertionError, match="Negative optical density."):
+        so.od_to_rgb(np.full((2, 2, 3), -0.5))
 
 
 def test_lab_threshold_index():
@@ -146,3 +165,81 @@ def test_grayscale_augmentor_golden():
     assert np.array_equal(a.pop(), g["out0"]) and np.array_equal(a.pop(), g["out1"])
     assert np.array_equal(a.pop_with(*g["draws0"]), g["out0"])
 
+
+
+VAHADANE_PIN = sorted(glob.glob(os.path.join(GOLDEN, "vahadane_pin_*.npz")))
+
+
+@pytest.mark.parametrize("path", VAHADANE_PIN, ids=[os.path.basename(p)[:-4] for p in VAHADANE_PIN])
+def test_vahadane_dictionary_is_pinned_by_an_independent_solver(path):
+    """oracle.vahadane_dictionary against scikit-learn's positive DictionaryLearning (tests/golden/make_vahadane_pin.py):
+    a different lasso, a different dictionary update, (seed 3) a different start -- the same optimum of the objective
+    spams.trainDL minimises (vahadane_stain_extractor.py:35-36).  Bar: rows within 1e-5, objective within 1e-7 relative."""
+    g = np.load(path)
+    I = so.synth_tile(int(g["size"]), int(g["size"]), int(g["seed"]))
+    assert sha(I) == str(g["input_sha"])
+    mask = so.tissue_mask(I).ravel()
+    OD = so.rgb_to_od(I).reshape(-1, 3)[mask]
+    assert OD.shape[0] == int(g["n_tissue"])
+    info = {}
+    D = so.vahadane_dictionary(OD, float(g["lambda"]), max_sweeps=2000, tol=1e-12, info=info)
+    if D[0, 0] < D[1, 0]:
+        D = D[::-1]
+    assert np.abs(D - g["D"]).max() < 1e-5, np.abs(D - g["D"]).max()
+    assert abs(info["objective"] - float(g["objective"])) < 1e-7 * float(g["objective"])
+    # and through the public entry point (mask, ordering, row normalisation: vahadane_stain_extractor.py:30-43)
+    M = so.vahadane_stain_matrix(I, tol=1e-12, max_sweeps=2000)
+    np.testing.assert_allclose(M, so.normalize_rows(g["D"]), rtol=0, atol=1e-5)
+
+
+REINHARD = sorted(glob.glob(os.path.join(GOLDEN, "reinhard_*.npz")))
+
+
+@pytest.mark.parametrize("path", REINHARD, ids=[os.path.basename(p)[:-4] for p in REINHARD])
+def test_reinhard_and_lab_helpers(path):
+    """ReinhardStainNormalizer, LuminosityStandardizer and the LAB helpers: the reference's own code ran on top of the cv2
+    stand-in (= the oracle's OpenCV restatement), so this pins the oracle's restatement of the REFERENCE's arithmetic
+    (percentiles, binary32 / binary64 promotion, clip-then-truncate, masking) -- not OpenCV's, which stays unpinned."""
+    g = np.load(path)
+    I = _case_input(g)
+    size, seed = int(g["size"]), int(g["seed"])
+    tgt = so.synth_tile(size, size, 1000 + seed, so.M_TRUE_TGT)
+    assert sha(I) == str(g["input_sha"]) and sha(tgt) == str(g["target_sha"])
+    assert np.array_equal(so.standardize_brightness(I), g["standardized"])
+    I1, I2, I3 = so.lab_split(I)
+    assert I1.dtype == np.float32
+    assert np.array_equal(np.stack([I1, I2, I3], axis=-1).reshape(-1, 3)[::97], g["lab_split_sub"])
+    means, stds = so.get_mean_std(I)
+    np.testing.assert_allclose([float(m) for m in means], g["means"], rtol=1e-14)
+    np.testing.assert_allclose([float(v) for v in stds], g["stds"], rtol=1e-13)
+    assert np.array_equal(so.merge_back(*so.lab_split(I)), g["merge_back"])
+    n = so.ReinhardStainNormalizer()
+    n.fit(tgt)
+    np.testing.assert_allclose([float(m) for m in n.target_means], g["target_means"], rtol=1e-14)
+    np.testing.assert_allclose([float(v) for v in n.target_stds], g["target_stds"], rtol=1e-13)
+    assert np.array_equal(n.transform(I), g["out"])
+    assert np.array_equal(n.transform(I, mask_background=True), g["out_masked"])
+    assert np.array_equal(n.transform(I, mask_background=True, luminosity_threshold=0.6), g["out_masked_06"])
+    assert np.array_equal(so.luminosity_standardize(I), g["lum_std"])
+    assert np.array_equal(so.luminosity_standardize(I, percentile=80), g["lum_std_80"])
+    OD = np.random.RandomState(seed).uniform(0.0, 3.0, size=(32, 32, 3))       # (an exact round trip of a uint8 image would
+    assert np.array_equal(so.od_to_rgb(OD), g["od_to_rgb"])                    #  sit on the truncation's knife edge)
+
+
+def test_lab_restatement_sanity():
+    """The 8-bit Lab restatement against float CIE Lab (a sanity bound, NOT a pin) and its own round trip."""
+    rng = np.random.RandomState(0)
+    I = rng.randint(0, 256, size=(128, 128, 3)).astype(np.uint8)
+    lab = so.rgb2lab_u8(I)
+    assert np.array_equal(lab[..., 0], so.lab_l8(I))
+    x = I / 255.0
+    lin = np.where(x <= 0.04045, x / 12.92, ((x + 0.055) / 1.055) ** 2.4)
+    xyz = lin @ np.array(so._SRGB2XYZ).T / np.array(so._D65)
+    f = np.where(xyz > 216 / 24389, np.cbrt(xyz), xyz * 841 / 108 + 16 / 116)
+    ref = np.stack([(116 * f[..., 1] - 16) * 2.55, 500 * (f[..., 0] - f[..., 1]) + 128, 200 * (f[..., 1] - f[..., 2]) + 128], -1)
+    assert np.abs(lab - ref).max() < 3.0
+    prim = np.array([[[255, 255, 255], [0, 0, 0], [255, 0, 0], [0, 255, 0], [0, 0, 255], [128, 128, 128]]], np.uint8)
+    assert so.rgb2lab_u8(prim).tolist() == [[[255, 128, 128], [0, 128, 128], [136, 208, 195], [224, 42, 211], [82, 207, 20], [137, 128, 128]]]
+    grey = np.repeat(np.arange(256, dtype=np.uint8)[None, :, None], 3, axis=2)
+    back = so.lab2rgb_u8(so.rgb2lab_u8(grey))
+    assert np.abs(back.astype(int) - grey.astype(int)).max() <= 1
