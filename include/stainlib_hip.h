@@ -30,7 +30,14 @@
 extern "C" {
 #endif
 
-#define SL_VERSION 100 /* 0.1.0 */
+#define SL_VERSION 200 /* 0.2.0 */
+
+/* The library is built with -fvisibility=hidden: exactly the functions declared here are exported. */
+#if defined(__GNUC__)
+#define SL_API __attribute__((visibility("default")))
+#else
+#define SL_API
+#endif
 
 /* return codes */
 #define SL_OK 0
@@ -54,17 +61,20 @@ extern "C" {
 #define SL_OP_HED_AUGMENT 5
 #define SL_OP_STAIN_AUGMENT 6
 #define SL_OP_TILE_MOMENTS 7
+#define SL_OP_LAB_STATS 8        /* sl_reinhard_stats, sl_reinhard_transform, sl_luminosity_standardize, sl_standardize_brightness */
 
 /* selection key sets of the pooled slide-level mode (sl_slide_key_*): each set carries TWO targets */
 #define SL_KEYSET_ANGLE 0 /* both targets: pseudo-angle of the projected OD, tissue pixels only (macenko_stain_extractor.py:29-34) */
 #define SL_KEYSET_CONC 1  /* target i: lasso concentration of stain i, all pixels (normalizer.py:36,47) */
 
-/* skimage semantics selector for sl_hed_augment */
+/* skimage semantics selector for sl_hed_augment.  Only 0.18 is pinned by vectors from a real scikit-image
+ * (0.18.3); the other three are restated from memory and checked against the CPU restatement only -- no source or wheel
+ * of those releases exists in the build environment. */
 #define SL_HED_SKIMAGE_018 0 /* ln(max(rgb,1e-6))/ln(1e-6) @ hed_from_rgb  (golden-pinned) */
-#define SL_HED_SKIMAGE_019 1 /* as 0.18 + stains clamped at 0 after separation */
-#define SL_HED_SKIMAGE_017 2 /* <= 0.17 (environment.yml:107 pins 0.17.2): -log10(rgb+2) @ hed_from_rgb, 10^(-stains @ rgb_from_hed) - 2 */
-/* scikit-image 0.17 (the version pinned in the reference's environment.yml:107) is NOT offered: its
- * log10(rgb+2) formulation cannot be checked against any source or wheel available to this build. */
+#define SL_HED_SKIMAGE_019 1 /* as 0.18 + stains clamped at 0 after separation  (unpinned) */
+#define SL_HED_SKIMAGE_017 2 /* presumed <= 0.17 (environment.yml:107 pins 0.17.2): -ln(rgb + 2) @ hed_from_rgb,
+                                exp(-stains @ rgb_from_hed) - 2, clipped  (natural logarithm; unpinned) */
+#define SL_HED_EXPERIMENTAL_LOG10 3 /* the same with a base-10 logarithm (round 1's reading of 0.17; kept as an experiment, unpinned) */
 
 /* Optional kernel timing.  When SlParams.profile is non-NULL, sl_*_fit / sl_*_transform bracket every
  * launch of the selected kernel classes with two caller-created hipEvent_t from events[] (start, stop),
@@ -101,14 +111,18 @@ typedef struct SlParams {
     int32_t schedule;           /* 0 = automatic; 1 = one launch per phase; 2 = persistent fused kernel */
     double dl_tol;              /* 1e-7 max-abs change of the dictionary between sweeps */
     SlProfile* profile;         /* NULL (default): no timing events */
+    int32_t* fallbacks_out;     /* NULL (default) or DEVICE pointer to n ints: per tile, how many of its four order statistics
+                                   (two angular, two concentration percentiles) needed the slow exact selection over the whole
+                                   tile because the sampled bracket missed or its candidate list overflowed (diagnostics;
+                                   results never depend on it).  Written by sl_macenko_* / sl_vahadane_*. */
 } SlParams;
 
-int sl_version(void);
-const char* sl_error_string(int code);
-void sl_default_params(SlParams* p);
+SL_API int sl_version(void);
+SL_API const char* sl_error_string(int code);
+SL_API void sl_default_params(SlParams* p);
 
 /* Bytes of device workspace an op needs for n tiles of h x w.  0 for ops that need none. */
-size_t sl_workspace_bytes(int op, int n_tiles, int h, int w);
+SL_API size_t sl_workspace_bytes(int op, int n_tiles, int h, int w);
 
 /* MacenkoStainExtractor.get_stain_matrix (extraction/macenko_stain_extractor.py:7-44)
  * + get_concentrations (utils/stain_utils.py:69-78) + np.percentile(C, 99, axis=0)
@@ -116,14 +130,14 @@ size_t sl_workspace_bytes(int op, int n_tiles, int h, int w);
  *   M_out    n x 2 x 3 double   unit-norm rows, H first
  *   maxC_out n x 2 double
  *   status   n int32 */
-int sl_macenko_fit(const uint8_t* rgb, int n, int h, int w, const SlParams* params,
+SL_API int sl_macenko_fit(const uint8_t* rgb, int n, int h, int w, const SlParams* params,
                    double* M_out, double* maxC_out, int32_t* status,
                    void* workspace, size_t workspace_bytes, void* stream);
 
 /* VahadaneStainExtractor.get_stain_matrix (extraction/vahadane_stain_extractor.py:19-43) with
  * spams.trainDL replaced by the converged optimum of the same objective, then as above.
  *   sweeps_out  n int32 (may be NULL): dictionary sweeps used per tile */
-int sl_vahadane_fit(const uint8_t* rgb, int n, int h, int w, const SlParams* params,
+SL_API int sl_vahadane_fit(const uint8_t* rgb, int n, int h, int w, const SlParams* params,
                     double* M_out, double* maxC_out, int32_t* status, int32_t* sweeps_out,
                     void* workspace, size_t workspace_bytes, void* stream);
 
@@ -132,7 +146,7 @@ int sl_vahadane_fit(const uint8_t* rgb, int n, int h, int w, const SlParams* par
  * (utils/stain_utils.py:69-78,101-112 ; normalization/normalizer.py:46-50).
  *   M_src n x 2 x 3, maxC_src n x 2 (per tile); M_tgt 2 x 3, maxC_tgt 2 (shared)
  *   prequant  optional n x P x 3 float: the values before the uint8 cast (parity tests) */
-int sl_normalize_apply(const uint8_t* rgb, uint8_t* out, int n, int h, int w,
+SL_API int sl_normalize_apply(const uint8_t* rgb, uint8_t* out, int n, int h, int w,
                        const double* M_src, const double* maxC_src,
                        const double* M_tgt, const double* maxC_tgt,
                        double lasso_lambda, float* prequant, void* stream);
@@ -140,13 +154,13 @@ int sl_normalize_apply(const uint8_t* rgb, uint8_t* out, int n, int h, int w,
 /* ExtractiveStainNormalizer('macenko').transform (normalization/normalizer.py:39-50) for a
  * batch: per-tile fit stages + the apply pass in one cache-friendly schedule.
  *   M_src_out n x 2 x 3 / maxC_src_out n x 2 may be NULL. */
-int sl_macenko_transform(const uint8_t* rgb, uint8_t* out, int n, int h, int w,
+SL_API int sl_macenko_transform(const uint8_t* rgb, uint8_t* out, int n, int h, int w,
                          const SlParams* params, const double* M_tgt, const double* maxC_tgt,
                          double* M_src_out, double* maxC_src_out, int32_t* status,
                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* ExtractiveStainNormalizer('vahadane').transform, same shape. */
-int sl_vahadane_transform(const uint8_t* rgb, uint8_t* out, int n, int h, int w,
+SL_API int sl_vahadane_transform(const uint8_t* rgb, uint8_t* out, int n, int h, int w,
                           const SlParams* params, const double* M_tgt, const double* maxC_tgt,
                           double* M_src_out, double* maxC_src_out, int32_t* status,
                           void* workspace, size_t workspace_bytes, void* stream);
@@ -156,7 +170,7 @@ int sl_vahadane_transform(const uint8_t* rgb, uint8_t* out, int n, int h, int w,
  * truncate.  sigma, bias: n x 3 double (H, E, D).  applied[i] (may be NULL) = 0 when tile i failed
  * cutoff_lo <= mean/255 <= cutoff_hi; such a tile is copied through unchanged.
  * workspace: sl_workspace_bytes(SL_OP_HED_AUGMENT, n, h, w) = 8 n bytes. */
-int sl_hed_augment(const uint8_t* rgb, uint8_t* out, int n, int h, int w,
+SL_API int sl_hed_augment(const uint8_t* rgb, uint8_t* out, int n, int h, int w,
                    const double* sigma, const double* bias, double cutoff_lo, double cutoff_hi,
                    int skimage_mode, int32_t* applied,
                    void* workspace, size_t workspace_bytes, void* stream);
@@ -164,35 +178,81 @@ int sl_hed_augment(const uint8_t* rgb, uint8_t* out, int n, int h, int w,
 /* The float branch of HedColorAugmenter.transform (augmentation/augmenter.py:288-289, 319-320): patches of
  * binary64 values in [0,1], n x h x w x 3; cutoff on np.mean(patch); binary64 arithmetic; clipped output.
  * workspace: 8 n bytes. */
-int sl_hed_augment_f64(const double* rgb, double* out, int n, int h, int w,
+SL_API int sl_hed_augment_f64(const double* rgb, double* out, int n, int h, int w,
                        const double* sigma, const double* bias, double cutoff_lo, double cutoff_hi,
                        int skimage_mode, int32_t* applied,
                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* convert_RGB_to_OD (utils/stain_utils.py:101-112) materialised: od_out n x h x w x 3 double. */
-int sl_rgb_to_od(const uint8_t* rgb, int n, int h, int w, double* od_out, void* stream);
+SL_API int sl_rgb_to_od(const uint8_t* rgb, int n, int h, int w, double* od_out, void* stream);
+
+/* convert_OD_to_RGB (utils/stain_utils.py:114-124): rgb_out[i] = uint8(255 * exp(-max(od[i], 1e-6))) for n_values doubles.
+ * negative_flag (device int32, may be NULL) is set to 1 when any od[i] < 0 (the reference asserts "Negative optical density."). */
+SL_API int sl_od_to_rgb(const double* od, size_t n_values, uint8_t* rgb_out, int32_t* negative_flag, void* stream);
 
 /* StainAugmentor.pop (augmentation/augmenter.py:428-449): concentrations with the tile's
  * stain matrix M (n x 2 x 3), C[:,i] = C[:,i]*alpha_i + beta_i on tissue pixels (all pixels
  * when augment_background), 255*exp(-C @ M), clip to [0,255], truncate.
- *   alpha_beta n x 4 float: alpha0, beta0, alpha1, beta1 (the reference's draw order) */
-int sl_stain_augment(const uint8_t* rgb, uint8_t* out, int n, int h, int w,
-                     const double* M, const float* alpha_beta, int augment_background,
+ *   alpha_beta n x 4 double: alpha0, beta0, alpha1, beta1 (the reference's draw order) */
+SL_API int sl_stain_augment(const uint8_t* rgb, uint8_t* out, int n, int h, int w,
+                     const double* M, const double* alpha_beta, int augment_background,
                      const SlParams* params, void* stream);
 
 /* LuminosityThresholdTissueLocator.get_tissue_mask (utils/stain_utils.py:32-48):
  * mask_out n x P uint8 (0/1, may be NULL), counts n int64 (may be NULL). */
-int sl_tissue_mask(const uint8_t* rgb, int n, int h, int w, double luminosity_threshold,
+SL_API int sl_tissue_mask(const uint8_t* rgb, int n, int h, int w, double luminosity_threshold,
                    uint8_t* mask_out, int64_t* counts, void* stream);
 
 /* get_concentrations (utils/stain_utils.py:69-78) materialised: C_out n x P x 2 float. */
-int sl_concentrations(const uint8_t* rgb, int n, int h, int w, const double* M,
+SL_API int sl_concentrations(const uint8_t* rgb, int n, int h, int w, const double* M,
                       double lasso_lambda, float* C_out, void* stream);
 
 /* GrayscaleAugmentor.pop (augmentation/augmenter.py:390-401): out = 3 x uint8(255 * clip(rgb2gray * alpha +
  * beta, 0, 1)), binary64 arithmetic like the reference.  alpha_beta: n x 2 doubles (device). */
-int sl_grayscale_augment(const uint8_t* rgb, uint8_t* out, int n, int h, int w, const double* alpha_beta,
+SL_API int sl_grayscale_augment(const uint8_t* rgb, uint8_t* out, int n, int h, int w, const double* alpha_beta,
                          void* stream);
+
+/* ---- OpenCV 8-bit Lab family: ReinhardStainNormalizer, LuminosityStandardizer, LAB helpers.
+ * cv2.cvtColor on uint8 images is restated from OpenCV's published RGB2Lab_b / Lab2RGBinteger (integer tables); no cv2 exists in
+ * the build environment, so this family is PARITY UNPINNED against OpenCV itself (tools/pin_cv2.py checks it wherever cv2 is
+ * installed).  The reference's own arithmetic around it (percentiles, binary32/binary64 promotion, clip-then-truncate, masking)
+ * is golden-pinned.  Workspace of the four entry points that take one: sl_workspace_bytes(SL_OP_LAB_STATS, n, h, w). */
+
+/* cv2.cvtColor(I, COLOR_RGB2LAB), uint8 (utils/stain_utils.py:62,152): lab_out n x h x w x 3 = L*255/100, a+128, b+128. */
+SL_API int sl_rgb_to_lab8(const uint8_t* rgb, uint8_t* lab_out, int n, int h, int w, void* stream);
+/* cv2.cvtColor(LAB, COLOR_LAB2RGB), uint8 (utils/stain_utils.py:66,172). */
+SL_API int sl_lab8_to_rgb(const uint8_t* lab, uint8_t* rgb_out, int n, int h, int w, void* stream);
+/* lab_split (utils/stain_utils.py:146-158): three n x h x w binary32 planes L8/2.55, a8-128, b8-128. */
+SL_API int sl_lab_split(const uint8_t* rgb, int n, int h, int w, float* I1, float* I2, float* I3, void* stream);
+/* merge_back (utils/stain_utils.py:160-172): I1*2.55, I2+128, I3+128 in the planes' own precision (is_f64: binary64 planes,
+ * else binary32), clip [0,255], truncate, LAB2RGB.  The planes are not modified (the reference scales them in place). */
+SL_API int sl_lab_merge(const void* I1, const void* I2, const void* I3, int is_f64, int n, int h, int w, uint8_t* rgb_out, void* stream);
+
+/* standardize_brightness (utils/stain_utils.py:188-194): p = 90th percentile (np.percentile, linear) of ALL byte values of the
+ * tile, out = uint8(clip(I * 255.0 / p, 0, 255)).  p_out: n doubles (may be NULL). */
+SL_API int sl_standardize_brightness(const uint8_t* rgb, uint8_t* out, int n, int h, int w, double* p_out,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
+/* get_mean_std (utils/stain_utils.py:174-186; cv2.meanStdDev of the lab_split planes: population std), optionally of the
+ * brightness-standardised tile (standardize != 0: what ReinhardStainNormalizer.fit / transform feed it, normalizer.py:65-66,78-80).
+ *   stats_out n x 8 double: p90 (NaN when !standardize), mean L, a, b, std L, a, b, 0 */
+SL_API int sl_reinhard_stats(const uint8_t* rgb, int n, int h, int w, int standardize, double* stats_out,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ReinhardStainNormalizer.transform (normalization/normalizer.py:70-94): standardize_brightness, lab_split, per-channel
+ * (x - mean) * (target_std / std) + target_mean in binary64, optional background masking with the luminosity test of the
+ * standardised tile (background -> L 254, a = b = 0 before merge_back), merge_back.
+ *   target_means / target_stds: 3 doubles each (DEVICE), shared by all tiles
+ *   stats_out n x 8 (may be NULL): as sl_reinhard_stats(standardize = 1), last entry = tissue pixels of the standardised tile
+ *                                  (0 with mask_background -> the reference raises TissueMaskException) */
+SL_API int sl_reinhard_transform(const uint8_t* rgb, uint8_t* out, int n, int h, int w, const double* target_means,
+                          const double* target_stds, int mask_background, double luminosity_threshold, double* stats_out,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* LuminosityStandardizer.standardize (utils/stain_utils.py:52-67): p = np.percentile(L8, percentile),
+ * L8 <- uint8(clip(255 * L8 / p, 0, 255)), LAB2RGB.  p_out: n doubles (may be NULL). */
+SL_API int sl_luminosity_standardize(const uint8_t* rgb, uint8_t* out, int n, int h, int w, double percentile, double* p_out,
+                              void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- pooled slide-level mode (BASELINE.json configs[4]; an extension: the reference has no notion of a slide).
  * Every tile of a slide gets the statistics the reference would compute from the vertical concatenation of all
@@ -201,7 +261,7 @@ int sl_grayscale_augment(const uint8_t* rgb, uint8_t* out, int n, int h, int w, 
  *
  * sl_tile_moments: per tile {n, sum od[3], sum od od^T [xx,xy,xz,yy,yz,zz]} over the tissue pixels, binary64,
  * run-to-run identical.  workspace: sl_workspace_bytes(SL_OP_TILE_MOMENTS, n, h, w). */
-int sl_tile_moments(const uint8_t* rgb, int n, int h, int w, const SlParams* params,
+SL_API int sl_tile_moments(const uint8_t* rgb, int n, int h, int w, const SlParams* params,
                     double* moments_out /* n x 10 */, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Keys are compared as order-preserving uint32 images of their binary32 value: ord(f) = bits(f) ^ 0x80000000 for
@@ -209,25 +269,25 @@ int sl_tile_moments(const uint8_t* rgb, int n, int h, int w, const SlParams* par
  * stain matrix M (2x3) for SL_KEYSET_CONC.  Both targets of the key set are served by the same sweep: hist
  * (device, 2 x 256 uint64) is ACCUMULATED into, target t counting bin = the 8 key bits below the top `prefix_bits`
  * bits over the keys whose top `prefix_bits` (0, 8, 16 or 24) bits equal prefixes[t] (HOST pointer, 2 values). */
-int sl_slide_key_histogram(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int keyset,
+SL_API int sl_slide_key_histogram(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int keyset,
                            const double* basis, const uint32_t* prefixes, int prefix_bits,
                            unsigned long long* hist, void* stream);
 /* The last two rounds in one sweep: hist16 (device, 2 x 65536 uint64, ACCUMULATED into) counts the LOW 16 key bits
  * over the keys whose top 16 bits equal prefixes16[t] (HOST pointer, 2 values). */
-int sl_slide_key_histogram16(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int keyset,
+SL_API int sl_slide_key_histogram16(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int keyset,
                              const double* basis, const uint32_t* prefixes16, unsigned long long* hist16, void* stream);
 /* sl_slide_key_histogram over a stratified pixel sample: one 64-chunk row in 2^sample_log2 (0 <= sample_log2 <= 12). */
-int sl_slide_key_histogram_sampled(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int keyset,
+SL_API int sl_slide_key_histogram_sampled(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int keyset,
                                    const double* basis, const uint32_t* prefixes, int prefix_bits, int sample_log2,
                                    unsigned long long* hist, void* stream);
 /* One sweep for an order statistic whose neighbourhood is known: hist_below (device, 2 x 65536 + 2 uint64, ACCUMULATED
  * into) = per target the histogram of key - window_lo[t] over the keys in [window_lo[t], window_lo[t] + 65536), followed
  * by the two counts of keys below window_lo[t] (HOST pointer, 2 ordered-uint32 values). */
-int sl_slide_key_window(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int keyset,
+SL_API int sl_slide_key_window(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int keyset,
                         const double* basis, const uint32_t* window_lo, unsigned long long* hist_below, void* stream);
 /* min_out[t] (device uint32 x 2, set to 0xffffffff by the caller) = min(min_out[t], smallest key of target t
  * above key_ords[t]) (key_ords: HOST pointer, 2 values). */
-int sl_slide_key_next_above(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int keyset,
+SL_API int sl_slide_key_next_above(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int keyset,
                             const double* basis, const uint32_t* key_ords, uint32_t* min_out, void* stream);
 
 #ifdef __cplusplus

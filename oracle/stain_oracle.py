@@ -525,7 +525,9 @@ HED_FROM_RGB = np.linalg.inv(RGB_FROM_HED)
 def rgb2hed(rgb_u8_or_float: np.ndarray, mode: str = "0.18") -> np.ndarray:
     x = rgb_u8_or_float
     x = x.astype(np.float64) / 255.0 if x.dtype == np.uint8 else x.astype(np.float64)
-    if mode == "0.17":                   # -log10(rgb + 2) @ hed_from_rgb (from memory; unpinned)
+    if mode == "0.17":                   # presumed <= 0.17: -ln(rgb + 2) @ hed_from_rgb (from memory; unpinned)
+        return (-np.log(x + 2.0)) @ HED_FROM_RGB
+    if mode == "experimental_log10":     # the same with base-10 logarithms (round 1's reading; unpinned)
         return (-np.log10(x + 2.0)) @ HED_FROM_RGB
     x = np.maximum(x, 1e-6)
     st = (np.log(x) / np.log(1e-6)) @ HED_FROM_RGB
@@ -535,7 +537,9 @@ def rgb2hed(rgb_u8_or_float: np.ndarray, mode: str = "0.18") -> np.ndarray:
 
 
 def hed2rgb(hed: np.ndarray, mode: str = "0.18") -> np.ndarray:
-    if mode == "0.17":
+    if mode == "0.17":                   # exp(.) - 2, rescale_intensity(in_range=(-1, 1)) = clip to [-1, 1]; the caller clips to [0, 1]
+        return np.clip(np.exp(-(hed @ RGB_FROM_HED)) - 2.0, 0, 1)
+    if mode == "experimental_log10":
         return np.clip(10.0 ** (-(hed @ RGB_FROM_HED)) - 2.0, 0, 1)
     log_rgb = -(hed * (-np.log(1e-6))) @ RGB_FROM_HED
     return np.clip(np.exp(log_rgb), 0, 1)

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libstainlib_hip.so")
+# STAINLIB_HIP_LIB: development override (tools/ load the -DSL_DEVTOOLS build, libstainlib_hip_dev.so, through it)
+LIB_PATH = os.environ.get("STAINLIB_HIP_LIB") or os.path.join(_HERE, "csrc", "libstainlib_hip.so")
 
 
 class SlProfile(C.Structure):
@@ -40,6 +41,7 @@ class SlParams(C.Structure):
         ("schedule", C.c_int32),
         ("dl_tol", C.c_double),
         ("profile", C.POINTER(SlProfile)),
+        ("fallbacks_out", C.c_void_p),
     ]
 
 
@@ -48,7 +50,10 @@ class StainlibHipError(RuntimeError):
 
 
 # ops (sl_workspace_bytes)
-OP_MACENKO_FIT, OP_MACENKO_TRANSFORM, OP_VAHADANE_FIT, OP_VAHADANE_TRANSFORM, OP_HED_AUGMENT, OP_STAIN_AUGMENT, OP_TILE_MOMENTS = range(1, 8)
+(OP_MACENKO_FIT, OP_MACENKO_TRANSFORM, OP_VAHADANE_FIT, OP_VAHADANE_TRANSFORM, OP_HED_AUGMENT, OP_STAIN_AUGMENT, OP_TILE_MOMENTS,
+ OP_LAB_STATS) = range(1, 9)
+# skimage semantics of sl_hed_augment (only 0.18 is golden-pinned)
+HED_SKIMAGE_018, HED_SKIMAGE_019, HED_SKIMAGE_017, HED_EXPERIMENTAL_LOG10 = range(4)
 # selection key sets of the pooled slide-level mode (two targets each)
 KEYSET_ANGLE, KEYSET_CONC = range(2)
 # per-tile status
@@ -72,6 +77,15 @@ _SIGNATURES = {
     "sl_tissue_mask": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_double, _P, _P, _P]),
     "sl_concentrations": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_double, _P, _P]),
     "sl_grayscale_augment": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "sl_od_to_rgb": (C.c_int, [_P, C.c_size_t, _P, _P, _P]),
+    "sl_rgb_to_lab8": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "sl_lab8_to_rgb": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "sl_lab_split": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "sl_lab_merge": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "sl_standardize_brightness": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_size_t, _P]),
+    "sl_reinhard_stats": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_size_t, _P]),
+    "sl_reinhard_transform": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_double, _P, _P, C.c_size_t, _P]),
+    "sl_luminosity_standardize": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_double, _P, _P, C.c_size_t, _P]),
     "sl_tile_moments": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(SlParams), _P, _P, C.c_size_t, _P]),
     "sl_slide_key_histogram": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(SlParams), C.c_int, C.POINTER(C.c_double),
                                           C.POINTER(C.c_uint32), C.c_int, _P, _P]),

@@ -54,9 +54,10 @@ def _checked(title, rng, lowest):
 class HedColorAugmenter(ColorAugmenterBase):
     """Colour perturbation in HED space: value * (1 + sigma) + bias per channel (augmenter.py:86-344).
 
-    ``skimage_mode`` selects the rgb2hed/hed2rgb semantics: "0.18" (default, golden-pinned), "0.19"
-    (stains clamped at zero after separation) or "0.17" (the release the reference's environment.yml pins:
-    -log10(rgb + 2) and 10^x - 2; restated from memory, checked against the CPU restatement only)."""
+    ``skimage_mode`` selects the rgb2hed/hed2rgb semantics.  Only "0.18" (default) is pinned by vectors from a real
+    scikit-image; the others are restated from memory and checked against the CPU restatement only: "0.19" (stains clamped
+    at zero after separation), "0.17" (presumed behaviour of the release the reference's environment.yml pins:
+    -ln(rgb + 2) and exp(x) - 2, clipped) and "experimental_log10" (the same with base-10 logarithms)."""
 
     def __init__(self, haematoxylin_sigma_range, haematoxylin_bias_range, eosin_sigma_range, eosin_bias_range,
                  dab_sigma_range, dab_bias_range, cutoff_range, skimage_mode="0.18"):
@@ -70,9 +71,10 @@ class HedColorAugmenter(ColorAugmenterBase):
         self._biases = [r[0] if r is not None else 0.0 for r in self._bias_ranges]
         cut = _checked("Cutoff", cutoff_range, 0.0)
         self._cutoff_range = cut if cut is not None else [0.0, 1.0]
-        if skimage_mode not in ("0.18", "0.19", "0.17"):
-            raise ValueError("skimage_mode must be '0.17', '0.18' or '0.19'")
-        self._skimage_mode = {"0.18": 0, "0.19": 1, "0.17": 2}[skimage_mode]
+        modes = {"0.18": 0, "0.19": 1, "0.17": 2, "experimental_log10": 3}
+        if skimage_mode not in modes:
+            raise ValueError("skimage_mode must be one of " + ", ".join(repr(m) for m in modes))
+        self._skimage_mode = modes[skimage_mode]
 
     def randomize(self):
         """Six draws from the global numpy stream: sigma H, E, D then bias H, E, D (augmenter.py:333-344)."""
@@ -94,9 +96,22 @@ class HedColorAugmenter(ColorAugmenterBase):
             return out[0].cpu().numpy() if int(applied[0]) else patch
         if not is_uint8_image(patch):
             raise TypeError("HedColorAugmenter.transform expects a uint8 or float (H, W, 3) ndarray")
-        out, applied = engine.hed_augment(_to_device(patch), [self._sigmas], [self._biases],
-                                          cutoff=self._cutoff_range, skimage_mode=self._skimage_mode)
-        if int(applied[0]) == 0:
+        dev = _to_device(patch)
+        out, applied, sums = engine.hed_augment(dev, [self._sigmas], [self._biases], cutoff=self._cutoff_range,
+                                                skimage_mode=self._skimage_mode, want_sums=True)
+        ok = bool(int(applied[0]))
+        # The device tests the EXACT mean (integer byte sum); the reference tests np.mean of the float32 image / 255
+        # (augmenter.py:291-293), which carries ~1e-7 of rounding.  Within 1e-6 of a bound the reference's own value decides.
+        exact = float(int(sums[0])) / patch.size / 255.0
+        lo, hi = self._cutoff_range
+        if min(abs(exact - lo), abs(exact - hi)) <= 1e-6 * max(abs(lo), abs(hi), 1e-30):
+            ref_mean = np.mean(a=patch.astype(dtype=np.float32)) / 255.0
+            ref_ok = bool(lo <= ref_mean <= hi)
+            if ref_ok and not ok:                                     # transform after all: no cutoff this time
+                out, _ = engine.hed_augment(dev, [self._sigmas], [self._biases], cutoff=(-np.inf, np.inf),
+                                            skimage_mode=self._skimage_mode)
+            ok = ref_ok
+        if not ok:
             return patch                                              # augmenter.py:331
         return out[0].cpu().numpy()
 

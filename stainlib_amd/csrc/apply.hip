@@ -24,7 +24,7 @@ extern "C" int sl_normalize_apply(const uint8_t* rgb, uint8_t* out, int n, int h
 }
 
 extern "C" int sl_stain_augment(const uint8_t* rgb, uint8_t* out, int n, int h, int w, const double* M,
-                                const float* alpha_beta, int augment_background, const SlParams* params,
+                                const double* alpha_beta, int augment_background, const SlParams* params,
                                 void* stream) {
     if (!rgb || !out || !M || !alpha_beta || n <= 0 || h <= 0 || w <= 0) return SL_ERR_BADARG;
     SlParams p;
@@ -33,12 +33,13 @@ extern "C" int sl_stain_augment(const uint8_t* rgb, uint8_t* out, int n, int h, 
     const long P = (long)h * w;
     if (P > (1L << 30)) return SL_ERR_BADARG;
     int parts = parts_for(P);
+    const int max_grid = max_resident_grid();
     {   // persistent workgroups walk tiles x parts items: no more parts than it takes to give every workgroup ~4 items
-        const long want = (4L * 512 + n - 1) / n;
+        const long want = (4L * max_grid + n - 1) / n;
         if (parts > want) parts = (int)(want < 1 ? 1 : want);
     }
     const long items = (long)n * parts;
-    const dim3 grid((unsigned)(items < 512 ? items : 512)), block(kAugThreads);
+    const dim3 grid((unsigned)(items < max_grid ? items : max_grid)), block(kAugThreads);
     const uint32_t y_lim = y_limit_for_threshold(p.luminosity_threshold);
     hipStream_t s = (hipStream_t)stream;
     if (aligned4(rgb, P) && aligned4(out, P))

@@ -396,7 +396,7 @@ constexpr int kAugThreads = 512;
 template <bool ALIGNED>
 static __global__ __launch_bounds__(kAugThreads, 4) void k_stain_augment(const uint8_t* __restrict__ rgb, uint8_t* __restrict__ out,
                                                        int P, int parts, int n_items, const double* __restrict__ M,
-                                                       const float* __restrict__ alpha_beta, int augment_background,
+                                                       const double* __restrict__ alpha_beta, int augment_background,
                                                        uint32_t y_lim, double lam) {
     __shared__ RowTab s_tab;
     s_tab.fill_b();
@@ -416,8 +416,8 @@ static __global__ __launch_bounds__(kAugThreads, 4) void k_stain_augment(const u
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int c = 0; c < 3; ++c) K.q[i][c] = in_vgpr((float)(-1.4426950408889634 * M[6 * (size_t)tile + 3 * i + c]));
-        K.al0 = in_vgpr(alpha_beta[4 * (size_t)tile + 0]); K.be0 = in_vgpr(alpha_beta[4 * (size_t)tile + 1]);
-        K.al1 = in_vgpr(alpha_beta[4 * (size_t)tile + 2]); K.be1 = in_vgpr(alpha_beta[4 * (size_t)tile + 3]);
+        K.al0 = in_vgpr((float)alpha_beta[4 * (size_t)tile + 0]); K.be0 = in_vgpr((float)alpha_beta[4 * (size_t)tile + 1]);
+        K.al1 = in_vgpr((float)alpha_beta[4 * (size_t)tile + 2]); K.be1 = in_vgpr((float)alpha_beta[4 * (size_t)tile + 3]);
         K.ylimf = in_vgpr((float)y_lim - 2048.0f);
         const int c0 = min(nch, part * span), c1 = min(nch, c0 + span);
         if (c0 >= c1) continue;

@@ -26,6 +26,18 @@ uint32_t y_limit_for_threshold(double luminosity_threshold) {
     return (uint32_t)(best + 1) << 12;
 }
 
+// Resident persistent-sweep workgroups of the current device: 2 per compute unit (512 threads, 128 VGPRs, < 80 KB of LDS
+// each; 256 CUs on MI355X -- queried, not assumed: a partitioned or smaller part gets the grid it can hold).  Falls back
+// to 256 CUs when no device is visible (sl_workspace_bytes is host-only and must answer without one).
+int max_resident_grid() {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+        (void)hipGetLastError();
+        cus = 256;
+    }
+    return 2 * cus;
+}
+
 }  // namespace sl
 
 extern "C" int sl_version(void) { return SL_VERSION; }

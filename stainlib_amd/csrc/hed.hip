@@ -7,14 +7,15 @@
 // so a pixel costs 3 LDS lookups, 9 FMA, 3 exp: the sweep is HBM-bound at 3 B read + 3 B written.
 // The cutoff test needs the tile mean BEFORE the transform; instead of a separate 3 B/px sweep the
 // transform runs speculatively while the same sweep sums the bytes, and a fix-up kernel copies the
-// (rare) tiles that fail the test.  >=0.19 semantics (stains clamped at 0) keep the two products apart;
-// <=0.17 semantics (the version environment.yml:107 pins: log10(rgb+2), 10^x - 2) fold the same way with another table.
+// (rare) tiles that fail the test.  >=0.19 semantics (stains clamped at 0) keep the two products apart; the presumed
+// <=0.17 semantics (the version environment.yml:107 pins: -ln(rgb+2), exp(.) - 2; restated from memory, unpinned) fold the
+// same way with another table and another weight on the bias term; the base-10 reading of it is kept as an experiment.
 #include "apply_kernels.hpp"
 #include "sl_host.hpp"
 
 namespace sl {
 
-struct HedConst { double H[9]; double R[9]; };   // hed_from_rgb, rgb_from_hed (row-major)
+struct HedConst { double H[9]; double R[9]; double log2_base; };   // hed_from_rgb, rgb_from_hed (row-major); MODE 2: log2 of the logarithm's base
 
 template <int MODE, bool ALIGNED>
 static __global__ __launch_bounds__(kWG) void k_hed(const uint8_t* __restrict__ rgb, uint8_t* __restrict__ out, int P,
@@ -27,7 +28,7 @@ static __global__ __launch_bounds__(kWG) void k_hed(const uint8_t* __restrict__ 
     const int tile = blockIdx.x / parts, part = blockIdx.x % parts;
     const double Ladj = log(1e-6);
     if (MODE == 2) {
-        s_x[tid] = (float)log2((double)tid / 255.0 + 2.0);                 // scikit-image <= 0.17: log10(rgb + 2), kept in base 2
+        s_x[tid] = (float)log2((double)tid / 255.0 + 2.0);                 // scikit-image <= 0.17: log(rgb + 2), kept in base 2
     } else {
         const double v = tid == 0 ? 1e-6 : fmax((double)tid / 255.0, 1e-6);
         s_x[tid] = (float)log(v);
@@ -39,8 +40,8 @@ static __global__ __launch_bounds__(kWG) void k_hed(const uint8_t* __restrict__ 
     const double* bs = bias + 3 * (size_t)tile;
     const double kL2E = 1.4426950408889634;
     if (MODE == 0 || MODE == 2) {
-        // MODE 2 (<= 0.17): stains = -log10(x+2) @ H, rgb' = 10^(-stains' @ R) - 2, i.e. in base 2
-        //     log2(rgb'+2) = log2(x+2) @ (H diag(1+sigma) R) - log2(10) * (bias @ R)
+        // MODE 2 (<= 0.17): stains = -log_B(x+2) @ H, rgb' = B^(-stains' @ R) - 2 (B = e, or 10 in the experimental reading), i.e.
+        //     log2(rgb'+2) = log2(x+2) @ (H diag(1+sigma) R) - log2(B) * (bias @ R)
 #pragma unroll
         for (int k = 0; k < 3; ++k)
 #pragma unroll
@@ -53,7 +54,7 @@ static __global__ __launch_bounds__(kWG) void k_hed(const uint8_t* __restrict__ 
         for (int c = 0; c < 3; ++c) {
             double acc = 0;
             for (int j = 0; j < 3; ++j) acc += bs[j] * hc.R[3 * j + c];
-            b[c] = in_vgpr((float)(MODE == 2 ? -3.321928094887362 * acc : Ladj * acc * kL2E));
+            b[c] = in_vgpr((float)(MODE == 2 ? -hc.log2_base * acc : Ladj * acc * kL2E));
         }
     } else {
 #pragma unroll
@@ -168,7 +169,8 @@ static __global__ __launch_bounds__(kWG) void k_hed_f64(const double* __restrict
         const double r = src[3 * (size_t)p], g = src[3 * (size_t)p + 1], b = src[3 * (size_t)p + 2];
         acc += r + g + b;
         double x[3];
-        if (MODE == 2) { x[0] = -log10(r + 2.0); x[1] = -log10(g + 2.0); x[2] = -log10(b + 2.0); }       // <= 0.17
+        if (MODE == 2) { x[0] = -log(r + 2.0); x[1] = -log(g + 2.0); x[2] = -log(b + 2.0); }             // presumed <= 0.17
+        else if (MODE == 3) { x[0] = -log10(r + 2.0); x[1] = -log10(g + 2.0); x[2] = -log10(b + 2.0); }   // experimental base-10 reading
         else { x[0] = log(fmax(r, 1e-6)) / Ladj; x[1] = log(fmax(g, 1e-6)) / Ladj; x[2] = log(fmax(b, 1e-6)) / Ladj; }
         double st[3];
 #pragma unroll
@@ -181,6 +183,8 @@ static __global__ __launch_bounds__(kWG) void k_hed_f64(const double* __restrict
         for (int c = 0; c < 3; ++c) {
             double v;
             if (MODE == 2) {
+                v = exp(-(st[0] * hc.R[c] + st[1] * hc.R[3 + c] + st[2] * hc.R[6 + c])) - 2.0;
+            } else if (MODE == 3) {
                 v = pow(10.0, -(st[0] * hc.R[c] + st[1] * hc.R[3 + c] + st[2] * hc.R[6 + c])) - 2.0;
             } else {
                 const double lr = -(st[0] * (-Ladj)) * hc.R[c] - (st[1] * (-Ladj)) * hc.R[3 + c] - (st[2] * (-Ladj)) * hc.R[6 + c];
@@ -232,7 +236,7 @@ extern "C" int sl_hed_augment(const uint8_t* rgb, uint8_t* out, int n, int h, in
                               const double* bias, double cutoff_lo, double cutoff_hi, int skimage_mode,
                               int32_t* applied, void* workspace, size_t workspace_bytes, void* stream) {
     if (!rgb || !out || !sigma || !bias || n <= 0 || h <= 0 || w <= 0) return SL_ERR_BADARG;
-    if (skimage_mode != SL_HED_SKIMAGE_018 && skimage_mode != SL_HED_SKIMAGE_019 && skimage_mode != SL_HED_SKIMAGE_017) return SL_ERR_BADARG;
+    if (skimage_mode < SL_HED_SKIMAGE_018 || skimage_mode > SL_HED_EXPERIMENTAL_LOG10) return SL_ERR_BADARG;
     const long P = (long)h * w;
     if (P > (1L << 30)) return SL_ERR_BADARG;
     if (!workspace || workspace_bytes < sizeof(unsigned long long) * (size_t)n || ((uintptr_t)workspace & 7u))
@@ -242,6 +246,7 @@ extern "C" int sl_hed_augment(const uint8_t* rgb, uint8_t* out, int n, int h, in
     const double R[9] = {0.65, 0.70, 0.29, 0.07, 0.99, 0.11, 0.27, 0.57, 0.78};
     for (int i = 0; i < 9; ++i) hc.R[i] = R[i];
     inv3(R, hc.H);
+    hc.log2_base = skimage_mode == SL_HED_EXPERIMENTAL_LOG10 ? 3.321928094887362 : 1.4426950408889634;
     hipStream_t s = (hipStream_t)stream;
     unsigned long long* sums = (unsigned long long*)workspace;
     SL_HIP_TRY(hipMemsetAsync(sums, 0, sizeof(unsigned long long) * (size_t)n, s));
@@ -262,7 +267,7 @@ extern "C" int sl_hed_augment_f64(const double* rgb, double* out, int n, int h, 
                                   const double* bias, double cutoff_lo, double cutoff_hi, int skimage_mode,
                                   int32_t* applied, void* workspace, size_t workspace_bytes, void* stream) {
     if (!rgb || !out || !sigma || !bias || n <= 0 || h <= 0 || w <= 0) return SL_ERR_BADARG;
-    if (skimage_mode != SL_HED_SKIMAGE_018 && skimage_mode != SL_HED_SKIMAGE_019 && skimage_mode != SL_HED_SKIMAGE_017) return SL_ERR_BADARG;
+    if (skimage_mode < SL_HED_SKIMAGE_018 || skimage_mode > SL_HED_EXPERIMENTAL_LOG10) return SL_ERR_BADARG;
     const long P = (long)h * w;
     if (P > (1L << 30)) return SL_ERR_BADARG;
     if (!workspace || workspace_bytes < sizeof(double) * (size_t)n || ((uintptr_t)workspace & 7u)) return SL_ERR_WORKSPACE;
@@ -270,6 +275,7 @@ extern "C" int sl_hed_augment_f64(const double* rgb, double* out, int n, int h, 
     const double R[9] = {0.65, 0.70, 0.29, 0.07, 0.99, 0.11, 0.27, 0.57, 0.78};
     for (int i = 0; i < 9; ++i) hc.R[i] = R[i];
     inv3(R, hc.H);
+    hc.log2_base = 0.0;
     hipStream_t s = (hipStream_t)stream;
     double* sums = (double*)workspace;
     SL_HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * (size_t)n, s));
@@ -277,7 +283,8 @@ extern "C" int sl_hed_augment_f64(const double* rgb, double* out, int n, int h, 
     const dim3 grid((unsigned)((long)n * parts)), block(kWG);
     if (skimage_mode == SL_HED_SKIMAGE_018) hipLaunchKernelGGL((k_hed_f64<0>), grid, block, 0, s, rgb, out, (int)P, parts, sigma, bias, hc, sums);
     else if (skimage_mode == SL_HED_SKIMAGE_019) hipLaunchKernelGGL((k_hed_f64<1>), grid, block, 0, s, rgb, out, (int)P, parts, sigma, bias, hc, sums);
-    else hipLaunchKernelGGL((k_hed_f64<2>), grid, block, 0, s, rgb, out, (int)P, parts, sigma, bias, hc, sums);
+    else if (skimage_mode == SL_HED_SKIMAGE_017) hipLaunchKernelGGL((k_hed_f64<2>), grid, block, 0, s, rgb, out, (int)P, parts, sigma, bias, hc, sums);
+    else hipLaunchKernelGGL((k_hed_f64<3>), grid, block, 0, s, rgb, out, (int)P, parts, sigma, bias, hc, sums);
     hipLaunchKernelGGL(k_hed_f64_fixup, grid, block, 0, s, rgb, out, (int)P, parts, sums, cutoff_lo, cutoff_hi, applied);
     return launch_status();
 }

@@ -15,18 +15,25 @@ constexpr size_t kGroupBytes = (size_t)2 << 30;   // uint8 bytes of one tile gro
 
 constexpr int kFusedMinTiles = 448;         // measured crossover (tools/crossover.py): below it one launch per phase wins
 constexpr int kFusedMinTilesSmall = 288;    // ... for tiles below 512 Ki pixels (256x256: 0.18 vs 0.20 ms at 256 tiles, 0.28 vs 0.25 at 384)
-constexpr int kFusedMaxGrid = 512;          // 2 resident 512-thread workgroups per CU x 256 CUs
 constexpr int kDictFusedMinTiles = 480;     // Vahadane: below it the dictionary sweeps run one launch per phase too (measured: 1024^2 tiles 5.3 vs
                                             // 6.3 ms at 384, 6.7 vs 6.6 at 512; a fused grid below 512 workgroups leaves slots idle)
 constexpr int kDictFusedMinTilesSmall = 192;   // ... for tiles below 512 Ki pixels (512^2: 0.82 vs 1.34 ms at 64 tiles, 1.53 vs 1.46 at 256)
 constexpr int kDictFixedSweeps = 4;         // full sweeps launched after the sample stage; tiles that need more finish in k_dict_tail
 
-unsigned g_debug_dyn_lds = 0;          // development aid: extra dynamic LDS per sweep workgroup (occupancy experiments)
+#ifdef SL_DEVTOOLS                       // development build only (libstainlib_hip_dev.so, see tools/README.md): process-global knobs
+unsigned g_debug_dyn_lds = 0;            // extra dynamic LDS per sweep workgroup (occupancy experiments)
+long long* g_phase_clock = nullptr;      // see sl_debug_set_phase_clock
+int g_debug_stop = 0;
+#define SL_DYN_LDS g_debug_dyn_lds
+#else
+#define SL_DYN_LDS 0u
+#endif
 
 struct Layout {
     int parts, stride_log2, n_sample, G, cap_raw, cap_list;
     bool fused;
     int grid;                               // fused: workgroups launched
+    int max_grid;                           // resident sweep workgroups of the device
     size_t off_M, off_maxC, off_status, off_partials, off_sample, off_cand, off_list, off_state, off_dstate, off_diag, total;
 };
 
@@ -34,9 +41,10 @@ size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 Layout make_layout(int n, long P, int method = kMethodMacenko, int schedule = 0) {
     Layout L;
+    L.max_grid = max_resident_grid();
     L.parts = parts_for(P);
     {   // the persistent sweep kernels walk tiles x parts items: no more parts than it takes to give every workgroup ~4 items
-        const long want = (4L * kFusedMaxGrid + n - 1) / (n > 0 ? n : 1);
+        const long want = (4L * L.max_grid + n - 1) / (n > 0 ? n : 1);
         if (L.parts > want) L.parts = (int)(want < 1 ? 1 : want);
     }
     L.stride_log2 = 6;
@@ -50,7 +58,7 @@ Layout make_layout(int n, long P, int method = kMethodMacenko, int schedule = 0)
     L.G = (int)g;
     const int min_fused = method == kMethodVahadane ? (P >= (1L << 19) ? kDictFusedMinTiles : kDictFusedMinTilesSmall) : (P >= (1L << 19) ? kFusedMinTiles : kFusedMinTilesSmall);
     L.fused = (schedule == 2) || (schedule != 1 && n >= min_fused);
-    L.grid = n < kFusedMaxGrid ? n : kFusedMaxGrid;
+    L.grid = n < L.max_grid ? n : L.max_grid;
     const size_t slots = L.fused ? (size_t)L.grid : (size_t)L.G;     // candidate buffers: per workgroup / per tile of a group
     size_t o = 0;
     L.off_M = o;        o = align_up(o + sizeof(double) * 6 * (size_t)n);
@@ -103,28 +111,28 @@ int run_stats_group(const uint8_t* rgb, int g0, int m, long P, const SlParams& p
     StatsArgs a = stats_args(rgb, g0, m, P, p, L, ws);
     const bool al = aligned4(a.rgb, P);
     const long items = (long)m * L.parts;
-    const dim3 gs((unsigned)(items < kFusedMaxGrid ? items : kFusedMaxGrid)), bs(kSweepThreads), gf((unsigned)m), bf(kFinishThreads);
+    const dim3 gs((unsigned)(items < L.max_grid ? items : L.max_grid)), bs(kSweepThreads), gf((unsigned)m), bf(kFinishThreads);
     SlProfile* prof = p.profile;
     {
         ProfScope ps(prof, SL_PROF_MOMENTS, m, s);
-        if (al) hipLaunchKernelGGL((k_moments<true>), gs, bs, g_debug_dyn_lds, s, a);
-        else    hipLaunchKernelGGL((k_moments<false>), gs, bs, g_debug_dyn_lds, s, a);
+        if (al) hipLaunchKernelGGL((k_moments<true>), gs, bs, SL_DYN_LDS, s, a);
+        else    hipLaunchKernelGGL((k_moments<false>), gs, bs, SL_DYN_LDS, s, a);
     }
     { ProfScope ps(prof, SL_PROF_FINISH, m, s); hipLaunchKernelGGL(k_finish_moments, gf, bf, 0, s, a); }
     {
         ProfScope ps(prof, SL_PROF_SELECT_ANGLE, m, s);
-        if (al) hipLaunchKernelGGL((k_select<kStageAngle, true>), gs, bs, g_debug_dyn_lds, s, a);
-        else    hipLaunchKernelGGL((k_select<kStageAngle, false>), gs, bs, g_debug_dyn_lds, s, a);
+        if (al) hipLaunchKernelGGL((k_select<kStageAngle, true>), gs, bs, SL_DYN_LDS, s, a);
+        else    hipLaunchKernelGGL((k_select<kStageAngle, false>), gs, bs, SL_DYN_LDS, s, a);
     }
     { ProfScope ps(prof, SL_PROF_FINISH, m, s); hipLaunchKernelGGL(k_finish_angle, gf, bf, 0, s, a); }
     {
         ProfScope ps(prof, SL_PROF_SELECT_CONC, m, s);
-        if (al) hipLaunchKernelGGL((k_select<kStageConc, true>), gs, bs, g_debug_dyn_lds, s, a);
-        else    hipLaunchKernelGGL((k_select<kStageConc, false>), gs, bs, g_debug_dyn_lds, s, a);
+        if (al) hipLaunchKernelGGL((k_select<kStageConc, true>), gs, bs, SL_DYN_LDS, s, a);
+        else    hipLaunchKernelGGL((k_select<kStageConc, false>), gs, bs, SL_DYN_LDS, s, a);
     }
     {
         ProfScope ps(prof, SL_PROF_FINISH, m, s);
-        hipLaunchKernelGGL(k_finish_conc, gf, bf, 0, s, a, M_all, maxC_all, status_all, g0);
+        hipLaunchKernelGGL(k_finish_conc, gf, bf, 0, s, a, M_all, maxC_all, status_all, p.fallbacks_out, g0);
     }
     return launch_status();
 }
@@ -136,7 +144,7 @@ int run_dict_group(const uint8_t* rgb, int g0, int m, long P, const SlParams& p,
     a.sweeps_out = sweeps_out;
     const bool al = aligned4(a.rgb, P);
     const long items = (long)m * L.parts;
-    const dim3 gs((unsigned)(items < kFusedMaxGrid ? items : kFusedMaxGrid)), bs(kSweepThreads), gf((unsigned)m), bf(kFinishThreads);
+    const dim3 gs((unsigned)(items < L.max_grid ? items : L.max_grid)), bs(kSweepThreads), gf((unsigned)m), bf(kFinishThreads);
     SlProfile* prof = p.profile;
     {
         ProfScope ps(prof, SL_PROF_DICT, m, s);
@@ -165,13 +173,10 @@ int run_dict_group(const uint8_t* rgb, int g0, int m, long P, const SlParams& p,
     }
     {
         ProfScope ps(prof, SL_PROF_FINISH, m, s);
-        hipLaunchKernelGGL(k_finish_conc, gf, bf, 0, s, a, M_all, maxC_all, status_all, g0);
+        hipLaunchKernelGGL(k_finish_conc, gf, bf, 0, s, a, M_all, maxC_all, status_all, p.fallbacks_out, g0);
     }
     return launch_status();
 }
-
-long long* g_phase_clock = nullptr;   // development aid, see sl_debug_set_phase_clock
-int g_debug_stop = 0;
 
 // The persistent schedule: one launch for the whole batch (fit only when out == nullptr).
 int run_fused(int method, const uint8_t* rgb, uint8_t* out, int n, long P, const SlParams& p, const Layout& L, char* ws,
@@ -197,16 +202,18 @@ int run_fused(int method, const uint8_t* rgb, uint8_t* out, int n, long P, const
     a.M_out = M_all;
     a.maxC_out = maxC_all;
     a.status_out = status_all;
-    a.diag_out = (int32_t*)(ws + L.off_diag);
+    a.diag_out = p.fallbacks_out ? p.fallbacks_out : (int32_t*)(ws + L.off_diag);
+#ifdef SL_DEVTOOLS
     a.phase_clock = g_phase_clock;
     a.debug_stop = g_debug_stop;
+#endif
     a.dl_lambda = p.dl_lambda;
     a.dl_tol = p.dl_tol;
     a.dl_max_sweeps = p.dl_max_sweeps > 0 ? p.dl_max_sweeps : 1;
     a.sweeps_out = sweeps_out;
     const bool al = aligned4(rgb, P) && (!out || aligned4(out, P));
     // Vahadane batches that cannot fill two workgroup slots per CU run one 1024-thread workgroup per tile instead
-    const bool wide = method == kMethodVahadane && n <= kFusedMaxGrid / 2;
+    const bool wide = method == kMethodVahadane && n <= L.max_grid / 2;
     const dim3 g((unsigned)L.grid), b(wide ? 1024 : kFusedThreads);
     ProfScope ps(p.profile, out ? SL_PROF_FUSED_TRANSFORM : SL_PROF_FUSED_FIT, n, s);
 #define SL_GO(M, T, A) hipLaunchKernelGGL((k_fused<M, T, A, kFusedThreads>), g, b, 0, s, a)
@@ -253,6 +260,8 @@ extern "C" size_t sl_workspace_bytes(int op, int n_tiles, int h, int w) {
         }
         case SL_OP_HED_AUGMENT:
             return (sizeof(unsigned long long) * (size_t)n_tiles + 255) & ~(size_t)255;
+        case SL_OP_LAB_STATS:
+            return lab_workspace_bytes(n_tiles);
         case SL_OP_TILE_MOMENTS:
             return (sizeof(double) * 10 * (size_t)parts_for((long)h * w) * (size_t)n_tiles + 255) & ~(size_t)255;
         default:
@@ -379,7 +388,10 @@ extern "C" int sl_vahadane_transform(const uint8_t* rgb, uint8_t* out, int n, in
     return SL_OK;
 }
 
-// Development aid (not part of the public header): where the per-tile state lives in the workspace.
+#ifdef SL_DEVTOOLS
+// Development aids, compiled ONLY into libstainlib_hip_dev.so (make dev): not part of the public header, backed by
+// process-global state, never in the product library (tests/test_host_api.py checks the export list).
+// where the per-tile state lives in the workspace
 extern "C" int sl_debug_layout(int n, int h, int w, size_t* off_state, size_t* sizeof_state, int* group,
                                size_t* off_diag, int* fused) {
     const Layout L = make_layout(n, (long)h * w);
@@ -408,3 +420,4 @@ extern "C" void sl_debug_bclk(unsigned long long* out, int reset) {
     if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(sl::g_bclk), z, 128); }
 }
 #endif
+#endif  // SL_DEVTOOLS

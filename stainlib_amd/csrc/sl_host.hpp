@@ -22,6 +22,12 @@ inline int launch_status() { return hip_err(hipGetLastError()); }
 // 0 means "no pixel is tissue".
 uint32_t y_limit_for_threshold(double luminosity_threshold);
 
+// resident persistent-sweep workgroups of the current device (2 per CU; see common.hip)
+int max_resident_grid();
+
+// workspace of the Lab family (lab.hip)
+size_t lab_workspace_bytes(int n_tiles);
+
 inline bool aligned4(const void* p, long pixels_per_tile) {
     return ((uintptr_t)p & 3u) == 0 && (pixels_per_tile & 3) == 0;
 }

@@ -147,6 +147,15 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_slide_keys(SlideArgs a, un
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if (ok[j]) process(ch[j], ccs[j], c1s[j]);
+            // parts longer than 8 x 64 rows (few tiles per launch: the host clamps parts to ~2048 / n): the wave walks on
+            // through its row class, so that the sample stays 1 row in 64 over the WHOLE part (not only its top)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (!ok[j]) continue;
+                const int tile = (it0 + j * (int)gridDim.x) / a.parts;
+                for (int cc = ccs[j] + 8 * 64 * 64; (cc & ~63) < c1s[j]; cc += 8 * 64 * 64)
+                    process(load_chunk_clamped<ALIGNED>(a.rgb + (size_t)tile * nbytes, nbytes, cc, c1s[j]), cc, c1s[j]);
+            }
         }
     } else {
         for (int item = blockIdx.x; item < a.n_items; item += gridDim.x) {
@@ -254,7 +263,7 @@ int fill_args(SlideArgs& a, const uint8_t* rgb, int n, int h, int w, const SlPar
     a.rgb = rgb;
     a.P = h * w;
     a.parts = parts_for((long)h * w);
-    const long want = (4L * 512 + n - 1) / n;                   // ~4 items per persistent workgroup
+    const long want = (4L * max_resident_grid() + n - 1) / n;   // ~4 items per persistent workgroup
     if (a.parts > want) a.parts = (int)(want < 1 ? 1 : want);
     a.n_items = n * a.parts;
     a.ylimf = (float)y_limit_for_threshold(p.luminosity_threshold) - 2048.0f;
@@ -268,7 +277,8 @@ int fill_args(SlideArgs& a, const uint8_t* rgb, int n, int h, int w, const SlPar
 
 template <int NEXT>
 void launch_keys(const SlideArgs& a, bool al, unsigned long long* hist, uint32_t* min_out, hipStream_t s) {
-    const dim3 g((unsigned)(a.n_items < 512 ? a.n_items : 512)), b(kSweepThreads);
+    const int mg = max_resident_grid();
+    const dim3 g((unsigned)(a.n_items < mg ? a.n_items : mg)), b(kSweepThreads);
     if (a.keyset == SL_KEYSET_ANGLE) {
         if (al) hipLaunchKernelGGL((k_slide_keys<SL_KEYSET_ANGLE, NEXT, true>), g, b, 0, s, a, hist, min_out);
         else    hipLaunchKernelGGL((k_slide_keys<SL_KEYSET_ANGLE, NEXT, false>), g, b, 0, s, a, hist, min_out);

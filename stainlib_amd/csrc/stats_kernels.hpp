@@ -178,22 +178,6 @@ __device__ __forceinline__ float ord2f(uint32_t o) {
     return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
 }
 
-// numpy.percentile(method='linear') position for n values (numpy/lib/function_base.py _quantile):
-// virtual index = n*q + (alpha + q*(1-alpha-beta)) - 1 with alpha = beta = 1.
-__device__ inline void percentile_pos(double n, double pct, long long& k, double& g) {
-    const double q = pct / 100.0;
-    double vi = n * q + (1.0 + q * (1.0 - 1.0 - 1.0)) - 1.0;
-    if (vi < 0) vi = 0;
-    if (vi > n - 1) vi = n - 1;
-    const double f = floor(vi);
-    k = (long long)f;
-    g = vi - f;
-}
-__device__ inline double np_lerp(double a, double b, double t) {
-    const double d = b - a;
-    return t >= 0.5 ? b - d * (1.0 - t) : a + d * t;
-}
-
 // ------------------------------------------------------------------------------------------
 // workgroup-level exact selection (any blockDim that is a multiple of 64)
 // ------------------------------------------------------------------------------------------
@@ -1746,7 +1730,7 @@ static __global__ __launch_bounds__(kFinishThreads) void k_finish_angle(StatsArg
 }
 
 static __global__ __launch_bounds__(kFinishThreads) void k_finish_conc(StatsArgs a, double* M_out, double* maxC_out,
-                                                                       int32_t* status_out, int tile0) {
+                                                                       int32_t* status_out, int32_t* fallbacks_out, int tile0) {
     __shared__ SmallTab s_tab;
     __shared__ SelScratch S;
     __shared__ float s_res[4];
@@ -1796,6 +1780,7 @@ static __global__ __launch_bounds__(kFinishThreads) void k_finish_conc(StatsArgs
     if (tid < 6 && M_out) M_out[(size_t)(tile0 + tile) * 6 + tid] = st.M[tid];
     if (tid < 2 && maxC_out) maxC_out[(size_t)(tile0 + tile) * 2 + tid] = st.maxC[tid];
     if (tid == 0 && status_out) status_out[tile0 + tile] = st.status;
+    if (tid == 0 && fallbacks_out) fallbacks_out[tile0 + tile] = bad ? 0 : st.fallbacks;
 }
 
 // ---- Vahadane, one launch per phase: k_dict<first> + k_dict_finish(first) [the sample stage runs inside it], then a
@@ -1978,8 +1963,10 @@ struct FusedArgs {
     double* maxC_out;        // [n_tiles][2]
     int32_t* status_out;     // [n_tiles]
     int32_t* diag_out;       // [n_tiles] fallbacks (may be NULL)
-    long long* phase_clock;  // [n_tiles][8] wall_clock64() at phase boundaries (development aid, may be NULL)
-    int debug_stop;          // development aid: leave the tile after phase marker debug_stop-1 (0 = run everything)
+#ifdef SL_DEVTOOLS
+    long long* phase_clock;  // [n_tiles][8] wall_clock64() at phase boundaries (development build only, may be NULL)
+    int debug_stop;          // development build only: leave the tile after phase marker debug_stop-1 (0 = run everything)
+#endif
     // Vahadane
     double dl_lambda;
     double dl_tol;
@@ -2044,7 +2031,11 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
 #endif
         int fallbacks = 0;
         int sweeps_used = 0;
+#ifdef SL_DEVTOOLS
 #define SL_PHASE(i) { if (a.phase_clock && tid == 0) a.phase_clock[(size_t)tile * 8 + (i)] = wall_clock64(); if (a.debug_stop == (i) + 1) { __syncthreads(); continue; } }
+#else
+#define SL_PHASE(i)
+#endif
 #ifdef SL_DEBUG_SUBCLK
 #define SL_SUB(j) { __syncthreads(); if (a.phase_clock && tid == 0) a.phase_clock[(size_t)a.n_tiles * 8 + (size_t)tile * 16 + (j)] = wall_clock64(); }
 #else

@@ -45,8 +45,21 @@ def make_params(**kw) -> _ffi.SlParams:
     return p
 
 
+def attach_fallbacks(params: _ffi.SlParams, n: int, device="cuda") -> torch.Tensor:
+    """Give ``params`` a device buffer of n int32 that sl_macenko_* / sl_vahadane_* fill with the per-tile count of order
+    statistics that needed the slow exact selection (SlParams.fallbacks_out; diagnostics only).  Returns the tensor --
+    keep it alive as long as ``params`` is used."""
+    t = torch.zeros((n,), dtype=torch.int32, device=device)
+    params.fallbacks_out = t.data_ptr()
+    return t
+
+
 class Workspace:
-    """Caller-owned scratch the library asks for via sl_workspace_bytes (grown on demand)."""
+    """Caller-owned scratch the library asks for via sl_workspace_bytes (grown on demand).
+
+    One Workspace must only ever be in use on ONE stream at a time: the kernels of a call keep their per-tile state in it.
+    Pass your own (``ws=``) to pin a buffer to a pipeline stage; without one every call takes a fresh block from torch's
+    caching allocator, which is stream-ordered -- two streams or threads can then never share scratch."""
 
     def __init__(self):
         self.buf = None
@@ -58,7 +71,13 @@ class Workspace:
         return self.buf
 
 
-_default_ws = Workspace()
+def _scratch(ws, op, n, h, w, device) -> torch.Tensor:
+    """The workspace of one call: the caller's Workspace, or a block of torch's caching allocator owned by the current
+    stream for the duration of the call's kernels (freed blocks are reused on the same stream only after them)."""
+    if ws is not None:
+        return ws.get(op, n, h, w, device)
+    need = int(_ffi.lib().sl_workspace_bytes(op, n, h, w))
+    return torch.empty(max(need, 256), dtype=torch.uint8, device=device)
 
 
 def normalize_apply(rgb, M_src, maxC_src, M_tgt, maxC_tgt, lasso_lambda=0.01, out=None, want_prequant=False):
@@ -85,7 +104,7 @@ def _fit(fn_name, op, rgb, params, ws, with_sweeps=False):
     M = torch.empty((n, 2, 3), dtype=torch.float64, device=dev)
     maxC = torch.empty((n, 2), dtype=torch.float64, device=dev)
     status = torch.empty((n,), dtype=torch.int32, device=dev)
-    wsb = (ws or _default_ws).get(op, n, h, w, dev)
+    wsb = _scratch(ws, op, n, h, w, dev)
     fn = getattr(_ffi.lib(), fn_name)
     if with_sweeps:
         sweeps = torch.empty((n,), dtype=torch.int32, device=dev)
@@ -119,7 +138,7 @@ def _transform(fn_name, op, rgb, M_tgt, maxC_tgt, params, out, ws):
     M = torch.empty((n, 2, 3), dtype=torch.float64, device=dev)
     maxC = torch.empty((n, 2), dtype=torch.float64, device=dev)
     status = torch.empty((n,), dtype=torch.int32, device=dev)
-    wsb = (ws or _default_ws).get(op, n, h, w, dev)
+    wsb = _scratch(ws, op, n, h, w, dev)
     code = getattr(_ffi.lib(), fn_name)(_ptr(rgb), _ptr(out), n, h, w, C.byref(p), _ptr(M_tgt), _ptr(maxC_tgt),
                                         _ptr(M), _ptr(maxC), _ptr(status), _ptr(wsb), wsb.numel(), _stream())
     _ffi.check(code, fn_name)
@@ -135,8 +154,8 @@ def vahadane_transform(rgb, M_tgt, maxC_tgt, params=None, out=None, ws=None):
     return _transform("sl_vahadane_transform", _ffi.OP_VAHADANE_TRANSFORM, rgb, M_tgt, maxC_tgt, params, out, ws)
 
 
-def hed_augment(rgb, sigma, bias, cutoff=(0.05, 0.95), skimage_mode=0, out=None, ws=None):
-    """Batched HedColorAugmenter.transform for uint8 tiles -> (out, applied (N,) i32)."""
+def hed_augment(rgb, sigma, bias, cutoff=(0.05, 0.95), skimage_mode=0, out=None, ws=None, want_sums=False):
+    """Batched HedColorAugmenter.transform for uint8 tiles -> (out, applied (N,) i32)[, exact byte sums (N,) int64]."""
     n, h, w = _check_tiles(rgb)
     dev = rgb.device
     sigma = _f64(sigma, (n, 3), dev)
@@ -144,10 +163,12 @@ def hed_augment(rgb, sigma, bias, cutoff=(0.05, 0.95), skimage_mode=0, out=None,
     if out is None:
         out = torch.empty_like(rgb)
     applied = torch.empty((n,), dtype=torch.int32, device=dev)
-    wsb = (ws or _default_ws).get(_ffi.OP_HED_AUGMENT, n, h, w, dev)
+    wsb = _scratch(ws, _ffi.OP_HED_AUGMENT, n, h, w, dev)
     _ffi.check(_ffi.lib().sl_hed_augment(_ptr(rgb), _ptr(out), n, h, w, _ptr(sigma), _ptr(bias), float(cutoff[0]),
                                          float(cutoff[1]), int(skimage_mode), _ptr(applied), _ptr(wsb), wsb.numel(),
                                          _stream()), "sl_hed_augment")
+    if want_sums:
+        return out, applied, wsb[:8 * n].view(torch.int64).clone()
     return out, applied
 
 
@@ -181,7 +202,7 @@ def stain_augment(rgb, M, alpha_beta, augment_background=False, params=None, out
     n, h, w = _check_tiles(rgb)
     dev = rgb.device
     M = _f64(M, (n, 2, 3), dev)
-    ab = torch.as_tensor(alpha_beta, dtype=torch.float32, device=dev).reshape(n, 4).contiguous()
+    ab = _f64(alpha_beta, (n, 4), dev)
     p = params if params is not None else _ffi.default_params()
     if out is None:
         out = torch.empty_like(rgb)
@@ -222,13 +243,109 @@ def concentrations(rgb, M, lasso_lambda=0.01):
     return Cout
 
 
+def od_to_rgb(od):
+    """convert_OD_to_RGB on a float64 CUDA tensor of any shape -> (uint8 tensor of the same shape, negative flag (1,) i32)."""
+    if not (od.is_cuda and od.dtype == torch.float64 and od.is_contiguous()):
+        raise ValueError("expected a contiguous CUDA float64 tensor")
+    out = torch.empty(od.shape, dtype=torch.uint8, device=od.device)
+    neg = torch.zeros((1,), dtype=torch.int32, device=od.device)
+    _ffi.check(_ffi.lib().sl_od_to_rgb(_ptr(od), od.numel(), _ptr(out), _ptr(neg), _stream()), "sl_od_to_rgb")
+    return out, neg
+
+
+# ---- OpenCV 8-bit Lab family (SURVEY 8f-3 / 8f-4; lab.hip) ---------------------------------------------------------------
+def rgb_to_lab8(rgb):
+    """cv2.cvtColor(COLOR_RGB2LAB) on uint8 tiles -> (N,H,W,3) uint8."""
+    n, h, w = _check_tiles(rgb)
+    out = torch.empty_like(rgb)
+    _ffi.check(_ffi.lib().sl_rgb_to_lab8(_ptr(rgb), _ptr(out), n, h, w, _stream()), "sl_rgb_to_lab8")
+    return out
+
+
+def lab8_to_rgb(lab):
+    """cv2.cvtColor(COLOR_LAB2RGB) on uint8 tiles."""
+    n, h, w = _check_tiles(lab)
+    out = torch.empty_like(lab)
+    _ffi.check(_ffi.lib().sl_lab8_to_rgb(_ptr(lab), _ptr(out), n, h, w, _stream()), "sl_lab8_to_rgb")
+    return out
+
+
+def lab_split(rgb):
+    """lab_split: three (N,H,W) float32 planes L8/2.55, a8-128, b8-128."""
+    n, h, w = _check_tiles(rgb)
+    I1, I2, I3 = (torch.empty((n, h, w), dtype=torch.float32, device=rgb.device) for _ in range(3))
+    _ffi.check(_ffi.lib().sl_lab_split(_ptr(rgb), n, h, w, _ptr(I1), _ptr(I2), _ptr(I3), _stream()), "sl_lab_split")
+    return I1, I2, I3
+
+
+def lab_merge(I1, I2, I3):
+    """merge_back: three (N,H,W) planes of one float dtype (float32 or float64) -> (N,H,W,3) uint8 RGB."""
+    if not (I1.dtype == I2.dtype == I3.dtype and I1.dtype in (torch.float32, torch.float64) and I1.shape == I2.shape == I3.shape
+            and I1.dim() == 3 and all(t.is_cuda and t.is_contiguous() for t in (I1, I2, I3))):
+        raise ValueError("expected three contiguous CUDA (N, H, W) planes of one float dtype")
+    n, h, w = I1.shape
+    out = torch.empty((n, h, w, 3), dtype=torch.uint8, device=I1.device)
+    _ffi.check(_ffi.lib().sl_lab_merge(_ptr(I1), _ptr(I2), _ptr(I3), 1 if I1.dtype == torch.float64 else 0, n, h, w, _ptr(out),
+                                       _stream()), "sl_lab_merge")
+    return out
+
+
+def standardize_brightness(rgb, out=None, ws=None):
+    """standardize_brightness per tile -> (out, p90 (N,) f64)."""
+    n, h, w = _check_tiles(rgb)
+    if out is None:
+        out = torch.empty_like(rgb)
+    p = torch.empty((n,), dtype=torch.float64, device=rgb.device)
+    wsb = _scratch(ws, _ffi.OP_LAB_STATS, n, h, w, rgb.device)
+    _ffi.check(_ffi.lib().sl_standardize_brightness(_ptr(rgb), _ptr(out), n, h, w, _ptr(p), _ptr(wsb), wsb.numel(), _stream()),
+               "sl_standardize_brightness")
+    return out, p
+
+
+def reinhard_stats(rgb, standardize=True, ws=None):
+    """(N, 8) float64 per tile: p90, mean L/a/b, std L/a/b (cv2.meanStdDev of the lab_split planes), tissue count."""
+    n, h, w = _check_tiles(rgb)
+    st = torch.empty((n, 8), dtype=torch.float64, device=rgb.device)
+    wsb = _scratch(ws, _ffi.OP_LAB_STATS, n, h, w, rgb.device)
+    _ffi.check(_ffi.lib().sl_reinhard_stats(_ptr(rgb), n, h, w, 1 if standardize else 0, _ptr(st), _ptr(wsb), wsb.numel(), _stream()),
+               "sl_reinhard_stats")
+    return st
+
+
+def reinhard_transform(rgb, target_means, target_stds, mask_background=False, luminosity_threshold=0.8, out=None, ws=None):
+    """Batched ReinhardStainNormalizer.transform -> (out, stats (N, 8))."""
+    n, h, w = _check_tiles(rgb)
+    dev = rgb.device
+    tm, ts = _f64(target_means, (3,), dev), _f64(target_stds, (3,), dev)
+    if out is None:
+        out = torch.empty_like(rgb)
+    st = torch.empty((n, 8), dtype=torch.float64, device=dev)
+    wsb = _scratch(ws, _ffi.OP_LAB_STATS, n, h, w, dev)
+    _ffi.check(_ffi.lib().sl_reinhard_transform(_ptr(rgb), _ptr(out), n, h, w, _ptr(tm), _ptr(ts), 1 if mask_background else 0,
+                                                float(luminosity_threshold), _ptr(st), _ptr(wsb), wsb.numel(), _stream()),
+               "sl_reinhard_transform")
+    return out, st
+
+
+def luminosity_standardize(rgb, percentile=95, out=None, ws=None):
+    """Batched LuminosityStandardizer.standardize -> (out, p (N,) f64)."""
+    n, h, w = _check_tiles(rgb)
+    if out is None:
+        out = torch.empty_like(rgb)
+    p = torch.empty((n,), dtype=torch.float64, device=rgb.device)
+    wsb = _scratch(ws, _ffi.OP_LAB_STATS, n, h, w, rgb.device)
+    _ffi.check(_ffi.lib().sl_luminosity_standardize(_ptr(rgb), _ptr(out), n, h, w, float(percentile), _ptr(p), _ptr(wsb),
+                                                    wsb.numel(), _stream()), "sl_luminosity_standardize")
+    return out, p
+
+
 # ---- pooled slide-level mode: per-process reductions (combined over ranks in stainlib_amd.distributed) -------------
 def tile_moments(rgb, params=None, ws=None):
     """(n, 10) float64 per tile: tissue count, sum od[3], sum od od^T [xx, xy, xz, yy, yz, zz]  (sl_tile_moments)."""
     n, h, w = _check_tiles(rgb)
     p = params if params is not None else _ffi.default_params()
     out = torch.empty((n, 10), dtype=torch.float64, device=rgb.device)
-    wsb = (ws or _default_ws).get(_ffi.OP_TILE_MOMENTS, n, h, w, rgb.device)
+    wsb = _scratch(ws, _ffi.OP_TILE_MOMENTS, n, h, w, rgb.device)
     _ffi.check(_ffi.lib().sl_tile_moments(_ptr(rgb), n, h, w, C.byref(p), _ptr(out), _ptr(wsb), wsb.numel(), _stream()),
                "sl_tile_moments")
     return out

@@ -47,11 +47,11 @@ class ExtractiveStainNormalizer(object):
         self._target_concentrations = None
 
     # -- engine entry points of this method ------------------------------------------------------
-    def _fit_tiles(self, tiles):
+    def _fit_tiles(self, tiles, ws=None):
         from .. import engine
         if self.method == "macenko":
-            return engine.macenko_fit(tiles)
-        M, maxC, status, _ = engine.vahadane_fit(tiles)
+            return engine.macenko_fit(tiles, ws=ws)
+        M, maxC, status, _ = engine.vahadane_fit(tiles, ws=ws)
         return M, maxC, status
 
     def _target_on(self, device):
@@ -66,11 +66,11 @@ class ExtractiveStainNormalizer(object):
             self._target_dev_key = key
         return self._target_dev
 
-    def _transform_tiles(self, tiles, out=None):
+    def _transform_tiles(self, tiles, out=None, ws=None):
         from .. import engine
         fn = engine.macenko_transform if self.method == "macenko" else engine.vahadane_transform
         M_t, c_t = self._target_on(tiles.device)
-        return fn(tiles, M_t, c_t, out=out)
+        return fn(tiles, M_t, c_t, out=out, ws=ws)
 
     def _big_image_statistics(self, dev):
         """(M (2,3), maxC (2,)) of one large image through the pooled statistics, or None when that path does not apply
@@ -98,14 +98,14 @@ class ExtractiveStainNormalizer(object):
         big = self._big_image_statistics(dev)
         if big is not None:
             self.stain_matrix_target, self.maxC_target = big[0], big[1].reshape((1, 2))
-            self._target = target
+            self._target = target.copy()
             self._target_concentrations = None
             return
         M, maxC, status = self._fit_tiles(dev)
         raise_for_status(int(status[0]))
         self.stain_matrix_target = M[0].cpu().numpy()
         self.maxC_target = maxC[0].cpu().numpy().reshape((1, 2))
-        self._target = target
+        self._target = target.copy()            # (the reference computes target_concentrations eagerly: later edits of the caller's array must not leak in)
         self._target_concentrations = None
 
     @property
@@ -134,14 +134,16 @@ class ExtractiveStainNormalizer(object):
         return out[0].cpu().numpy()
 
     # -- batched extension -------------------------------------------------------------------------
-    def fit_batch_targets(self, tiles):
+    def fit_batch_targets(self, tiles, ws=None):
         """Per-tile (M, maxC, status) device tensors for a batch of candidate targets."""
-        return self._fit_tiles(tiles)
+        return self._fit_tiles(tiles, ws=ws)
 
-    def transform_batch(self, tiles, out=None):
+    def transform_batch(self, tiles, out=None, ws=None):
         """(N,H,W,3) uint8 device tensor -> (out, M_src, maxC_src, status) device tensors.  A tile whose
-        status is non-zero (1 = empty tissue mask, 2 = degenerate) is passed through unchanged."""
-        return self._transform_tiles(tiles, out=out)
+        status is non-zero (1 = empty tissue mask, 2 = degenerate) is passed through unchanged.
+        ``ws``: an ``engine.Workspace`` to reuse (ONE stream at a time); by default every call takes its scratch from
+        torch's stream-ordered caching allocator, so concurrent streams / threads never share it."""
+        return self._transform_tiles(tiles, out=out, ws=ws)
 
     def state_dict(self):
         return {"method": self.method, "stain_matrix_target": np.array(self.stain_matrix_target),
@@ -151,6 +153,8 @@ class ExtractiveStainNormalizer(object):
         assert d["method"] == self.method
         self.stain_matrix_target = np.array(d["stain_matrix_target"], dtype=np.float64).reshape(2, 3)
         self.maxC_target = np.array(d["maxC_target"], dtype=np.float64).reshape(1, 2)
+        self._target = None                      # the state of an earlier fit() no longer describes this target
+        self._target_concentrations = None
 
 
 class MacenkoNormalizer(ExtractiveStainNormalizer):
@@ -163,3 +167,42 @@ class MacenkoNormalizer(ExtractiveStainNormalizer):
 class VahadaneNormalizer(ExtractiveStainNormalizer):
     def __init__(self):
         super().__init__("vahadane")
+
+
+class ReinhardStainNormalizer(object):
+    """normalization/normalizer.py:54-94 (exported at stainlib/__init__.py:28): Reinhard colour transfer in cv2's 8-bit Lab.
+
+    ``fit`` keeps ``target_means`` / ``target_stds`` as tuples of (1,1) float64 arrays like cv2.meanStdDev returns them.
+    The whole transform is three sweeps of csrc/lab.hip (two histogram sweeps, one table-driven map); OpenCV's integer Lab
+    conversions are restated there -- parity unpinned against cv2 itself, the reference's own arithmetic
+    around them is golden-pinned."""
+
+    def __init__(self, target_means=0, target_stds=0):
+        self.target_means = target_means                                  # normalizer.py:61-62
+        self.target_stds = target_stds
+
+    def fit(self, target):
+        from .. import engine
+        st = engine.reinhard_stats(_to_device(target), standardize=True)[0].cpu().numpy()      # normalizer.py:65-66
+        self.target_means = tuple(np.array([[st[1 + c]]]) for c in range(3))
+        self.target_stds = tuple(np.array([[st[4 + c]]]) for c in range(3))
+
+    def _targets(self):
+        return ([float(np.asarray(m).reshape(-1)[0]) for m in self.target_means],
+                [float(np.asarray(s).reshape(-1)[0]) for s in self.target_stds])
+
+    def transform(self, I, mask_background=False, luminosity_threshold=0.8):
+        """normalizer.py:70-94."""
+        from .. import engine
+        from ..utils.excepts import TissueMaskException
+        tm, ts = self._targets()
+        out, st = engine.reinhard_transform(_to_device(I), tm, ts, mask_background, luminosity_threshold)
+        if mask_background and int(st[0, 7]) == 0:
+            raise TissueMaskException("Empty tissue mask computed")       # stain_utils.py:46-47 via normalizer.py:86
+        return out[0].cpu().numpy()
+
+    def transform_batch(self, tiles, mask_background=False, luminosity_threshold=0.8, out=None, ws=None):
+        """Batched extension: (N,H,W,3) uint8 device tensor -> (out, stats (N,8): p90, means, stds, tissue pixels)."""
+        from .. import engine
+        tm, ts = self._targets()
+        return engine.reinhard_transform(tiles, tm, ts, mask_background, luminosity_threshold, out=out, ws=ws)

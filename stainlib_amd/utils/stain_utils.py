@@ -75,6 +75,19 @@ class LuminosityThresholdTissueLocator(ABCTissueLocator):
         return mask[0].cpu().numpy().astype(bool)
 
 
+class LuminosityStandardizer(object):
+    """stain_utils.py:50-67 (exported at stainlib/__init__.py:30).  cv2's 8-bit Lab both ways is OpenCV's integer algorithm
+    restated in csrc/lab.hip (parity unpinned against cv2 itself); the percentile and the rescaling of L are
+    the reference's arithmetic, evaluated once per byte value."""
+
+    @staticmethod
+    def standardize(I, percentile=95):
+        assert is_uint8_image(I), _UINT8_MSG
+        from .. import engine
+        out, _ = engine.luminosity_standardize(_to_device(I), percentile)
+        return out[0].cpu().numpy()
+
+
 def get_concentrations(I, stain_matrix, regularizer=0.01):
     """stain_utils.py:69-78 -> (P, 2) float64 (binary32 values from the device)."""
     assert is_uint8_image(I), _UINT8_MSG
@@ -94,3 +107,45 @@ def convert_RGB_to_OD(I):
     assert is_uint8_image(I), _UINT8_MSG
     from .. import engine
     return engine.rgb_to_od(_to_device(I))[0].cpu().numpy()
+
+
+def convert_OD_to_RGB(OD):
+    """stain_utils.py:114-124: uint8(255 * exp(-max(OD, 1e-6))), same shape; asserts on negative optical densities."""
+    import torch
+    from .. import engine
+    od = torch.from_numpy(np.ascontiguousarray(OD, dtype=np.float64)).cuda()
+    out, neg = engine.od_to_rgb(od)
+    assert int(neg[0]) == 0, "Negative optical density."                # stain_utils.py:122
+    return out.cpu().numpy()
+
+
+def lab_split(I):
+    """stain_utils.py:146-158: (I1, I2, I3) float32 planes L8/2.55, a8-128, b8-128 of cv2's 8-bit Lab."""
+    from .. import engine
+    I1, I2, I3 = engine.lab_split(_to_device(I))
+    return I1[0].cpu().numpy(), I2[0].cpu().numpy(), I3[0].cpu().numpy()
+
+
+def merge_back(I1, I2, I3):
+    """stain_utils.py:160-172: planes (float32 or float64, like numpy promotes them) -> RGB uint8.  The reference scales its
+    arguments in place; this mirror leaves them untouched."""
+    import torch
+    from .. import engine
+    dt = np.result_type(I1, I2, I3)
+    dt = np.float64 if dt == np.float64 else np.float32
+    planes = [torch.from_numpy(np.ascontiguousarray(np.asarray(p), dtype=dt)[None]).cuda() for p in (I1, I2, I3)]
+    return engine.lab_merge(*planes)[0].cpu().numpy()
+
+
+def get_mean_std(I):
+    """stain_utils.py:174-186: ((m1, m2, m3), (sd1, sd2, sd3)), each a (1,1) float64 array like cv2.meanStdDev returns."""
+    from .. import engine
+    st = engine.reinhard_stats(_to_device(I), standardize=False)[0].cpu().numpy()
+    return tuple(np.array([[st[1 + c]]]) for c in range(3)), tuple(np.array([[st[4 + c]]]) for c in range(3))
+
+
+def standardize_brightness(I):
+    """stain_utils.py:188-194: uint8(clip(I * 255.0 / percentile(I, 90), 0, 255))."""
+    from .. import engine
+    out, _ = engine.standardize_brightness(_to_device(I))
+    return out[0].cpu().numpy()

@@ -25,7 +25,7 @@ def test_normalizer_fit_transform_like_the_reference():
         np.testing.assert_allclose(n.maxC_target, g["maxC_target"], rtol=2e-6)
         out = n.transform(I)
         assert isinstance(out, np.ndarray) and out.dtype == np.uint8 and out.shape == I.shape
-        u8_parity(out, g["out"], max_rate=4e-4)
+        u8_parity(out, g["out"])
     tc = n.target_concentrations
     assert tc.shape == (256 * 256, 2) and tc.dtype == np.float64
     np.testing.assert_allclose(tc, so.get_concentrations(tgt, n.stain_matrix_target), rtol=0, atol=5e-6)
@@ -75,12 +75,12 @@ def test_hed_lighter_vs_reference_golden(path):
     g = np.load(path)
     I = so.synth_tile(int(g["size"]), int(g["size"]), int(g["seed"]))
     a = sl.HedLighterColorAugmenter()
-    u8_parity(a.transform(I), g["out_unrandomized"], max_rate=1e-4)
+    u8_parity(a.transform(I), g["out_unrandomized"])
     np.random.seed(int(g["npseed"]))
     a.randomize()
     out = a.transform(I)
     assert out.dtype == np.uint8 and out.shape == I.shape
-    rate = u8_parity(out, g["out"], max_rate=1e-4)                       # true scikit-image 0.18.3 output
+    rate = u8_parity(out, g["out"])                       # true scikit-image 0.18.3 output
     assert rate < 5e-5
     white = np.full((16, 16, 3), 255, np.uint8)
     dark = np.full((16, 16, 3), 3, np.uint8)
@@ -104,24 +104,24 @@ def test_hed_batch_modes_and_ragged():
     out, applied = out.cpu().numpy(), applied.cpu().numpy()
     assert list(applied) == [1, 1, 1, 1, 1, 0] and np.array_equal(out[5], tiles[5])
     for i in range(5):
-        u8_parity(out[i], so.hed_transform(tiles[i], sig[i], bia[i]), max_rate=1e-4)
+        u8_parity(out[i], so.hed_transform(tiles[i], sig[i], bia[i]))
     out19, _ = engine.hed_augment(to_dev(tiles[:3]), sig[:3], bia[:3], skimage_mode=1)
     for i in range(3):
-        u8_parity(out19[i].cpu().numpy(), so.hed_transform(tiles[i], sig[i], bia[i], mode="0.19"), max_rate=1e-4)
+        u8_parity(out19[i].cpu().numpy(), so.hed_transform(tiles[i], sig[i], bia[i], mode="0.19"))
     # scikit-image <= 0.17 semantics (the release environment.yml pins): -log10(rgb + 2), 10^x - 2
     out17, _ = engine.hed_augment(to_dev(tiles[:3]), sig[:3], bia[:3], skimage_mode=2)
     for i in range(3):
         want = so.hed_transform(tiles[i], sig[i], bia[i], mode="0.17")
-        u8_parity(out17[i].cpu().numpy(), want, max_rate=1e-4)
+        u8_parity(out17[i].cpu().numpy(), want)
         assert not np.array_equal(want, so.hed_transform(tiles[i], sig[i], bia[i]))      # a different map, not a relabelling
     a17 = sl.HedLightColorAugmenter(skimage_mode="0.17")
     a17._sigmas, a17._biases = list(sig[0]), list(bia[0])
-    u8_parity(a17.transform(tiles[0]), so.hed_transform(tiles[0], sig[0], bia[0], mode="0.17"), max_rate=1e-4)
+    u8_parity(a17.transform(tiles[0]), so.hed_transform(tiles[0], sig[0], bia[0], mode="0.17"))
     f = tiles[1].astype(np.float64) / 255.0
     np.testing.assert_allclose(a17.transform(f), so.hed_transform(f, sig[0], bia[0], mode="0.17"), rtol=0, atol=1e-12)
     odd = [so.synth_tile(33, 47, 8)]
     o, _ = engine.hed_augment(to_dev(odd), [sig[0]], [bia[0]])
-    u8_parity(o[0].cpu().numpy(), so.hed_transform(odd[0], sig[0], bia[0]), max_rate=1e-3)
+    u8_parity(o[0].cpu().numpy(), so.hed_transform(odd[0], sig[0], bia[0]))
     # the cutoff test on a ragged tile needs the EXACT byte sum: 4653 bytes whose mean sits 340 counts below the
     # 0.95 limit -- three stray copies of the last byte (255) in the padding of the last chunk would push it over
     edge = np.full((33, 47, 3), 242, np.uint8).reshape(-1)
@@ -147,8 +147,8 @@ def test_stain_augmentor_vs_reference_golden(path):
     assert a.image_shape == I.shape and a.n_stains == 2
     np.random.seed(int(g["npseed"]))
     o0, o1 = a.pop(), a.pop()
-    u8_parity(o0, g["out0"], max_rate=4e-4)
-    u8_parity(o1, g["out1"], max_rate=4e-4)
+    u8_parity(o0, g["out0"])
+    u8_parity(o1, g["out1"])
     assert np.array_equal(a.tissue_mask, so.tissue_mask(I).ravel())
     assert a.source_concentrations.shape == (I.shape[0] * I.shape[1], 2)
 
@@ -175,7 +175,7 @@ def test_slide_level_mode_single_rank():
     for i in range(6):
         C = so.get_concentrations(tiles[i], Ms) * (on.maxC_target / mcs)
         want = so.truncate_u8(255 * np.exp(-C @ on.stain_matrix_target)).reshape(tiles[i].shape)
-        u8_parity(out[i].cpu().numpy(), want, max_rate=4e-4)
+        u8_parity(out[i].cpu().numpy(), want)
 
 
 def test_tile_pipeline_matches_direct_transform():
@@ -237,7 +237,7 @@ def test_pooled_slide_mode_matches_reference_on_concatenated_tiles():
     on = so.ExtractiveStainNormalizer("macenko")
     on.fit(tgt)
     want = on.transform(tall)                                             # the reference recipe on the tall image
-    u8_parity(out.cpu().numpy().reshape(tall.shape), want, max_rate=4e-4)
+    u8_parity(out.cpu().numpy().reshape(tall.shape), want)
 
 
 def test_grayscale_augmentor_matches_reference_golden():
@@ -250,8 +250,8 @@ def test_grayscale_augmentor_matches_reference_golden():
     aug.fit(I)
     np.random.seed(11)
     out0, out1 = aug.pop(), aug.pop()
-    u8_parity(out0, g["out0"], max_rate=1e-5)
-    u8_parity(out1, g["out1"], max_rate=1e-5)
+    u8_parity(out0, g["out0"])
+    u8_parity(out1, g["out1"])
     assert out0.shape == I.shape and np.array_equal(out0[..., 0], out0[..., 1]) and np.array_equal(out0[..., 0], out0[..., 2])
     # unaligned size, batch entry point, against the oracle
     from stainlib_amd import engine
@@ -261,7 +261,7 @@ def test_grayscale_augmentor_matches_reference_golden():
     for i in range(3):
         o = so.GrayscaleAugmentor()
         o.fit(tiles[i])
-        u8_parity(out[i], o.pop_with(*ab[i]), max_rate=1e-5)
+        u8_parity(out[i], o.pop_with(*ab[i]))
     with pytest.raises(sl.TissueMaskException):
         sl.GrayscaleAugmentor().fit(np.full((16, 16, 3), 255, np.uint8))
 
