@@ -51,7 +51,8 @@ extern "C" {
 #define SL_TILE_EMPTY_MASK 1     /* stain_utils.py:46-47 -> TissueMaskException */
 #define SL_TILE_DEGENERATE_COV 2 /* fewer than 2 tissue pixels (np.cov is NaN in the reference), or tissue of a single colour:
                                     two parallel stain vectors, inf/NaN concentrations in the reference */
-#define SL_TILE_ZERO_MAXC 3      /* 99th percentile of a concentration is 0: normalizer.py:48 divides by it */
+#define SL_TILE_ZERO_MAXC 3      /* 99th percentile of a concentration is 0: normalizer.py:48 divides by it (inf / NaN cast to uint8
+                                    in the reference).  A tile with any non-zero status is passed through unchanged by the transforms. */
 
 /* ops for sl_workspace_bytes */
 #define SL_OP_MACENKO_FIT 1

@@ -267,9 +267,10 @@ static __global__ __launch_bounds__(kWG) void k_apply(const uint8_t* __restrict_
     const int c0 = part * span;
     const int c1 = min(nch, c0 + span);
 
-    // A tile whose fit failed (empty tissue mask / degenerate covariance: M is NaN) is passed
-    // through unchanged; the caller sees why in status[].  (Block-uniform branch.)
-    if (!(M_src[6 * (size_t)tile] == M_src[6 * (size_t)tile])) {
+    // A tile whose fit failed (empty tissue mask / degenerate covariance: M is NaN; a zero 99th-percentile concentration,
+    // which the reference divides by, normalizer.py:48) is passed through unchanged; the caller sees why in status[].
+    // (Block-uniform branch.)
+    if (!(M_src[6 * (size_t)tile] == M_src[6 * (size_t)tile]) || !(maxC_src[2 * (size_t)tile] > 0.0) || !(maxC_src[2 * (size_t)tile + 1] > 0.0)) {
         for (int c = c0 + tid; c < c1; c += kWG) store_chunk<ALIGNED>(dst, nbytes, c, load_chunk<ALIGNED>(src, nbytes, c));
         return;
     }

@@ -2232,7 +2232,7 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
         // ---------------- sweep 4: apply
         if (TRANSFORM) {
             uint8_t* dst = a.out + (size_t)tile * nbytes;
-            if (bad) {
+            if (sh.status != SL_TILE_OK) {       // block-uniform (sh.status is final: barrier above); includes a zero maxC found in finish 3
                 for (int c = tid; c < nch; c += NT) store_chunk<ALIGNED>(dst, nbytes, c, load_chunk<ALIGNED>(src, nbytes, c));
             } else {
                 ApplyK K;

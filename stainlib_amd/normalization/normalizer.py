@@ -140,7 +140,7 @@ class ExtractiveStainNormalizer(object):
 
     def transform_batch(self, tiles, out=None, ws=None):
         """(N,H,W,3) uint8 device tensor -> (out, M_src, maxC_src, status) device tensors.  A tile whose
-        status is non-zero (1 = empty tissue mask, 2 = degenerate) is passed through unchanged.
+        status is non-zero (1 = empty tissue mask, 2 = degenerate, 3 = a zero 99th-percentile concentration) is passed through unchanged.
         ``ws``: an ``engine.Workspace`` to reuse (ONE stream at a time); by default every call takes its scratch from
         torch's stream-ordered caching allocator, so concurrent streams / threads never share it."""
         return self._transform_tiles(tiles, out=out, ws=ws)

@@ -76,13 +76,44 @@ def test_vahadane_default_tolerance_and_transform():
     np.testing.assert_allclose(sa.stain_matrix, Ms, rtol=0, atol=V_ATOL)
 
 
-def test_vahadane_1024_tile():
+def test_vahadane_512_tile():
     from stainlib_amd import engine
     I = so.synth_tile(512, 512, 11)
     M, mc, st, sweeps = engine.vahadane_fit(to_dev([I]))
     Mo, mco, info = _oracle_fit(I)
     np.testing.assert_allclose(M.cpu().numpy()[0], Mo, rtol=0, atol=V_ATOL)
     assert int(sweeps[0]) < 30
+
+
+def test_vahadane_1024_tiles_fit_and_transform():
+    """BASELINE configs[2] tile size: 1024 x 1024, fit and transform, both schedules, against the converged oracle (whose
+    dictionary tests/golden/vahadane_pin_*.npz pin to scikit-learn's DictionaryLearning)."""
+    from stainlib_amd import engine
+    tiles = [so.synth_tile(1024, 1024, s) for s in (21, 22)]
+    tgt = so.synth_tile(1024, 1024, 1001, so.M_TRUE_TGT)
+    Mto, mcto, _ = _oracle_fit(tgt)
+    fits = [_oracle_fit(I) for I in tiles]
+    outs = []
+    for sched in (1, 2):
+        p = engine.make_params(schedule=sched, dl_tol=1e-7)
+        Mt, mct, st, _ = engine.vahadane_fit(to_dev([tgt]), params=p)
+        np.testing.assert_allclose(Mt[0].cpu().numpy(), Mto, rtol=0, atol=V_ATOL)
+        out, M, mc, st = engine.vahadane_transform(to_dev(tiles), Mt[0], mct[0], params=p)
+        assert (st.cpu().numpy() == 0).all()
+        for i, I in enumerate(tiles):
+            np.testing.assert_allclose(M[i].cpu().numpy(), fits[i][0], rtol=0, atol=V_ATOL)
+            np.testing.assert_allclose(mc[i].cpu().numpy(), fits[i][1], rtol=2e-5)
+            Cs = so.get_concentrations(I, fits[i][0]) * (mcto / fits[i][1])
+            want = so.truncate_u8(255 * np.exp(-Cs @ Mto)).reshape(I.shape)
+            d = np.abs(out[i].cpu().numpy().astype(np.int16) - want.astype(np.int16))
+            flips = int((d != 0).sum())
+            print(f"vahadane 1024^2 schedule {sched} tile {i}: {flips} of {d.size} bytes differ ({flips / d.size:.2e}); "
+                  f"|dM| {np.abs(M[i].cpu().numpy() - fits[i][0]).max():.1e}")
+            # the dictionary agrees with the oracle's to ~1e-6 (its own stopping tolerance), which moves every pixel:
+            # the byte bound is the dictionary tolerance times the density of values near an integer
+            assert d.max() <= 1 and flips <= 2e-3 * d.size
+        outs.append(out)
+    assert (outs[0] != outs[1]).float().mean().item() < 1e-4
 
 
 def test_vahadane_schedules_agree():
