@@ -89,42 +89,64 @@ __device__ __forceinline__ void store_chunk(uint8_t* tile, size_t nbytes, int c,
     }
 }
 
-struct ReconK {
-    float q[2][3];  // -log2(e) * scale_i * M_out[i][c]
-};
-
-// One pixel: OD -> concentrations -> (optional affine) -> Beer-Lambert in base 2.
-template <bool CLIP>
-__device__ __forceinline__ void recon_px(const ReconK& R, float c1, float c2, float (&v)[3]) {
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-        const float e = fmaf(c1, R.q[0][ch], c2 * R.q[1][ch]);
-        float t = 255.0f * __builtin_amdgcn_exp2f(e);
-        if (CLIP) t = fminf(t, 255.0f);   // t >= 0 always; NaN -> 255 is irrelevant (cast gives 0 first)
-        v[ch] = t;
-    }
-}
-
 // Truncating cast of normalizer.py:50 (`astype(np.uint8)`): toward zero, then modulo 256.
 __device__ __forceinline__ uint32_t trunc_u8(float t) { return ((uint32_t)t) & 0xffu; }
 
 // ---- the normalisation step shared by k_apply and sweep 4 of the fused kernel (bit-identical by construction) ----
+// Issue count per pixel (the sweep is vector-issue bound): the lasso's max(min(a, s), 0) is ONE v_min_f32 with
+// the clamp modifier -- VOP3 clamp is [0, 1], so the concentrations are carried scaled by 2^-k, k chosen per tile from a
+// bound on |a|, |s| over every optical density a byte can produce (exact: a power of two), and compensated in q.
+// (Folding the factor 255 into the exponent -- 2^(e + log2 255), three multiplies fewer -- was measured and dropped: a
+// pixel with zero concentrations must give EXACTLY 255 like the reference, and 2^(log2 255) comes out as 254.99998, which
+// truncates to 254 on every background pixel.)
 struct ApplyK {
-    LassoK L;            // source stain matrix; affine parts VGPR-resident
-    float q[2][3];       // -log2(e) * (maxC_tgt_i / maxC_src_i) * M_tgt[i][c], VGPR-resident
+    LassoK L;            // source stain matrix, weights scaled by 2^-k; affine parts VGPR-resident
+    float q[2][3];       // -log2(e) * (maxC_tgt_i / maxC_src_i) * M_tgt[i][c] * 2^k, VGPR-resident
     bool fast;           // wave-uniform: g12 >= 0 and every q <= 0, i.e. 0 <= 255*2^e <= 255 for every pixel
 };
+
+constexpr double kOdMax = 5.541263545158426;      // -ln(1/255): the largest optical density of a byte
+
+// 2^-k with 2^k >= every |a_i|, |s_i| the lasso can produce from byte optical densities (k in [0, 60])
+__device__ __forceinline__ double lasso_unit_scale(const LassoK& k) {
+    double b = 1.0;
+    const float* rows[4] = {k.wa1, k.wa2, k.ws1, k.ws2};
+    const float ks[4] = {k.ka1, k.ka2, k.ks1, k.ks2};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double v = kOdMax * (fabs((double)rows[r][0]) + fabs((double)rows[r][1]) + fabs((double)rows[r][2])) + fabs((double)ks[r]);
+        b = v > b ? v : b;                                  // (NaN / inf from a singular matrix: the tile is reported, any scale does)
+    }
+    int e = 0;
+    (void)frexp(b, &e);                                     // b = f * 2^e, f in [0.5, 1)  =>  b <= 2^e
+    e = e < 0 ? 0 : (e > 60 ? 60 : e);
+    return ldexp(1.0, -e);
+}
+__device__ __forceinline__ void scale_lasso(LassoK& k, float sc) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { k.wa1[c] *= sc; k.wa2[c] *= sc; k.ws1[c] *= sc; k.ws2[c] *= sc; }
+    k.ka1 *= sc; k.ka2 *= sc; k.ks1 *= sc; k.ks2 *= sc;     // (g12, g22 only enter sign tests that are homogeneous in s1, s2)
+}
+
+// max(min(a, s), 0) for operands in [-1, 1]: v_min_f32 with the VOP3 clamp modifier
+__device__ __forceinline__ float min_clamp01(float a, float s) {
+    float r;
+    asm("v_min_f32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(s));
+    return r;
+}
 
 __device__ __forceinline__ void apply_consts(const double* M_src, const double* maxC_src, const double* M_tgt,
                                              const double* maxC_tgt, double lam, ApplyK& K) {
     lasso_consts(M_src, lam, K.L);
+    const double sc = lasso_unit_scale(K.L), inv = 1.0 / sc;       // powers of two
+    scale_lasso(K.L, (float)sc);
     bool nonpos = true;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const double ratio = maxC_tgt[i] / maxC_src[i];                          // normalizer.py:48
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float q = (float)(-1.4426950408889634 * ratio * M_tgt[3 * i + c]);
+            const float q = (float)(-1.4426950408889634 * ratio * M_tgt[3 * i + c] * inv);
             nonpos = nonpos & (q <= 0.0f);
             K.q[i][c] = in_vgpr(uni(q));
         }
@@ -142,8 +164,8 @@ __device__ __forceinline__ void apply_px(const ApplyK& K, float x, float y, floa
         lasso_interior(K.L, x, y, z, a1, a2);
         const float s1 = fmaf(K.L.ws1[2], z, fmaf(K.L.ws1[1], y, fmaf(K.L.ws1[0], x, K.L.ks1)));
         const float s2 = fmaf(K.L.ws2[2], z, fmaf(K.L.ws2[1], y, fmaf(K.L.ws2[0], x, K.L.ks2)));
-        c1 = fmaxf(fminf(a1, s1), 0.0f);
-        c2 = fmaxf(fminf(a2, s2), 0.0f);
+        c1 = min_clamp01(a1, s1);
+        c2 = min_clamp01(a2, s2);
     } else {
         lasso2(K.L, x, y, z, c1, c2);
     }
@@ -322,9 +344,9 @@ static __global__ __launch_bounds__(kWG) void k_apply(const uint8_t* __restrict_
 // row table in layout B: one conflict-free ds_read_b64 {gamma, od32} per byte, gathers issued one chunk ahead of the
 // arithmetic, the next trip's chunks in flight (the structure of apply_sweep).
 struct AugmentK {
-    LassoK L;            // VGPR-resident
-    float q[2][3];       // -log2(e) * M[i][c]
-    float al0, be0, al1, be1, ylimf;
+    LassoK L;            // VGPR-resident, weights scaled by 2^-k (see ApplyK)
+    float q[2][3];       // -log2(e) * M[i][c] * 2^k
+    float al0, be0, al1, be1, ylimf;            // be_i scaled by 2^-k
 };
 
 template <bool ALIGNED, bool ALL, bool FAST, class TR>
@@ -350,8 +372,8 @@ __device__ __forceinline__ void augment_sweep(const uint8_t* src, uint8_t* dst, 
                 lasso_interior(K.L, er.y, eg.y, eb.y, i1, i2);
                 const float s1 = fmaf(K.L.ws1[2], eb.y, fmaf(K.L.ws1[1], eg.y, fmaf(K.L.ws1[0], er.y, K.L.ks1)));
                 const float s2 = fmaf(K.L.ws2[2], eb.y, fmaf(K.L.ws2[1], eg.y, fmaf(K.L.ws2[0], er.y, K.L.ks2)));
-                a1 = fmaxf(fminf(i1, s1), 0.0f);
-                a2 = fmaxf(fminf(i2, s2), 0.0f);
+                a1 = min_clamp01(i1, s1);
+                a2 = min_clamp01(i2, s2);
             } else {
                 lasso2(K.L, er.y, eg.y, eb.y, a1, a2);
             }
@@ -412,13 +434,15 @@ static __global__ __launch_bounds__(kAugThreads, 4) void k_stain_augment(const u
         // per-tile constants live in VGPRs (a VALU op with an SGPR operand issues at half rate on gfx950)
         AugmentK K;
         lasso_consts(M + 6 * (size_t)tile, lam, K.L);
+        const double sc = lasso_unit_scale(K.L), inv = 1.0 / sc;      // powers of two (see ApplyK)
+        scale_lasso(K.L, (float)sc);
         vgpr(K.L);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) K.q[i][c] = in_vgpr((float)(-1.4426950408889634 * M[6 * (size_t)tile + 3 * i + c]));
-        K.al0 = in_vgpr((float)alpha_beta[4 * (size_t)tile + 0]); K.be0 = in_vgpr((float)alpha_beta[4 * (size_t)tile + 1]);
-        K.al1 = in_vgpr((float)alpha_beta[4 * (size_t)tile + 2]); K.be1 = in_vgpr((float)alpha_beta[4 * (size_t)tile + 3]);
+            for (int c = 0; c < 3; ++c) K.q[i][c] = in_vgpr((float)(-1.4426950408889634 * M[6 * (size_t)tile + 3 * i + c] * inv));
+        K.al0 = in_vgpr((float)alpha_beta[4 * (size_t)tile + 0]); K.be0 = in_vgpr((float)(alpha_beta[4 * (size_t)tile + 1] * sc));
+        K.al1 = in_vgpr((float)alpha_beta[4 * (size_t)tile + 2]); K.be1 = in_vgpr((float)(alpha_beta[4 * (size_t)tile + 3] * sc));
         K.ylimf = in_vgpr((float)y_lim - 2048.0f);
         const int c0 = min(nch, part * span), c1 = min(nch, c0 + span);
         if (c0 >= c1) continue;

@@ -202,9 +202,17 @@ def test_tile_pipeline_matches_direct_transform():
     pipe = normalizer_pipeline(n, (8, 96, 96, 3))
     outs = [o.copy() for o in pipe.run(batches)]
     assert [o.shape[0] for o in outs] == [8, 8, 8, 8, 3]
+    on = so.ExtractiveStainNormalizer("macenko")
+    on.stain_matrix_target, on.maxC_target = n.stain_matrix_target, n.maxC_target
     for b, o in zip(batches, outs):
         direct = n.transform_batch(to_dev(b))[0].cpu().numpy()
         assert np.array_equal(o, direct)
+        for i in range(b.shape[0]):                      # and against the oracle: host bytes in, host bytes out
+            u8_parity(o[i], on.transform(b[i]), label="pipeline")
+    # pageable producer (plain numpy arrays, staged into pinned memory by the pipeline's copy threads) and a second run on the
+    # same pipeline object: the same bytes
+    outs2 = [o.copy() for o in pipe.run([np.array(b) for b in batches])]
+    assert all(np.array_equal(x, y) for x, y in zip(outs, outs2))
 
 
 def test_pooled_slide_mode_matches_reference_on_concatenated_tiles():
@@ -244,6 +252,25 @@ def test_pooled_slide_mode_matches_reference_on_concatenated_tiles():
         sd.window_rank_pairs = real
     assert s3.last_path == ["window", "window"] and s4.last_path == ["radix", "radix"]
     assert np.array_equal(M3, M4) and np.array_equal(c3, c4)
+    # spatially structured slide with few tiles, i.e. long parts (the 1/64 sample used to cover only the top of
+    # each part): white band on the left of every tile, tissue whose staining drifts from the top to the bottom of the tile
+    rng = np.random.RandomState(3)
+    struct = []
+    for k in range(3):
+        t = so.synth_tile(1024, 512, 90 + k)
+        ramp = np.linspace(0.6, 1.4, 1024)[:, None, None]
+        t = np.clip(255.0 * (t / 255.0) ** ramp, 0, 255).astype(np.uint8)
+        t[:, :100] = 255
+        struct.append(t)
+    tall_s = np.concatenate(struct, axis=0)
+    M_ws = so.macenko_stain_matrix(tall_s)
+    c_ws = np.percentile(so.get_concentrations(tall_s, M_ws), 99, axis=0)
+    s5 = PooledSlideStatistics()
+    M5, c5 = s5(to_dev(struct))
+    print("structured slide: selection paths", s5.last_path)
+    np.testing.assert_allclose(M5, M_ws, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(c5, c_ws, rtol=2e-6)
+    assert s5.last_path == ["window", "window"]          # the sample is good enough to centre the window on a structured slide too
     tgt = so.synth_tile(128, 128, 1001, so.M_TRUE_TGT)
     n = sl.MacenkoNormalizer()
     n.fit(tgt)

@@ -76,7 +76,7 @@ def _general_case(M_src, M_tgt, tiles, maxC_src, maxC_tgt):
         assert np.isin(np.abs(d), (0, 1, 255)).all(), np.unique(np.abs(d))
         flips = int((d != 0).sum())
         print(f"general path tile {i}: {flips} of {d.size} bytes differ; values above 255: {int((want_pre >= 256).sum())}")
-        assert flips <= max(2, int(1e-4 * d.size))
+        assert flips <= max(4, int(1e-4 * d.size))
         stats.append((float(want_pre.max()), C))
     return stats
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collects every measurement the docs cite into gpurun_out/ (run on the GPU box from the repo root):
-#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r01'
-tag=${1:-r01}
+#   make -C tools && /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r02'
+tag=${1:-r02}
 cd "$GRAFT_REPO_ROOT" || exit 1
 out=$PWD/gpurun_out
 mkdir -p "$out"
@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 python bench.py --steps 20 --warmup 3 2>/dev/null | tail -1 > "$out/${tag}_bench_n1.json"
 python tools/bench_configs.py 2>/dev/null | tail -1 > "$out/${tag}_secondary_configs.json"
 python tools/crossover.py 2>/dev/null | grep "^size" > "$out/${tag}_crossover.txt"
-python tools/phase_times.py 512 1024 2>/dev/null | grep -A12 "per-tile" > "$out/${tag}_phase_times.txt"
+STAINLIB_HIP_LIB=$PWD/stainlib_amd/csrc/libstainlib_hip_dev.so python tools/phase_times.py 512 1024 2>/dev/null | grep -A12 "per-tile" > "$out/${tag}_phase_times.txt"
 rm -rf /tmp/kt; timeout 600 rocprofv3 --kernel-trace -d /tmp/kt -o p -- python bench.py --steps 20 --warmup 3 > /dev/null 2>&1
 python tools/rocpd_stats.py "$(ls /tmp/kt/*/*.db /tmp/kt/*.db 2>/dev/null | head -1)" > "$out/${tag}_kernel_stats.md" 2>&1
 # Vahadane, 128 tiles (BASELINE configs[2]): per-kernel times of the one-launch-per-phase schedule
@@ -34,7 +34,7 @@ for pass in "f:FETCH_SIZE" "w:WRITE_SIZE" "s1:SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_W
   rm -rf /tmp/pmc_$t; timeout 400 rocprofv3 --pmc $c -d /tmp/pmc_$t -o p -- python tools/run_fused_once.py 512 > /dev/null 2>&1
   python tools/pmc_summary.py "$(ls /tmp/pmc_$t/*/*.db /tmp/pmc_$t/*.db 2>/dev/null | head -1)" > "$out/${tag}_pmc_$t.txt" 2>&1
 done
-[ -x build/ubench_ops ] && timeout 120 build/ubench_ops > "$out/${tag}_ubench_ops.txt" 2>&1
-[ -x build/ubench_issue ] && timeout 120 build/ubench_issue > "$out/${tag}_ubench_issue.txt" 2>&1
-[ -x build/kbench_stream ] && timeout 120 build/kbench_stream > "$out/${tag}_kbench_stream.txt" 2>&1
+[ -x tools/bin/ubench_ops ] && timeout 120 tools/bin/ubench_ops > "$out/${tag}_ubench_ops.txt" 2>&1
+[ -x tools/bin/ubench_issue ] && timeout 120 tools/bin/ubench_issue > "$out/${tag}_ubench_issue.txt" 2>&1
+[ -x tools/bin/kbench_stream ] && timeout 120 tools/bin/kbench_stream > "$out/${tag}_kbench_stream.txt" 2>&1
 ls -la "$out" | tail -20

@@ -1,4 +1,5 @@
-"""Per-phase time of the fused kernel (development aid)."""
+"""Per-phase time of the fused kernel (development aid).  Needs the -DSL_DEVTOOLS build of the library:
+    make -C stainlib_amd/csrc dev && STAINLIB_HIP_LIB=$PWD/stainlib_amd/csrc/libstainlib_hip_dev.so python tools/phase_times.py"""
 import ctypes as C
 import sys
 
