@@ -130,9 +130,13 @@ __device__ __forceinline__ void scale_lasso(LassoK& k, float sc) {
 
 // max(min(a, s), 0) for operands in [-1, 1]: v_min_f32 with the VOP3 clamp modifier
 __device__ __forceinline__ float min_clamp01(float a, float s) {
+#ifdef SL_EXP_NOCLAMP
+    return fmaxf(fminf(a, s), 0.0f);
+#else
     float r;
     asm("v_min_f32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(s));
     return r;
+#endif
 }
 
 __device__ __forceinline__ void apply_consts(const double* M_src, const double* maxC_src, const double* M_tgt,

@@ -261,3 +261,160 @@ def test_percentile_position_and_lerp_follow_numpy():
     for pct in (1.0, 99.0, 50.0, 0.0, 100.0):
         k, g = sd.percentile_position(len(x), pct)
         assert sd.np_lerp(x[k], x[min(k + 1, len(x) - 1)], g) == np.percentile(x, pct)
+
+
+# ---- the REAL PooledSlideStatistics.__call__ / SlideNormalizer.transform_shard on two gloo ranks ------------------------
+# The engine's device sweeps (sl_tile_moments, sl_slide_key_*, sl_normalize_apply) are replaced by numpy stand-ins built
+# on the oracle, with the same contracts as include/stainlib_hip.h; everything else -- the moment / pixel-count
+# all-reduces, the sampled estimate, the window all-reduce, the radix fallback, the broadcast-free agreement of the ranks,
+# the apply pass with the slide statistics -- is the product code of stainlib_amd/distributed.py executing.
+def _install_numpy_engine(force_radix=False):
+    from oracle import stain_oracle as so
+    from stainlib_amd import _ffi, engine
+
+    def f2ord(a):
+        u = np.asarray(a, np.float32).view(np.uint32)
+        return np.where(u & 0x80000000, ~u, u | 0x80000000).astype(np.uint64)
+
+    def keys(tiles, keyset, basis):
+        """ordered-uint32 keys of this rank's pixels, per target: [k0, k1] (angle: tissue pixels only, one key set twice)"""
+        T = tiles.numpy()
+        od = np.concatenate([so.rgb_to_od(t).reshape(-1, 3) for t in T]).astype(np.float32)
+        if keyset == _ffi.KEYSET_ANGLE:
+            mask = np.concatenate([(so.lab_l8(t) / 255.0 < 0.8).ravel() for t in T])
+            V = np.asarray(basis, np.float64).reshape(3, 2).astype(np.float32)
+            th = od[mask] @ V
+            x, y = th[:, 0], th[:, 1]
+            d = np.abs(x) + np.abs(y)
+            p = np.where(d > 0, y / np.where(d > 0, d, 1), 0).astype(np.float32)
+            p = np.where(x < 0, np.where(y >= 0, 2.0, -2.0).astype(np.float32) - p, p).astype(np.float32)
+            k = f2ord(p)
+            return [k, k]
+        C = so.lasso2_nonneg(od.astype(np.float64), np.asarray(basis, np.float64).reshape(2, 3), 0.01).astype(np.float32)
+        return [f2ord(C[:, 0]), f2ord(C[:, 1])]
+
+    def tile_moments(tiles, params=None, ws=None):
+        rows = []
+        for t in tiles.numpy():
+            od = so.rgb_to_od(t).reshape(-1, 3)[(so.lab_l8(t) / 255.0 < 0.8).ravel()]
+            S = od.T @ od
+            rows.append([len(od), *od.sum(0), S[0, 0], S[0, 1], S[0, 2], S[1, 1], S[1, 2], S[2, 2]])
+        return torch.tensor(rows, dtype=torch.float64)
+
+    def hist(tiles, keyset, basis, prefixes, bits, hist=None, params=None, every=1):
+        ks = keys(tiles, keyset, basis)
+        rows = []
+        for t in range(2):
+            o = ks[t][::every]
+            sel = o if bits == 0 else o[(o >> np.uint64(32 - bits)) == np.uint64(prefixes[t])]
+            rows.append(np.bincount(((sel >> np.uint64(24 - bits)) & np.uint64(255)).astype(np.int64), minlength=256))
+        return torch.from_numpy(np.stack(rows).astype(np.int64))
+
+    def hist16(tiles, keyset, basis, prefixes16, hist=None, params=None):
+        ks = keys(tiles, keyset, basis)
+        rows = [np.bincount((ks[t][(ks[t] >> np.uint64(16)) == np.uint64(prefixes16[t])] & np.uint64(0xffff)).astype(np.int64), minlength=65536)
+                for t in range(2)]
+        return torch.from_numpy(np.stack(rows).astype(np.int64))
+
+    def window(tiles, keyset, basis, lo, params=None):
+        if force_radix:                       # a window that sees nothing: the caller must fall back to the radix rounds
+            return torch.zeros((2 * 65536 + 2,), dtype=torch.int64)
+        ks = keys(tiles, keyset, basis)
+        out = np.zeros(2 * 65536 + 2, np.int64)
+        for t in range(2):
+            d = ks[t].astype(np.int64) - int(lo[t])
+            out[t * 65536:(t + 1) * 65536] = np.bincount(d[(d >= 0) & (d < 65536)], minlength=65536)
+            out[2 * 65536 + t] = int((d < 0).sum())
+        return torch.from_numpy(out)
+
+    def next_above(tiles, keyset, basis, key_ords, params=None):
+        ks = keys(tiles, keyset, basis)
+        out = []
+        for t in range(2):
+            g = ks[t][ks[t] > np.uint64(key_ords[t])]
+            out.append(int(g.min()) if len(g) else 0xffffffff)
+        return out
+
+    def normalize_apply(rgb, M_src, maxC_src, M_tgt, maxC_tgt, lasso_lambda=0.01, out=None, want_prequant=False):
+        res = []
+        for i, t in enumerate(rgb.numpy()):
+            C = so.get_concentrations(t, np.asarray(M_src[i])) * (np.asarray(maxC_tgt).reshape(2) / np.asarray(maxC_src[i]))
+            res.append(so.truncate_u8(255 * np.exp(-C @ np.asarray(M_tgt))).reshape(t.shape))
+        return torch.from_numpy(np.stack(res))
+
+    engine.make_params = lambda **kw: None
+    engine.tile_moments = tile_moments
+    engine.slide_key_histogram = hist
+    engine.slide_key_histogram_sampled = lambda tiles, keyset, basis, pre, bits, slog, params=None: hist(tiles, keyset, basis, pre, bits, every=1 << slog)
+    engine.slide_key_histogram16 = hist16
+    engine.slide_key_window = window
+    engine.slide_key_next_above = next_above
+    engine.normalize_apply = normalize_apply
+
+
+def _slide_tiles():
+    from oracle import stain_oracle as so
+    return [so.synth_tile(48, 64, 300 + s) for s in range(5)] + [so.structured_tile("white_bg", 64, 48, 7).transpose(1, 0, 2).copy()]
+
+
+class _FittedTarget:                       # what SlideNormalizer needs of a fitted normalizer
+    def __init__(self):
+        from oracle import stain_oracle as so
+        n = so.ExtractiveStainNormalizer("macenko")
+        n.fit(so.synth_tile(64, 64, 1001, so.M_TRUE_TGT))
+        self.stain_matrix_target, self.maxC_target = n.stain_matrix_target, n.maxC_target
+
+
+def _pooled_worker(rank, world, port, force_radix, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    _install_numpy_engine(force_radix)
+    tiles = _slide_tiles()
+    lo, hi = sd.shard_range(len(tiles), rank, world)              # 6 tiles -> 3 + 3; rank 1 holds the white-background tile
+    mine = torch.from_numpy(np.stack(tiles[lo:hi]))
+    stats = sd.PooledSlideStatistics()
+    M, maxC = stats(mine)
+    out, M_s, mc_s, st = sd.SlideNormalizer(_FittedTarget(), mode="pooled").transform_shard(mine)
+    q.put((rank, M, maxC, list(stats.last_path), out.numpy(), M_s.numpy(), mc_s.numpy()))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("force_radix", [False, True])
+def test_pooled_slide_statistics_real_call_on_two_gloo_ranks(force_radix):
+    from oracle import stain_oracle as so
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pooled_worker, args=(r, 2, port, force_radix, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # the single-rank run of the same code, and the reference's statistics of the concatenated slide
+    q1 = ctx.Queue()
+    p1 = ctx.Process(target=_pooled_worker, args=(0, 1, port, force_radix, q1))
+    p1.start()
+    one = q1.get(timeout=300)
+    p1.join(timeout=60)
+    tall = np.concatenate(_slide_tiles(), axis=0)
+    M_ref = so.macenko_stain_matrix(tall)
+    c_ref = np.percentile(so.get_concentrations(tall, M_ref), 99, axis=0)
+    for rank, M, maxC, path, out, M_s, mc_s in res:
+        # (on a slide of 18 k pixels the ranks k and k+1 of the 99th percentile lie further apart than one window is wide:
+        #  that stage legitimately falls back -- on every rank alike, since the decision is made on all-reduced counts)
+        assert path == (["radix", "radix"] if force_radix else ["window", "radix"]) and path == one[3]
+        assert np.array_equal(M, res[0][1]) and np.array_equal(maxC, res[0][2])    # the ranks agree to the bit (no broadcast needed)
+        np.testing.assert_allclose(M, one[1], rtol=0, atol=1e-12)                  # = the single-rank run up to the order of the
+        np.testing.assert_allclose(maxC, one[2], rtol=1e-12)                       #   moment sums (all-reduce of two partial sums)
+        np.testing.assert_allclose(M, M_ref, rtol=0, atol=2e-6)                    # = the reference on the concatenated image
+        np.testing.assert_allclose(maxC, c_ref, rtol=2e-6)
+        assert np.array_equal(M_s, M) and np.array_equal(mc_s, maxC)
+    both = np.concatenate([res[0][4], res[1][4]])                                  # the two shards' outputs = the single-rank output
+    d = both.astype(np.int16) - one[4].astype(np.int16)
+    assert np.abs(d).max() <= 1 and (d != 0).sum() <= 2                            # (1e-16 in M can flip a byte on a knife edge)
