@@ -80,6 +80,12 @@ def _cpu_worker(args):
         except OSError:
             pass
     _one_thread()
+    try:        # keep numpy's 25 MB temporaries in the heap instead of mmap/munmap per array: with one process per core the
+        libc = C.CDLL("libc.so.6")      # page-fault and memory-cgroup traffic of fresh mappings is what limits scaling
+        libc.mallopt(-3, 1 << 30)       # M_MMAP_THRESHOLD
+        libc.mallopt(-1, 2 ** 31 - 1)   # M_TRIM_THRESHOLD
+    except Exception:  # noqa: BLE001
+        pass
     from oracle import stain_oracle as so
     nrm = so.ExtractiveStainNormalizer("macenko")
     nrm.stain_matrix_target, nrm.maxC_target = Mt, mct.reshape(1, 2)
@@ -161,7 +167,9 @@ def cpu_baseline(size: int, transforms_per_core: int = 20):
         "parallel_efficiency": round(value / (len(cpus) / t_single), 3),
         "stage_seconds_single_thread": split,
         "note": "the lasso stage is a vectorised closed form, not spams' OpenMP LARS, and the mask an integer-table restatement, not "
-                "OpenCV: the reference's own third-party calls cannot be timed (absent); the stage split lets the reader discount them",
+                "OpenCV: the reference's own third-party calls cannot be timed (absent); the stage split lets the reader discount them. "
+                "parallel_efficiency = value / (cores x single-core rate): numpy's float64 temporaries (25 MB each, ~30 per transform) make "
+                "the port memory-bound, and the GPU boxes' hosts are shared with other jobs",
         "reference_crosscheck": cross,
     }
 
