@@ -220,9 +220,9 @@ template <bool ALIGNED>
 __global__ __launch_bounds__(kSweepThreads, 4) void k_tile_moment_partials(const uint8_t* rgb, int P, int parts, float ylimf, double* partials) {
     __shared__ RowTab s_tab;
     __shared__ double s_red[kSweepThreads / 64][10];
-    s_tab.fill();
+    s_tab.fill_b();
     __syncthreads();
-    const TabReader T = TabReader::make(s_tab);
+    const TabReaderB T = TabReaderB::make(s_tab);
     const int tile = blockIdx.x / parts, part = blockIdx.x % parts;
     const int tid = threadIdx.x, lane = tid & 63;
     const uint8_t* src = rgb + (size_t)tile * P * 3;
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_tile_moment_partials(const
     part_range((P + 3) >> 2, parts, part, c0, c1);
     Moments mo;
     uint32_t n_tissue = 0;
-    moments_sweep<ALIGNED, kPhaseTrip>(src, P, c0, c1, tid, kSweepThreads, T, ylimf, 6, nullptr, mo, n_tissue);
+    if (c0 < c1) moments_sweep_b<ALIGNED, kPhaseTrip>(src, P, c0, c1, tid, kSweepThreads, T, ylimf, 6, nullptr, mo, n_tissue);   // (block-uniform)
     double v[10];
     mo.to_array(v, n_tissue, lane);
 #pragma unroll

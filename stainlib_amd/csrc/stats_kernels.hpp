@@ -5,8 +5,8 @@
 //   -> lasso concentrations of ALL pixels -> percentile(99) per stain -> rescale -> 255 exp(-C M_t)
 //
 // Four dependent streaming sweeps over the uint8 tile, nothing per-pixel stored in between:
-//   sweep 1  moments   tissue test, 9 binary64 moment sums, one stratified-random sample pixel per
-//                      `stride` pixels
+//   sweep 1  moments   tissue test, 9 moment sums (binary32 bursts of one trip per lane, binary64 totals), one
+//                      stratified-random sample pixel per `stride` pixels
 //   finish 1           cov -> Jacobi eigh -> V ; sample -> brackets [lo,hi] that contain the 1st/99th
 //                      angular order statistics with overwhelming probability
 //   sweep 2  select    exact counts below / inside each bracket, bracket members ("candidates", ~1 %
@@ -41,7 +41,16 @@ namespace sl {
 constexpr int kMaxSample = 16384;   // samples per tile (<= P/64)
 constexpr int kMinCapRaw = 65536;   // raw-pixel candidate capacity per tile and stage: max(this, P/12), set by the host
 constexpr int kMinCapList = 16384;  // exact-key bracket members per list after the refine pass: max(this, P/40)
+#ifdef SL_EXP_FIN512
+constexpr int kFinishThreads = 512;
+#else
 constexpr int kFinishThreads = 1024;
+#endif
+#ifdef SL_EXP_FIN2
+#define SL_FINISH_BOUNDS __launch_bounds__(kFinishThreads, 2)
+#else
+#define SL_FINISH_BOUNDS __launch_bounds__(kFinishThreads)
+#endif
 constexpr int kFusedThreads = 512;  // 2 resident workgroups per CU (<=128 VGPRs, <80 KB LDS each)
 constexpr int kSweepThreads = 512;  // sweep kernels of the one-launch-per-phase schedule (same occupancy: 64 KB table each)
 constexpr int kFusedTrip = 4;       // chunks per lane and sweep trip in the fused kernel (even)
@@ -648,6 +657,26 @@ struct Moments {
     }
 };
 
+// The sums of ONE trip of one lane (kTrip chunks = 16 pixels) in binary32, then added to the binary64 totals: 9 fast
+// FMAs per pixel instead of 9 binary64 ones (4 issue cycles each, both pipes blocked), and the optical densities come from
+// the 8-byte {gamma, od32} rows (layout B: half the LDS time of the 16-byte rows, no table switch after the sweep).
+// A trip's pixel set is the same in both schedules (part_range keeps parts trip-aligned), so the binary32 partial sums are
+// bit-identical across schedules and batch sizes; only the order of the binary64 additions differs, as before.
+// Measured against the binary64 reference: stain matrix error 1.6e-8 -> 4e-8 (test tolerance 2e-6).
+struct BurstMoments {
+    float sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+    __device__ __forceinline__ void add(float x, float y, float z) {
+        sx += x; sy += y; sz += z;
+        sxx = fmaf(x, x, sxx); sxy = fmaf(x, y, sxy); sxz = fmaf(x, z, sxz);
+        syy = fmaf(y, y, syy); syz = fmaf(y, z, syz); szz = fmaf(z, z, szz);
+    }
+    __device__ __forceinline__ void flush(Moments& m) {
+        m.sx += (double)sx; m.sy += (double)sy; m.sz += (double)sz; m.sxx += (double)sxx; m.sxy += (double)sxy; m.sxz += (double)sxz;
+        m.syy += (double)syy; m.syz += (double)syz; m.szz += (double)szz;
+        sx = sy = sz = sxx = sxy = sxz = syy = syz = szz = 0.0f;
+    }
+};
+
 
 // Sample bookkeeping of one chunk row (64 chunks starting at the wave-uniform, 64-aligned chunk `row0`): the lane
 // whose chunk the draw selects stores pixel 0 or 3 of it.  Scalar hash, ~6 vector instructions per chunk.
@@ -663,71 +692,65 @@ __device__ __forceinline__ void sample_row(const Chunk& ch, int row0, int cc, in
     }
 }
 
-// Table values of two pixels (sweep 1 works in half chunks: 6 x ds_read_b128 = 24 VGPRs per stage)
-struct HalfGather { TabEntry e[6]; };
-
-// sweep 1 over chunks [c0, c1) with `nthreads` cooperating threads (thread index t); c0 must be a multiple of 64.
-// n_tissue is wave-uniform (a scalar popcount per pixel row).  Per pixel: 4 slow-pipe + 9 binary64 + 3 fast-pipe
-// instructions.  The LDS gathers run one stage (two pixels) ahead of the arithmetic: a wave has only three
-// partners on its SIMD to hide the ~100-cycle gather latency, so it must overlap its own.
-template <bool ALIGNED, int kTrip, class TR, bool STREAM = false>
-__device__ __forceinline__ void moments_sweep(const uint8_t* src, int P, int c0, int c1, int t, int nthreads,
-                                              const TR& T, float ylimf, int stride_log2, uint32_t* samp,
-                                              Moments& mo, uint32_t& n_tissue) {
+// Sweep 1 on the layout-B table ({gamma, od32} per byte): the structure of select_sweep (gathers of a chunk issued one chunk
+// ahead of its arithmetic, next trip's chunks in flight), tissue test, binary32 burst sums flushed once per trip.
+// c0 must be a multiple of 64; for schedule-independent bursts also of kTrip * nthreads (part_range guarantees it).
+template <bool ALIGNED, int kTrip, bool STREAM = false>
+__device__ __forceinline__ void moments_sweep_b(const uint8_t* src, int P, int c0, int c1, int t, int nthreads,
+                                                const TabReaderB& T, float ylimf, int stride_log2, uint32_t* samp,
+                                                Moments& mo, uint32_t& n_tissue) {
     const size_t nbytes = (size_t)P * 3;
     const int lane = t & 63;
     const int cps_log2 = stride_log2 - 2;          // chunks per sampling block
     const int w0 = __builtin_amdgcn_readfirstlane(c0 + (t & ~63));
-    auto fetch = [&](int cc) { return load_chunk_clamped<ALIGNED, STREAM>(src, nbytes, cc, c1); };   // dead lanes: see `live`
-    auto gather = [&](const Chunk& ch, int half) {
-        HalfGather g;
+    struct G { float2 v[12]; };
+    auto fetch = [&](int cc) { return load_chunk_clamped<ALIGNED, STREAM>(src, nbytes, cc, c1); };
+    auto gather = [&](const Chunk& ch) {
+        G g;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) g.e[i] = T.entry(T.addr(ch, 6 * half + i));
+        for (int i = 0; i < 12; ++i) g.v[i] = T.gam_odf(T.addr(ch, i));
         return g;
     };
-    // TAIL = false: every lane of the trip holds a chunk of in-range pixels, so the tissue predicate is the bare
-    // compare (a ballot of an AND of predicates costs two extra vector instructions, see tools/ubench notes)
-    auto compute = [&](auto tail_tag, const HalfGather& g, int cc, int half) {
+    BurstMoments bm;
+    auto compute = [&](auto tail_tag, const G& g, int cc) {
         constexpr bool TAIL = decltype(tail_tag)::value;
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const TabEntry &er = g.e[3 * p], &eg = g.e[3 * p + 1], &eb = g.e[3 * p + 2];
-            const bool tc = is_tissue_f(er.gam, eg.gam, eb.gam, ylimf);
+        for (int px = 0; px < 4; ++px) {
+            const float2 er = g.v[3 * px], eg = g.v[3 * px + 1], eb = g.v[3 * px + 2];
+            const bool tc = is_tissue_f(er.x, eg.x, eb.x, ylimf);
             if (!TAIL) {
                 n_tissue += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(tc));
-                if (tc) mo.add(er.od, eg.od, eb.od);             // 9 binary64 ops under the exec mask, no select
+                if (tc) bm.add(er.y, eg.y, eb.y);
             } else {
-                const bool inb = (cc < c1) & (ALIGNED | ((size_t)cc * 4 + 2 * half + p < (size_t)P));
+                const bool inb = (cc < c1) & (ALIGNED | ((size_t)cc * 4 + px < (size_t)P));
                 const unsigned long long m = __builtin_amdgcn_ballot_w64(tc) & __builtin_amdgcn_ballot_w64(inb);
                 n_tissue += (uint32_t)__popcll(m);
-                if (tc & inb) mo.add(er.od, eg.od, eb.od);
+                if (tc & inb) bm.add(er.y, eg.y, eb.y);
             }
         }
     };
-    // kTrip chunks per lane and trip, the next trip's chunks already requested: 2 x kTrip x 12 B in flight per
-    // lane -- with 16 waves per CU it takes that much to cover the HBM latency at full rate (measured)
     Chunk cur[kTrip], nx[kTrip];
 #pragma unroll
     for (int k = 0; k < kTrip; ++k) { cur[k] = fetch(w0 + lane + k * nthreads); nx[k] = fetch(w0 + lane + (kTrip + k) * nthreads); }
-    HalfGather g[2];
-    g[0] = gather(cur[0], 0);
+    G g[2];
+    g[0] = gather(cur[0]);
     auto trip = [&](auto tail_tag, int cb) {
 #pragma unroll
         for (int k = 0; k < kTrip; ++k) sample_row<ALIGNED>(cur[k], cb + k * nthreads, cb + k * nthreads + lane, c1, P, cps_log2, samp);
 #pragma unroll
-        for (int st = 0; st < 2 * kTrip; ++st) {             // stage = half chunk; gathers run one stage ahead
-            const int k = st >> 1, half = st & 1;
-            if (st + 1 < 2 * kTrip) {
-                g[(st + 1) & 1] = gather(cur[(st + 1) >> 1], (st + 1) & 1);
+        for (int k = 0; k < kTrip; ++k) {
+            if (k + 1 < kTrip) {
+                g[(k + 1) & 1] = gather(cur[k + 1]);
             } else {
 #pragma unroll
                 for (int j = 0; j < kTrip; ++j) { cur[j] = nx[j]; nx[j] = fetch(cb + lane + (2 * kTrip + j) * nthreads); }
-                g[0] = gather(cur[0], 0);
+                g[0] = gather(cur[0]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            compute(tail_tag, g[st & 1], cb + k * nthreads + lane, half);
+            compute(tail_tag, g[k & 1], cb + k * nthreads + lane);
             __builtin_amdgcn_sched_barrier(0);
         }
+        bm.flush(mo);
     };
     const int lim = ALIGNED ? c1 : min(c1, P >> 2);          // chunks made of in-range pixels only
     int cb = w0;
@@ -1505,9 +1528,12 @@ __device__ __forceinline__ void dict_learn(const uint8_t* src, int P, int nch, i
 // ------------------------------------------------------------------------------------------
 // multi-kernel schedule
 // ------------------------------------------------------------------------------------------
-// chunk range of part `part` of a tile: spans are multiples of 64 chunks so that every wave row is 64-aligned
+// chunk range of part `part` of a tile: spans are multiples of one sweep trip of a workgroup (kSweepThreads x kPhaseTrip =
+// 2048 chunks), so that every wave row is 64-aligned AND every lane's trips cover the same pixels as in the fused kernel
+// (the binary32 burst sums of moments_sweep_b are then identical in both schedules); trailing parts may be empty
 __device__ __forceinline__ void part_range(int nch, int parts, int part, int& c0, int& c1) {
-    const int span = (((nch + parts - 1) / parts) + 63) & ~63;
+    constexpr int kAlign = kSweepThreads * kPhaseTrip;
+    const int span = (((nch + parts - 1) / parts) + kAlign - 1) / kAlign * kAlign;
     c0 = min(nch, part * span);
     c1 = min(nch, c0 + span);
 }
@@ -1518,9 +1544,9 @@ template <bool ALIGNED>
 static __global__ __launch_bounds__(kSweepThreads, 4) void k_moments(StatsArgs a) {
     __shared__ RowTab s_tab;
     __shared__ double s_red[kSweepThreads / 64][10];
-    s_tab.fill();
+    s_tab.fill_b();
     __syncthreads();
-    const TabReader T = TabReader::make(s_tab);
+    const TabReaderB T = TabReaderB::make(s_tab);
     const int tid = threadIdx.x, lane = tid & 63;
     for (int item = blockIdx.x; item < a.n_items; item += gridDim.x) {
         const int tile = item / a.parts, part = item % a.parts;
@@ -1530,10 +1556,11 @@ static __global__ __launch_bounds__(kSweepThreads, 4) void k_moments(StatsArgs a
         part_range((a.P + 3) >> 2, a.parts, part, c0, c1);
         Moments mo;
         uint32_t n_tissue = 0;
-        if ((size_t)a.P * 3 >= kStreamBytes)      // uniform: non-temporal tile loads for big tiles (see kStreamBytes)
-            moments_sweep<ALIGNED, kPhaseTrip, TabReader, true>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, a.stride_log2, samp, mo, n_tissue);
+        if (c0 >= c1) {                            // an empty trailing part (block-uniform): its partial sums are zeros
+        } else if ((size_t)a.P * 3 >= kStreamBytes)      // uniform: non-temporal tile loads for big tiles (see kStreamBytes)
+            moments_sweep_b<ALIGNED, kPhaseTrip, true>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, a.stride_log2, samp, mo, n_tissue);
         else
-            moments_sweep<ALIGNED, kPhaseTrip, TabReader, false>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, a.stride_log2, samp, mo, n_tissue);
+            moments_sweep_b<ALIGNED, kPhaseTrip, false>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, a.stride_log2, samp, mo, n_tissue);
         double v[10];
         mo.to_array(v, n_tissue, lane);
 #pragma unroll
@@ -1594,7 +1621,7 @@ __device__ __forceinline__ void conc_brackets(const SampleConcKey& key, int n_sa
     wg_brackets_regs<2, KPT, 2>(ord, set_of, p2, lo, hi, S);
 }
 
-static __global__ __launch_bounds__(kFinishThreads) void k_finish_moments(StatsArgs a) {
+static __global__ SL_FINISH_BOUNDS void k_finish_moments(StatsArgs a) {
     __shared__ SmallTab s_tab;
     __shared__ SelScratch S;
     __shared__ double s_sum[10];
@@ -1661,7 +1688,7 @@ static __global__ __launch_bounds__(kSweepThreads, 4) void k_select(StatsArgs a)
     }
 }
 
-static __global__ __launch_bounds__(kFinishThreads) void k_finish_angle(StatsArgs a) {
+static __global__ SL_FINISH_BOUNDS void k_finish_angle(StatsArgs a) {
     __shared__ SmallTab s_tab;
     __shared__ SelScratch S;
     __shared__ float s_res[4];
@@ -1729,7 +1756,7 @@ static __global__ __launch_bounds__(kFinishThreads) void k_finish_angle(StatsArg
     if (tid == 0) { st.lo[0] = lo[0]; st.hi[0] = hi[0]; st.lo[1] = lo[1]; st.hi[1] = hi[1]; }
 }
 
-static __global__ __launch_bounds__(kFinishThreads) void k_finish_conc(StatsArgs a, double* M_out, double* maxC_out,
+static __global__ SL_FINISH_BOUNDS void k_finish_conc(StatsArgs a, double* M_out, double* maxC_out,
                                                                        int32_t* status_out, int32_t* fallbacks_out, int tile0) {
     __shared__ SmallTab s_tab;
     __shared__ SelScratch S;
@@ -2042,7 +2069,10 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
 #define SL_SUB(j)
 #endif
         SL_PHASE(0);
-        sh.tab.fill();                       // layout A for the moment / dictionary sweeps (all waves left the last tile's apply)
+        // Vahadane: layout A for the dictionary sweeps (binary64 optical densities), rewritten per tile (all waves left the
+        // last tile's apply); Macenko works on layout B throughout: written once, before the first tile
+        if (METHOD == kMethodVahadane) sh.tab.fill();
+        else if (tile == (int)blockIdx.x) sh.tab.fill_b();
         __syncthreads();
 
         if (METHOD == kMethodMacenko) {
@@ -2050,8 +2080,8 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
             {
                 Moments mo;
                 uint32_t n_tissue = 0;
-                if (stream) moments_sweep<ALIGNED, kFusedTrip, TabReader, true>(src, a.P, 0, nch, tid, NT, T, a.ylimf, a.stride_log2, samp, mo, n_tissue);
-                else moments_sweep<ALIGNED, kFusedTrip, TabReader, false>(src, a.P, 0, nch, tid, NT, T, a.ylimf, a.stride_log2, samp, mo, n_tissue);
+                if (stream) moments_sweep_b<ALIGNED, kFusedTrip, true>(src, a.P, 0, nch, tid, NT, TB, a.ylimf, a.stride_log2, samp, mo, n_tissue);
+                else moments_sweep_b<ALIGNED, kFusedTrip, false>(src, a.P, 0, nch, tid, NT, TB, a.ylimf, a.stride_log2, samp, mo, n_tissue);
                 double v[10];
                 mo.to_array(v, n_tissue, lane);
 #pragma unroll
@@ -2060,7 +2090,6 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
                     for (int i = 0; i < 10; ++i) sh.red[wave][i] = v[i];
             }
             __syncthreads();
-            sh.tab.fill_b();                 // every wave is past sweep 1: switch the table to layout B (~1 us)
             if (tid < 10) {
                 double t = 0;
                 for (int w = 0; w < NT / 64; ++w) t += sh.red[w][tid];

@@ -165,10 +165,12 @@ def test_fit_1024_vs_oracle_and_permutation_invariance():
     Mo, mco = _fit_oracle(I)
     np.testing.assert_allclose(M[0], Mo, rtol=0, atol=M_ATOL)
     np.testing.assert_allclose(mc[0], mco, rtol=MAXC_RTOL)
-    # get_stain_matrix depends on the multiset of pixels only; order statistics are exact => bit-equal keys,
-    # moment sums differ only by binary64 summation order
-    np.testing.assert_allclose(M[1], M[0], rtol=0, atol=1e-12)
-    np.testing.assert_allclose(mc[1], mc[0], rtol=1e-12)
+    # get_stain_matrix depends on the multiset of pixels only.  The moment sums are formed in binary32 bursts of 16 pixels
+    # per lane (then binary64): permuting the pixels regroups the bursts, which moves the covariance by ~1e-8 relative --
+    # the same size as the error against the float64 oracle (the order statistics themselves are exact on their keys)
+    np.testing.assert_allclose(M[1], M[0], rtol=0, atol=2e-7)
+    np.testing.assert_allclose(mc[1], mc[0], rtol=2e-6)
+    print("permutation: |dM|", np.abs(M[1] - M[0]).max(), "vs oracle", np.abs(M[0] - Mo).max())
 
 
 def test_params_are_honoured():

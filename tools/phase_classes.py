@@ -16,7 +16,8 @@ size = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 tgt = synth_tiles(1, size, size, seed=1, M_true=[[0.55, 0.75, 0.35], [0.10, 0.95, 0.20]])
 Mt, mct, st = engine.macenko_fit(tgt)
 ev = HipEvents(4096)
-for n in (16, 32, 48, 64, 96, 128, 256, 512):
+ns = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [16, 32, 48, 64, 96, 128, 256, 512]
+for n in ns:
     rgb = synth_tiles(n, size, size, seed=3)
     out = torch.empty_like(rgb)
     p = engine.make_params(schedule=1)

@@ -5,10 +5,11 @@ sys.path.insert(0, ".")
 from stainlib_amd import engine
 from tools.synth import synth_tiles
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+sched = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rgb = synth_tiles(n, 1024, 1024, seed=3)
 tgt = synth_tiles(1, 1024, 1024, seed=1, M_true=[[0.55, 0.75, 0.35], [0.10, 0.95, 0.20]])
 Mt, mct, st = engine.macenko_fit(tgt)
 out = torch.empty_like(rgb)
 for _ in range(3):
-    engine.macenko_transform(rgb, Mt[0], mct[0], out=out)
+    engine.macenko_transform(rgb, Mt[0], mct[0], out=out, params=engine.make_params(schedule=sched))
 torch.cuda.synchronize()
