@@ -144,14 +144,14 @@ int run_dict_group(const uint8_t* rgb, int g0, int m, long P, const SlParams& p,
     a.sweeps_out = sweeps_out;
     const bool al = aligned4(a.rgb, P);
     const long items = (long)m * L.parts;
-    const dim3 gs((unsigned)(items < L.max_grid ? items : L.max_grid)), bs(kSweepThreads), gf((unsigned)m), bf(kFinishThreads);
+    const dim3 gs((unsigned)(items < L.max_grid ? items : L.max_grid)), bs(kSweepThreads), gf((unsigned)m), bf(kFinishThreads), bd(kDictFinishThreads);
     SlProfile* prof = p.profile;
     {
         ProfScope ps(prof, SL_PROF_DICT, m, s);
         if (al) hipLaunchKernelGGL((k_dict<true, true>), gs, bs, 0, s, a);
         else    hipLaunchKernelGGL((k_dict<false, true>), gs, bs, 0, s, a);
     }
-    { ProfScope ps(prof, SL_PROF_FINISH, m, s); hipLaunchKernelGGL(k_dict_finish, gf, bf, 0, s, a, 1); }
+    { ProfScope ps(prof, SL_PROF_FINISH, m, s); hipLaunchKernelGGL(k_dict_finish, gf, bd, 0, s, a, 1); }
     const int fixed = a.dl_max_sweeps - 1 < kDictFixedSweeps ? a.dl_max_sweeps - 1 : kDictFixedSweeps;
     for (int i = 0; i < fixed; ++i) {
         {
@@ -159,12 +159,12 @@ int run_dict_group(const uint8_t* rgb, int g0, int m, long P, const SlParams& p,
             if (al) hipLaunchKernelGGL((k_dict<true, false>), gs, bs, 0, s, a);
             else    hipLaunchKernelGGL((k_dict<false, false>), gs, bs, 0, s, a);
         }
-        { ProfScope ps(prof, SL_PROF_FINISH, m, s); hipLaunchKernelGGL(k_dict_finish, gf, bf, 0, s, a, 0); }
+        { ProfScope ps(prof, SL_PROF_FINISH, m, s); hipLaunchKernelGGL(k_dict_finish, gf, bd, 0, s, a, 0); }
     }
     {
         ProfScope ps(prof, SL_PROF_FINISH, m, s);
-        if (al) hipLaunchKernelGGL((k_dict_tail<true>), gf, bf, 0, s, a);
-        else    hipLaunchKernelGGL((k_dict_tail<false>), gf, bf, 0, s, a);
+        if (al) hipLaunchKernelGGL((k_dict_tail<true>), gf, bd, 0, s, a);
+        else    hipLaunchKernelGGL((k_dict_tail<false>), gf, bd, 0, s, a);
     }
     {
         ProfScope ps(prof, SL_PROF_SELECT_CONC, m, s);
@@ -212,23 +212,16 @@ int run_fused(int method, const uint8_t* rgb, uint8_t* out, int n, long P, const
     a.dl_max_sweeps = p.dl_max_sweeps > 0 ? p.dl_max_sweeps : 1;
     a.sweeps_out = sweeps_out;
     const bool al = aligned4(rgb, P) && (!out || aligned4(out, P));
-    // Vahadane batches that cannot fill two workgroup slots per CU run one 1024-thread workgroup per tile instead
-    const bool wide = method == kMethodVahadane && n <= L.max_grid / 2;
-    const dim3 g((unsigned)L.grid), b(wide ? 1024 : kFusedThreads);
+    const dim3 g((unsigned)L.grid), b(kFusedThreads);
     ProfScope ps(p.profile, out ? SL_PROF_FUSED_TRANSFORM : SL_PROF_FUSED_FIT, n, s);
 #define SL_GO(M, T, A) hipLaunchKernelGGL((k_fused<M, T, A, kFusedThreads>), g, b, 0, s, a)
-#define SL_GO_WIDE(M, T, A) hipLaunchKernelGGL((k_fused<M, T, A, 1024>), g, b, 0, s, a)
     if (method == kMethodMacenko) {
         if (out) { if (al) SL_GO(kMethodMacenko, true, true); else SL_GO(kMethodMacenko, true, false); }
         else     { if (al) SL_GO(kMethodMacenko, false, true); else SL_GO(kMethodMacenko, false, false); }
-    } else if (wide) {
-        if (out) { if (al) SL_GO_WIDE(kMethodVahadane, true, true); else SL_GO_WIDE(kMethodVahadane, true, false); }
-        else     { if (al) SL_GO_WIDE(kMethodVahadane, false, true); else SL_GO_WIDE(kMethodVahadane, false, false); }
     } else {
         if (out) { if (al) SL_GO(kMethodVahadane, true, true); else SL_GO(kMethodVahadane, true, false); }
         else     { if (al) SL_GO(kMethodVahadane, false, true); else SL_GO(kMethodVahadane, false, false); }
     }
-#undef SL_GO_WIDE
 #undef SL_GO
     return launch_status();
 }

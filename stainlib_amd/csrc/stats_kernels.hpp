@@ -1097,123 +1097,170 @@ struct RawSink {
 // fixed point is the one plain full-batch block-coordinate descent reaches (oracle:
 // vahadane_dictionary), but in ~9 sweeps instead of ~90.
 // ------------------------------------------------------------------------------------------
-// binary64 twin of LassoK for the dictionary sweep: the active set is decided in binary64 so that the
-// partition (and with it the fixed-point iteration) is reproducible to ~1e-16, far below any dl_tol
-struct LassoK64 {
-    double wa1[3], ka1, wa2[3], ka2, ws1[3], ks1, ws2[3], ks2, g12, g22;
-};
-__device__ __forceinline__ void lasso_consts64(const double* M, double lam, LassoK64& k) {
-    const double g11 = M[0] * M[0] + M[1] * M[1] + M[2] * M[2];
-    const double g22 = M[3] * M[3] + M[4] * M[4] + M[5] * M[5];
-    const double g12 = M[0] * M[3] + M[1] * M[4] + M[2] * M[5];
-    const double det = g11 * g22 - g12 * g12;
-    const double i11 = g22 / det, i12 = -g12 / det, i22 = g11 / det;
-    for (int c = 0; c < 3; ++c) {
-        k.wa1[c] = i11 * M[c] + i12 * M[3 + c];
-        k.wa2[c] = i12 * M[c] + i22 * M[3 + c];
-        k.ws1[c] = M[c] / g11;
-        k.ws2[c] = M[3 + c] / g22;
-    }
-    k.ka1 = -lam * (i11 + i12); k.ka2 = -lam * (i12 + i22); k.ks1 = -lam / g11; k.ks2 = -lam / g22;
-    k.g12 = g12; k.g22 = g22;
-}
-__device__ __forceinline__ double uni(double v) {
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffLL)), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-__device__ __forceinline__ void uni(LassoK64& k) {
-    for (int c = 0; c < 3; ++c) { k.wa1[c] = uni(k.wa1[c]); k.wa2[c] = uni(k.wa2[c]); k.ws1[c] = uni(k.ws1[c]); k.ws2[c] = uni(k.ws2[c]); }
-    k.ka1 = uni(k.ka1); k.ka2 = uni(k.ka2); k.ks1 = uni(k.ks1); k.ks2 = uni(k.ks2); k.g12 = uni(k.g12); k.g22 = uni(k.g22);
-}
-
-struct ClsAcc {
-    double sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
-    uint32_t n = 0;
-    __device__ __forceinline__ void add(double x, double y, double z) {
-        n += 1;
+// ---- class moments in binary32 bursts --------------------------------------------------------------------------------
+// The classification (which of the code's active sets a pixel falls in) and the nine moment products are binary32; a lane
+// sums them over kDictBurstTrips trips (128 pixels), then the wave adds its 64 lanes' bursts (DPP, binary32) into its
+// binary64 row of workgroup memory.  Per pixel: 12 fast FMAs + 5 compares to classify, 9 fast FMAs under the class's exec
+// mask to accumulate -- the binary64 version issued 41 binary64 instructions (4 cycles each, both pipes blocked) and three
+// 16-byte LDS gathers.  A pixel next to a class boundary may land on the other side than in exact arithmetic; the code is
+// continuous across the boundary, so its contribution moves by its distance to the boundary (~1e-7): far below dl_tol.
+// The bursts cover the same pixels in the fused kernel and in the per-phase kernels (parts are aligned to
+// kDictBurstTrips trips of a 512-thread workgroup): both schedules iterate the same map.
+constexpr int kDictTrip = 2;             // chunks per lane and trip in the dictionary sweeps (register pressure: 27 burst sums live)
+constexpr int kDictBurstTrips = 16;      // trips per burst: 16 x 2 x 512 chunks = 64 Ki pixels per workgroup = 128 pixels per lane
+constexpr int kDictAlignTrips = kDictBurstTrips * kDictTrip / 4;   // the same span in units of the sweep kernels' 4-chunk trips (part_range)
+struct ClsBurst {
+    float sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+    __device__ __forceinline__ void add(float x, float y, float z) {
         sx += x; sy += y; sz += z;
-        sxx = fma(x, x, sxx); sxy = fma(x, y, sxy); sxz = fma(x, z, sxz);
-        syy = fma(y, y, syy); syz = fma(y, z, syz); szz = fma(z, z, szz);
-    }
-    __device__ __forceinline__ void to_array(double* v) const {
-        v[0] = (double)n; v[1] = sx; v[2] = sy; v[3] = sz; v[4] = sxx; v[5] = sxy; v[6] = sxz;
-        v[7] = syy; v[8] = syz; v[9] = szz;
+        sxx = fmaf(x, x, sxx); sxy = fmaf(x, y, sxy); sxz = fmaf(x, z, sxz);
+        syy = fmaf(y, y, syy); syz = fmaf(y, z, syz); szz = fmaf(z, z, szz);
     }
 };
 
-// classify every tissue pixel of chunks [c0,c1) under the dictionary L and accumulate the moments of classes
-// both / only-1 / only-2; n_tissue (wave-uniform) counts all tissue pixels.  c0 must be a multiple of 64.
-template <bool ALIGNED, bool SAMPLE, bool STREAM = false>
-__device__ __forceinline__ void dict_sweep(const uint8_t* src, int P, int c0, int c1, int t, int nthreads, const TabReader& T,
-                                           float ylimf, int stride_log2, const LassoK64& L, uint32_t* samp,
-                                           ClsAcc (&acc)[3], uint32_t& n_tissue) {
+// sum over the 64 lanes of a wave, valid in lane 63 (DPP: no LDS traffic)
+__device__ __forceinline__ float wave_total_f32(float v) {
+#define SL_DPP_ADD(ctrl, rmask) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xf, false))
+    SL_DPP_ADD(0x111, 0xf);      // row_shr:1
+    SL_DPP_ADD(0x112, 0xf);      // row_shr:2
+    SL_DPP_ADD(0x114, 0xf);      // row_shr:4
+    SL_DPP_ADD(0x118, 0xf);      // row_shr:8   -> lane 15 of every row holds the row's sum
+    SL_DPP_ADD(0x142, 0xa);      // row_bcast:15 -> rows 1, 3
+    SL_DPP_ADD(0x143, 0xc);      // row_bcast:31 -> rows 2, 3: lane 63 holds the wave's sum
+#undef SL_DPP_ADD
+    return v;
+}
+
+// the dictionary as the classification needs it (VGPR-resident)
+struct DictK { float m1[3], m2[3], nlam, g11, g12, g22; };
+__device__ __forceinline__ void dict_consts(const double* D, double lam, DictK& k) {
+    for (int c = 0; c < 3; ++c) { k.m1[c] = in_vgpr((float)D[c]); k.m2[c] = in_vgpr((float)D[3 + c]); }
+    k.nlam = in_vgpr((float)(-lam));
+    k.g11 = in_vgpr((float)(D[0] * D[0] + D[1] * D[1] + D[2] * D[2]));
+    k.g22 = in_vgpr((float)(D[3] * D[3] + D[4] * D[4] + D[5] * D[5]));
+    k.g12 = in_vgpr((float)(D[0] * D[3] + D[1] * D[4] + D[2] * D[5]));
+}
+
+// the wave's binary64 row: [class][n, s(3), q(6)] for classes both / only-1 / only-2, then [30] = tissue pixels
+struct DictWaveAcc {
+    ClsBurst b[3];
+    uint32_t n[3] = {0, 0, 0};            // wave-uniform counts of the current burst
+    uint32_t n_tissue = 0;
+    double* row;                          // 32 doubles of workgroup memory owned by this wave
+    __device__ __forceinline__ void begin(double* r, int lane) {
+        row = r;
+        if (lane < 32) row[lane] = 0.0;
+    }
+    __device__ __forceinline__ void flush(int lane) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v[9] = {b[c].sx, b[c].sy, b[c].sz, b[c].sxx, b[c].sxy, b[c].sxz, b[c].syy, b[c].syz, b[c].szz};
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const float t = wave_total_f32(v[i]);
+                if (lane == 63) row[10 * c + 1 + i] += (double)t;
+            }
+            if (lane == 63) row[10 * c] += (double)n[c];
+            b[c] = ClsBurst{};
+            n[c] = 0;
+        }
+        if (lane == 63) row[30] += (double)n_tissue;
+        n_tissue = 0;
+    }
+    // one pixel: tissue = the lane's pixel counts; od = (x, y, z)
+    // The active set from the NUMERATORS of the interior solution (b = D x - lambda; a = G^-1 b has the signs of
+    // n1 = g22 b1 - g12 b2, n2 = g11 b2 - g12 b1): two nearly parallel atoms (early sweeps) make G^-1 large and a binary32
+    // a = W x + k cancels catastrophically, the numerators do not.  only-1 holds when b1 > 0 and the gradient with respect
+    // to the second code at (b1/g11, 0) is non-positive, i.e. n2 <= 0.
+    __device__ __forceinline__ void pixel(const DictK& L, bool tissue, float x, float y, float z) {
+        const float b1 = fmaf(L.m1[2], z, fmaf(L.m1[1], y, fmaf(L.m1[0], x, L.nlam)));
+        const float b2 = fmaf(L.m2[2], z, fmaf(L.m2[1], y, fmaf(L.m2[0], x, L.nlam)));
+        const float n1 = fmaf(L.g22, b1, -L.g12 * b2), n2 = fmaf(L.g11, b2, -L.g12 * b1);
+        const bool both = tissue & (n1 >= 0.0f) & (n2 >= 0.0f);
+        const bool only1 = tissue & !both & (b1 > 0.0f) & (n2 <= 0.0f);
+        const bool only2 = tissue & !both & !only1 & (b2 > 0.0f);
+        n_tissue += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(tissue));
+        n[0] += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(both));
+        n[1] += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(only1));
+        n[2] += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(only2));
+        if (both) b[0].add(x, y, z);
+        if (only1) b[1].add(x, y, z);
+        if (only2) b[2].add(x, y, z);
+    }
+};
+
+// classify every tissue pixel of chunks [c0,c1) under the dictionary L and accumulate the class moments into acc (its row
+// must have been begun; the caller flushes nothing: the sweep ends flushed).  c0 must be a multiple of 64 (of
+// kDictBurstTrips trips for schedule-independent bursts).  Structure of moments_sweep_b.
+template <bool ALIGNED, bool SAMPLE, int kTrip, bool STREAM = false>
+__device__ __forceinline__ void dict_sweep_b(const uint8_t* src, int P, int c0, int c1, int t, int nthreads, const TabReaderB& T,
+                                             float ylimf, int stride_log2, const DictK& L, uint32_t* samp, DictWaveAcc& acc) {
     const size_t nbytes = (size_t)P * 3;
     const int lane = t & 63;
     const int cps_log2 = stride_log2 - 2;
     const int w0 = __builtin_amdgcn_readfirstlane(c0 + (t & ~63));
-    for (int cb = w0; cb < c1; cb += nthreads * 2) {
-        Chunk in[2];
+    struct G { float2 v[12]; };
+    auto fetch = [&](int cc) { return load_chunk_clamped<ALIGNED, STREAM>(src, nbytes, cc, c1); };
+    auto gather = [&](const Chunk& ch) {
+        G g;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int cc = cb + lane + u * nthreads;
-            in[u] = load_chunk_clamped<ALIGNED, STREAM>(src, nbytes, cc, c1);
+        for (int i = 0; i < 12; ++i) g.v[i] = T.gam_odf(T.addr(ch, i));
+        return g;
+    };
+    auto compute = [&](auto tail_tag, const G& g, int cc) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            const float2 er = g.v[3 * px], eg = g.v[3 * px + 1], eb = g.v[3 * px + 2];
+            bool tissue = is_tissue_f(er.x, eg.x, eb.x, ylimf);
+            if (TAIL) tissue = tissue & (cc < c1) & (ALIGNED | ((size_t)cc * 4 + px < (size_t)P));
+            acc.pixel(L, tissue, er.y, eg.y, eb.y);
+        }
+    };
+    // (no gather look-ahead here: the 27 burst sums leave no room for a second set of table values, and the sweep is bound by
+    //  its ~60 vector instructions per pixel, not by the LDS latency the other waves of the SIMD cover)
+    Chunk cur[kTrip], nx[kTrip];
+#pragma unroll
+    for (int k = 0; k < kTrip; ++k) { cur[k] = fetch(w0 + lane + k * nthreads); nx[k] = fetch(w0 + lane + (kTrip + k) * nthreads); }
+    int trips = 0;
+    auto trip = [&](auto tail_tag, int cb) {
+        if (SAMPLE) {
+#pragma unroll
+            for (int k = 0; k < kTrip; ++k) sample_row<ALIGNED>(cur[k], cb + k * nthreads, cb + k * nthreads + lane, c1, P, cps_log2, samp);
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int row0 = cb + u * nthreads, cc = row0 + lane;
-            if (SAMPLE) sample_row<ALIGNED>(in[u], row0, cc, c1, P, cps_log2, samp);
-            const bool live = cc < c1;
-#pragma unroll
-            for (int px = 0; px < 4; ++px) {
-                const TabEntry er = T.entry(T.addr(in[u], 3 * px)), eg = T.entry(T.addr(in[u], 3 * px + 1)),
-                               eb = T.entry(T.addr(in[u], 3 * px + 2));
-                bool tissue = live & is_tissue_f(er.gam, eg.gam, eb.gam, ylimf);
-                if (!ALIGNED) tissue = tissue & ((size_t)cc * 4 + px < (size_t)P);
-                n_tissue += (uint32_t)__popcll(__ballot(tissue));
-                const double ox = er.od, oy = eg.od, oz = eb.od;
-                // active set of the exact code (same quantities as lasso2, in binary64)
-                const double a1 = fma(L.wa1[2], oz, fma(L.wa1[1], oy, fma(L.wa1[0], ox, L.ka1)));
-                const double a2 = fma(L.wa2[2], oz, fma(L.wa2[1], oy, fma(L.wa2[0], ox, L.ka2)));
-                const double s1 = fma(L.ws1[2], oz, fma(L.ws1[1], oy, fma(L.ws1[0], ox, L.ks1)));
-                const double s2 = fma(L.ws2[2], oz, fma(L.ws2[1], oy, fma(L.ws2[0], ox, L.ks2)));
-                const bool both = (a1 >= 0.0) & (a2 >= 0.0);
-                const bool only1 = !both & (s1 > 0.0) & (fma(-L.g12, s1, L.g22 * s2) <= 0.0);
-                const bool only2 = !both & !only1 & (s2 > 0.0);
-                if (tissue & both) acc[0].add(ox, oy, oz);
-                if (tissue & only1) acc[1].add(ox, oy, oz);
-                if (tissue & only2) acc[2].add(ox, oy, oz);
-            }
+        for (int k = 0; k < kTrip; ++k) {
+            const G g = gather(cur[k]);
+            compute(tail_tag, g, cb + k * nthreads + lane);
         }
-    }
+#pragma unroll
+        for (int j = 0; j < kTrip; ++j) { cur[j] = nx[j]; nx[j] = fetch(cb + lane + (2 * kTrip + j) * nthreads); }
+        if (++trips == kDictBurstTrips) { acc.flush(lane); trips = 0; }          // wave-uniform
+    };
+    const int lim = ALIGNED ? c1 : min(c1, P >> 2);
+    int cb = w0;
+    for (; cb + (kTrip - 1) * nthreads + 64 <= lim; cb += nthreads * kTrip) trip(std::false_type{}, cb);
+    if (cb < c1) trip(std::true_type{}, cb);
+    if (trips) acc.flush(lane);
 }
 
-// the same classification + accumulation over the tile's stratified SAMPLE (tissue entries only): a
-// 1/64-cost stand-in for a full sweep, used to bring D close to its fixed point before touching the tile again
-__device__ __forceinline__ void dict_sweep_sample(const uint32_t* samp, int n_sample, int stride_log2, int P, int t,
-                                                  int nthreads, const TabReader& T, float ylimf, const LassoK64& L,
-                                                  ClsAcc (&acc)[3], uint32_t& n_tissue) {
+// the same classification + accumulation over the tile's stratified SAMPLE (tissue entries only): a 1/64-cost stand-in for
+// a full sweep, used to bring D close to its fixed point before touching the tile again.  Always walked by 512 "virtual
+// lanes" (threads beyond 511 idle) so that the bursts do not depend on the workgroup size of the calling kernel.
+__device__ __forceinline__ void dict_sweep_sample_b(const uint32_t* samp, int n_sample, int stride_log2, int P, int t,
+                                                    const TabReaderB& T, float ylimf, const DictK& L, DictWaveAcc& acc) {
     const int lane = t & 63;
     const int cps_log2 = stride_log2 - 2;
-    for (int b0 = t & ~63; b0 < n_sample; b0 += nthreads) {
-        const int b = b0 + lane;
-        const bool have = b < n_sample && sample_pixel((uint32_t)b, cps_log2) < P;
-        const uint32_t s = samp[have ? b : 0];                      // unconditional load (n_sample >= 1); `have` masks the result
-        const TabEntry er = T.entry(T.addr(s, 0)), eg = T.entry(T.addr(s, 1)), eb = T.entry(T.addr(s, 2));
-        const bool tissue = have & is_tissue_f(er.gam, eg.gam, eb.gam, ylimf);
-        n_tissue += (uint32_t)__popcll(__ballot(tissue));
-        const double ox = er.od, oy = eg.od, oz = eb.od;
-        const double a1 = fma(L.wa1[2], oz, fma(L.wa1[1], oy, fma(L.wa1[0], ox, L.ka1)));
-        const double a2 = fma(L.wa2[2], oz, fma(L.wa2[1], oy, fma(L.wa2[0], ox, L.ka2)));
-        const double s1 = fma(L.ws1[2], oz, fma(L.ws1[1], oy, fma(L.ws1[0], ox, L.ks1)));
-        const double s2 = fma(L.ws2[2], oz, fma(L.ws2[1], oy, fma(L.ws2[0], ox, L.ks2)));
-        const bool both = (a1 >= 0.0) & (a2 >= 0.0);
-        const bool only1 = !both & (s1 > 0.0) & (fma(-L.g12, s1, L.g22 * s2) <= 0.0);
-        const bool only2 = !both & !only1 & (s2 > 0.0);
-        if (tissue & both) acc[0].add(ox, oy, oz);
-        if (tissue & only1) acc[1].add(ox, oy, oz);
-        if (tissue & only2) acc[2].add(ox, oy, oz);
+    if (t < 512) {                                                      // wave-uniform
+        for (int b0 = t & ~63; b0 < n_sample; b0 += 512) {
+            const int b = b0 + lane;
+            const bool have = b < n_sample && sample_pixel((uint32_t)b, cps_log2) < P;
+            const uint32_t s = samp[have ? b : 0];                      // unconditional load (n_sample >= 1); `have` masks the result
+            const float2 er = T.gam_odf(T.addr(s, 0)), eg = T.gam_odf(T.addr(s, 1)), eb = T.gam_odf(T.addr(s, 2));
+            acc.pixel(L, have & is_tissue_f(er.x, eg.x, eb.x, ylimf), er.y, eg.y, eb.y);
+        }
     }
+    acc.flush(lane);
 }
 
 // A (2x2) and B (3x2) of the dictionary update from the class moments m[c] = {n, s(3), q(6)}: with the codes of a
@@ -1485,33 +1532,26 @@ __device__ __forceinline__ bool dict_advance(DictIter& it, DictProgress& pr, dou
 // One workgroup iterates a tile's dictionary from (it, pr) until it settles.  Schedule: one full sweep (it also drops
 // the sample), then the SAME fixed-point iteration on the 16 Ki-pixel sample until it settles (each step costs 1/64 of
 // a sweep), then full sweeps from that warm start until the dictionary moves by less than tol: ~4 full sweeps instead
-// of ~9.  T must be a layout-A reader; red/sum are workgroup scratch.  Ends with a barrier.  SAMPLE_ONLY: only the
+// of ~9.  red/sum are workgroup scratch.  Ends with a barrier.  SAMPLE_ONLY: only the
 // sample stage (the per-phase schedule runs the full sweeps as launches of their own).
 template <bool ALIGNED, int NT, bool SAMPLE_ONLY = false, bool STREAM = false>
-__device__ __forceinline__ void dict_learn(const uint8_t* src, int P, int nch, int tid, const TabReader& T, float ylimf,
+__device__ __forceinline__ void dict_learn(const uint8_t* src, int P, int nch, int tid, const TabReaderB& T, float ylimf,
                                            int stride_log2, uint32_t* samp, int n_sample, double lam, double tol, int max_sweeps,
                                            DictIter& it, double (*red)[32], double* sum, DictProgress& pr) {
+    static_assert(SAMPLE_ONLY || NT == kSweepThreads, "full sweeps run with the 512-thread trip geometry of the sweep kernels");
     const int lane = tid & 63, wave = tid >> 6;
     while (pr.sweeps_used < max_sweeps && (!SAMPLE_ONLY || pr.stage == 1)) {
-        LassoK64 Ld;
-        lasso_consts64(it.D, lam, Ld);
-        uni(Ld);
-        ClsAcc acc[3];
-        uint32_t n_tissue = 0;
-        if (!SAMPLE_ONLY && pr.stage == 0)
-            dict_sweep<ALIGNED, true, STREAM>(src, P, 0, nch, tid, NT, T, ylimf, stride_log2, Ld, samp, acc, n_tissue);
-        else if (SAMPLE_ONLY || pr.stage == 1)
-            dict_sweep_sample(samp, n_sample, stride_log2, P, tid, NT, T, ylimf, Ld, acc, n_tissue);
-        else
-            dict_sweep<ALIGNED, false, STREAM>(src, P, 0, nch, tid, NT, T, ylimf, stride_log2, Ld, samp, acc, n_tissue);
-        double v[31];
-        acc[0].to_array(v); acc[1].to_array(v + 10); acc[2].to_array(v + 20);
-        v[30] = lane == 0 ? (double)n_tissue : 0.0;      // n_tissue is wave-uniform
-#pragma unroll
-        for (int i = 0; i < 31; ++i) v[i] = wave_sum(v[i]);
+        DictK Ld;
+        dict_consts(it.D, lam, Ld);
         __syncthreads();                                             // previous iteration's readers of red are done
-        if (lane == 0)
-            for (int i = 0; i < 31; ++i) red[wave][i] = v[i];
+        DictWaveAcc acc;
+        acc.begin(red[wave], lane);
+        if (!SAMPLE_ONLY && pr.stage == 0)
+            dict_sweep_b<ALIGNED, true, kDictTrip, STREAM>(src, P, 0, nch, tid, NT, T, ylimf, stride_log2, Ld, samp, acc);
+        else if (SAMPLE_ONLY || pr.stage == 1)
+            dict_sweep_sample_b(samp, n_sample, stride_log2, P, tid, T, ylimf, Ld, acc);
+        else
+            dict_sweep_b<ALIGNED, false, kDictTrip, STREAM>(src, P, 0, nch, tid, NT, T, ylimf, stride_log2, Ld, samp, acc);
         __syncthreads();
         if (tid < 31) {
             double t = 0;
@@ -1531,8 +1571,8 @@ __device__ __forceinline__ void dict_learn(const uint8_t* src, int P, int nch, i
 // chunk range of part `part` of a tile: spans are multiples of one sweep trip of a workgroup (kSweepThreads x kPhaseTrip =
 // 2048 chunks), so that every wave row is 64-aligned AND every lane's trips cover the same pixels as in the fused kernel
 // (the binary32 burst sums of moments_sweep_b are then identical in both schedules); trailing parts may be empty
-__device__ __forceinline__ void part_range(int nch, int parts, int part, int& c0, int& c1) {
-    constexpr int kAlign = kSweepThreads * kPhaseTrip;
+__device__ __forceinline__ void part_range(int nch, int parts, int part, int& c0, int& c1, int align_trips = 1) {
+    const int kAlign = kSweepThreads * kPhaseTrip * align_trips;     // (the dictionary sweeps sum over kDictBurstTrips trips)
     const int span = (((nch + parts - 1) / parts) + kAlign - 1) / kAlign * kAlign;
     c0 = min(nch, part * span);
     c1 = min(nch, c0 + span);
@@ -1831,38 +1871,31 @@ template <bool ALIGNED, bool FIRST>
 static __global__ __launch_bounds__(kSweepThreads, 4) void k_dict(StatsArgs a) {
     __shared__ RowTab s_tab;
     __shared__ double s_red[kSweepThreads / 64][32];
-    s_tab.fill();
+    s_tab.fill_b();
     __syncthreads();
-    const TabReader T = TabReader::make(s_tab);
+    const TabReaderB T = TabReaderB::make(s_tab);
     const int tid = threadIdx.x, lane = tid & 63;
     for (int item = blockIdx.x; item < a.n_items; item += gridDim.x) {
         const int tile = item / a.parts, part = item % a.parts;
         const DictState& ds = a.dstate[tile];
         if (!FIRST && ds.done) continue;                                    // block-uniform
-        LassoK64 Ld;
+        DictK Ld;
         if (FIRST) {
             DictIter it0;
             dict_iter_init(it0);
-            lasso_consts64(it0.D, a.dl_lambda, Ld);
+            dict_consts(it0.D, a.dl_lambda, Ld);
         } else {
-            lasso_consts64(ds.it.D, a.dl_lambda, Ld);
+            dict_consts(ds.it.D, a.dl_lambda, Ld);
         }
-        uni(Ld);
         const uint8_t* src = a.rgb + (size_t)tile * a.P * 3;
         uint32_t* samp = a.sample + (size_t)tile * a.n_sample;
         int c0, c1;
-        part_range((a.P + 3) >> 2, a.parts, part, c0, c1);
-        ClsAcc acc[3];
-        uint32_t n_tissue = 0;
-        if ((size_t)a.P * 3 >= kStreamBytes) dict_sweep<ALIGNED, FIRST, true>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, a.stride_log2, Ld, samp, acc, n_tissue);
-        else dict_sweep<ALIGNED, FIRST, false>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, a.stride_log2, Ld, samp, acc, n_tissue);
-        double v[31];
-        acc[0].to_array(v); acc[1].to_array(v + 10); acc[2].to_array(v + 20);
-        v[30] = lane == 0 ? (double)n_tissue : 0.0;
-#pragma unroll
-        for (int i = 0; i < 31; ++i) v[i] = wave_sum(v[i]);
-        if (lane == 0)
-            for (int i = 0; i < 31; ++i) s_red[tid >> 6][i] = v[i];
+        part_range((a.P + 3) >> 2, a.parts, part, c0, c1, kDictAlignTrips);
+        DictWaveAcc acc;
+        acc.begin(s_red[tid >> 6], lane);
+        if (c0 >= c1) {                          // an empty trailing part (block-uniform): zeros
+        } else if ((size_t)a.P * 3 >= kStreamBytes) dict_sweep_b<ALIGNED, FIRST, kDictTrip, true>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, a.stride_log2, Ld, samp, acc);
+        else dict_sweep_b<ALIGNED, FIRST, kDictTrip, false>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, a.stride_log2, Ld, samp, acc);
         __syncthreads();
         if (tid < 31) {
             double t = 0;
@@ -1882,15 +1915,18 @@ __device__ __forceinline__ void dict_finalize(const DictIter& it, TileState& st)
     if (st.status != SL_TILE_OK) for (int i = 0; i < 6; ++i) st.M[i] = nan_d();
 }
 
-static __global__ __launch_bounds__(kFinishThreads) void k_dict_finish(StatsArgs a, int first) {
+// (512 threads like the sweep kernels: the sample stage and the straggler sweeps then form the same binary32 bursts as the
+// fused kernel)
+constexpr int kDictFinishThreads = kSweepThreads;
+static __global__ __launch_bounds__(kDictFinishThreads) void k_dict_finish(StatsArgs a, int first) {
     __shared__ RowTab s_tab;
-    __shared__ DictScratch<kFinishThreads> s_d;
+    __shared__ DictScratch<kDictFinishThreads> s_d;
     const int tile = blockIdx.x, tid = threadIdx.x;
     DictState& ds = a.dstate[tile];
     if (!first && ds.done) return;
     DictProgress pr{0, 0, 0, 0};
     if (first) {
-        s_tab.fill();
+        s_tab.fill_b();
         if (tid == 0) dict_iter_init(s_d.it);
     } else {
         pr = ds.pr;
@@ -1906,8 +1942,8 @@ static __global__ __launch_bounds__(kFinishThreads) void k_dict_finish(StatsArgs
     __syncthreads();
     bool go = dict_advance(s_d.it, pr, a.dl_tol, tid) && pr.sweeps_used < a.dl_max_sweeps;
     if (go && pr.stage == 1) {                        // block-uniform; only after the first sweep
-        const TabReader T = TabReader::make(s_tab);
-        dict_learn<true, kFinishThreads, true>(nullptr, a.P, 0, tid, T, a.ylimf, a.stride_log2, a.sample + (size_t)tile * a.n_sample,
+        const TabReaderB T = TabReaderB::make(s_tab);
+        dict_learn<true, kDictFinishThreads, true>(nullptr, a.P, 0, tid, T, a.ylimf, a.stride_log2, a.sample + (size_t)tile * a.n_sample,
                                                a.n_sample, a.dl_lambda, a.dl_tol, a.dl_max_sweeps, s_d.it, s_d.red, s_d.sum, pr);
         go = s_d.it.status == SL_TILE_OK && pr.stage == 2;
     }
@@ -1920,23 +1956,23 @@ static __global__ __launch_bounds__(kFinishThreads) void k_dict_finish(StatsArgs
 }
 
 template <bool ALIGNED>
-static __global__ __launch_bounds__(kFinishThreads) void k_dict_tail(StatsArgs a) {
+static __global__ __launch_bounds__(kDictFinishThreads) void k_dict_tail(StatsArgs a) {
     __shared__ RowTab s_tab;
     __shared__ SelScratch S;
-    __shared__ DictScratch<kFinishThreads> s_d;
+    __shared__ DictScratch<kDictFinishThreads> s_d;
     __shared__ LassoK s_L;
     __shared__ int s_status;
     const int tile = blockIdx.x, tid = threadIdx.x;
     DictState& ds = a.dstate[tile];
     TileState& st = a.state[tile];
-    s_tab.fill();
+    s_tab.fill_b();
     __syncthreads();
     if (!ds.done) {                                   // block-uniform: this tile needs more sweeps than the launches gave it
         DictProgress pr = ds.pr;
         if (tid == 0) s_d.it = ds.it;
         __syncthreads();
-        const TabReader T = TabReader::make(s_tab);
-        dict_learn<ALIGNED, kFinishThreads>(a.rgb + (size_t)tile * a.P * 3, a.P, (a.P + 3) >> 2, tid, T, a.ylimf, a.stride_log2,
+        const TabReaderB T = TabReaderB::make(s_tab);
+        dict_learn<ALIGNED, kDictFinishThreads>(a.rgb + (size_t)tile * a.P * 3, a.P, (a.P + 3) >> 2, tid, T, a.ylimf, a.stride_log2,
                                             a.sample + (size_t)tile * a.n_sample, a.n_sample, a.dl_lambda, a.dl_tol,
                                             a.dl_max_sweeps, s_d.it, s_d.red, s_d.sum, pr);
         if (tid == 0) {
@@ -1957,13 +1993,13 @@ static __global__ __launch_bounds__(kFinishThreads) void k_dict_tail(StatsArgs a
     if (s_status != SL_TILE_OK) return;               // block-uniform
     SampleConcKey ckey;
     ckey.sample = a.sample + (size_t)tile * a.n_sample;
-    ckey.tab = view_of(s_tab);
+    ckey.tab = view_of_b(s_tab);
     ckey.L = s_L;
     ckey.cps_log2 = a.stride_log2 - 2;
     ckey.P = a.P;
     ckey.col = 0;
     float lo[2], hi[2];
-    conc_brackets<kFinishThreads>(ckey, a.n_sample, lo, hi, S);
+    conc_brackets<kDictFinishThreads>(ckey, a.n_sample, lo, hi, S);
     if (tid == 0) { st.lo[0] = lo[0]; st.hi[0] = hi[0]; st.lo[1] = lo[1]; st.hi[1] = hi[1]; }
 }
 
@@ -2028,8 +2064,7 @@ template <int METHOD, bool TRANSFORM, bool ALIGNED, int NT>
 static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
     __shared__ FusedShared<NT> sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const TabReader T = TabReader::make(sh.tab);          // layout A: moment / dictionary sweeps
-    const TabReaderB TB = TabReaderB::make(sh.tab);       // layout B: everything after them
+    const TabReaderB TB = TabReaderB::make(sh.tab);       // the 8-byte {gamma, od32} rows serve every sweep
     const int nch = (a.P + 3) >> 2;
     uint32_t* samp = a.sample + (size_t)blockIdx.x * a.n_sample;
     uint32_t* rawl = a.raw + (size_t)blockIdx.x * a.cap_raw;
@@ -2069,10 +2104,7 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
 #define SL_SUB(j)
 #endif
         SL_PHASE(0);
-        // Vahadane: layout A for the dictionary sweeps (binary64 optical densities), rewritten per tile (all waves left the
-        // last tile's apply); Macenko works on layout B throughout: written once, before the first tile
-        if (METHOD == kMethodVahadane) sh.tab.fill();
-        else if (tile == (int)blockIdx.x) sh.tab.fill_b();
+        if (tile == (int)blockIdx.x) sh.tab.fill_b();       // the row table: written once, before the workgroup's first tile
         __syncthreads();
 
         if (METHOD == kMethodMacenko) {
@@ -2170,9 +2202,9 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
             }
             __syncthreads();
             DictProgress pr{0, 0, 0, 0};
-            if (stream) dict_learn<ALIGNED, NT, false, true>(src, a.P, nch, tid, T, a.ylimf, a.stride_log2, samp, a.n_sample, a.dl_lambda,
+            if (stream) dict_learn<ALIGNED, NT, false, true>(src, a.P, nch, tid, TB, a.ylimf, a.stride_log2, samp, a.n_sample, a.dl_lambda,
                                                              a.dl_tol, a.dl_max_sweeps, sh.it, sh.red, sh.sum, pr);
-            else dict_learn<ALIGNED, NT, false, false>(src, a.P, nch, tid, T, a.ylimf, a.stride_log2, samp, a.n_sample, a.dl_lambda,
+            else dict_learn<ALIGNED, NT, false, false>(src, a.P, nch, tid, TB, a.ylimf, a.stride_log2, samp, a.n_sample, a.dl_lambda,
                                                        a.dl_tol, a.dl_max_sweeps, sh.it, sh.red, sh.sum, pr);
             sweeps_used = pr.sweeps_used;
             if (tid == 0) {
@@ -2182,7 +2214,6 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
                     if (stain_matrix_singular(sh.M)) sh.status = SL_TILE_DEGENERATE_COV;
                 }
             }
-            sh.tab.fill_b();                 // the dictionary sweeps are over: layout B from here on
         }
         __syncthreads();
         const bool bad = sh.status != SL_TILE_OK;                               // block-uniform
