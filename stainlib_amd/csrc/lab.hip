@@ -88,9 +88,10 @@ __device__ __forceinline__ uint32_t clip_trunc_u8(double x) { return (uint32_t)f
 // Per-tile scratch (workspace): histograms as uint64 (3 * 2^30 bytes per tile overflow 32 bits)
 struct LabScratch {
     unsigned long long bytes[256];      // all byte values of the tile
-    unsigned long long lab[3][256];     // L8, a8, b8 of the (optionally brightness-standardised) tile
+    unsigned long long lab_l[256];      // L8 of the (optionally brightness-standardised) tile
+    unsigned long long ab[4];           // sum a8, sum a8^2, sum b8, sum b8^2 (a - 128 and b - 128 are affine in the byte: no histogram needed)
     unsigned long long tissue;          // pixels of the standardised tile passing the luminosity test
-    unsigned long long pad_[7];
+    unsigned long long pad_[3];
 };
 
 // np.percentile(values, pct) (linear interpolation) of the integer population described by a 256-bin histogram; one thread
@@ -162,14 +163,15 @@ template <bool ALIGNED>
 static __global__ __launch_bounds__(kLabWG) void k_lab_hist(const uint8_t* __restrict__ rgb, int P, int parts, int standardize,
                                                             int want_ab, double thr, LabScratch* __restrict__ sc) {
     __shared__ LabTabs s_t;
-    __shared__ uint32_t s_h[kLabWG / 64][3][256];
+    __shared__ uint32_t s_h[kLabWG / 64][256];
     __shared__ uint8_t s_lut[256];
     __shared__ double s_p;
-    __shared__ unsigned long long s_tissue;
+    __shared__ unsigned long long s_tissue, s_ab[4];
     const int tile = blockIdx.x / parts, part = blockIdx.x % parts, wave = threadIdx.x >> 6;
     s_t.fill();
-    for (int i = threadIdx.x; i < (kLabWG / 64) * 3 * 256; i += kLabWG) (&s_h[0][0][0])[i] = 0;
+    for (int i = threadIdx.x; i < (kLabWG / 64) * 256; i += kLabWG) (&s_h[0][0])[i] = 0;
     if (threadIdx.x == 0) s_tissue = 0;
+    if (threadIdx.x < 4) s_ab[threadIdx.x] = 0;
     fill_brightness_lut(s_lut, sc[tile], standardize, &s_p);
     const int lim = l8_limit(thr);
     const size_t nbytes = (size_t)P * 3;
@@ -177,7 +179,7 @@ static __global__ __launch_bounds__(kLabWG) void k_lab_hist(const uint8_t* __res
     const int nch = (P + 3) >> 2;
     const int span = (nch + parts - 1) / parts;
     const int c0 = part * span, c1 = min(nch, c0 + span);
-    uint32_t n_tissue = 0;
+    uint32_t n_tissue = 0, sa = 0, saa = 0, sb = 0, sbb = 0;     // a part holds <= 32 Ki pixels = 128 per thread: 128 * 255^2 < 2^32
     for (int c = c0 + (int)threadIdx.x; c < c1; c += kLabWG) {
         const Chunk in = load_chunk<ALIGNED>(src, nbytes, c);
 #pragma unroll
@@ -185,31 +187,44 @@ static __global__ __launch_bounds__(kLabWG) void k_lab_hist(const uint8_t* __res
             if (!ALIGNED && (size_t)c * 4 + px >= (size_t)P) break;
             int L, A, B;
             rgb_to_lab8(s_t, s_lut[chunk_byte(in, 3 * px)], s_lut[chunk_byte(in, 3 * px + 1)], s_lut[chunk_byte(in, 3 * px + 2)], L, A, B);
-            atomicAdd(&s_h[wave][0][L], 1u);
-            if (want_ab) { atomicAdd(&s_h[wave][1][A], 1u); atomicAdd(&s_h[wave][2][B], 1u); }
+            atomicAdd(&s_h[wave][L], 1u);
+            sa += (uint32_t)A; saa += (uint32_t)(A * A); sb += (uint32_t)B; sbb += (uint32_t)(B * B);
             n_tissue += L < lim ? 1u : 0u;
         }
     }
-    unsigned long long nt = wave_sum((unsigned long long)n_tissue);
-    if ((threadIdx.x & 63) == 0 && nt) atomicAdd(&s_tissue, nt);
+    unsigned long long red[5] = {n_tissue, sa, saa, sb, sbb};
+#pragma unroll
+    for (int i = 0; i < 5; ++i) red[i] = wave_sum(red[i]);
+    if ((threadIdx.x & 63) == 0) {
+        if (red[0]) atomicAdd(&s_tissue, red[0]);
+        if (want_ab) for (int i = 0; i < 4; ++i) atomicAdd(&s_ab[i], red[1 + i]);
+    }
     __syncthreads();
     const int v = threadIdx.x;
-    for (int ch = 0; ch < (want_ab ? 3 : 1); ++ch) {
-        unsigned long long t = 0;
-        for (int w = 0; w < kLabWG / 64; ++w) t += s_h[w][ch][v];
-        if (t) atomicAdd(&sc[tile].lab[ch][v], t);
-    }
+    unsigned long long t = 0;
+    for (int w = 0; w < kLabWG / 64; ++w) t += s_h[w][v];
+    if (t) atomicAdd(&sc[tile].lab_l[v], t);
+    if (want_ab && threadIdx.x < 4) atomicAdd(&sc[tile].ab[threadIdx.x], s_ab[threadIdx.x]);
     if (threadIdx.x == 0 && s_tissue) atomicAdd(&sc[tile].tissue, s_tissue);
 }
 
-// cv2.meanStdDev of a lab_split plane from the histogram of its byte: value(v) = binary32 as lab_split makes it
-// (stain_utils.py:153-157), sums in binary64, population variance clamped at 0.  One thread.
-__device__ inline void mean_std_of_hist(const unsigned long long* hist, int channel, double& mean, double& sd) {
+// cv2.meanStdDev of a lab_split plane (stain_utils.py:153-157): sums in binary64, population variance clamped at 0.  One thread.
+// L: value(v) = binary32 v / 2.55f as lab_split makes it, from the histogram of L8.  a, b: value = byte - 128, so the two
+// sums follow exactly from the integer sums of the byte and its square (every term is an integer below 2^53).
+__device__ inline void mean_std_of_scratch(const LabScratch& sc, int channel, double& mean, double& sd) {
     double n = 0, s1 = 0, s2 = 0;
     for (int v = 0; v < 256; ++v) {
-        const double x = channel == 0 ? (double)((float)v / 2.55f) : (double)((float)v - 128.0f);
-        const double c = (double)hist[v];
-        n += c; s1 += c * x; s2 += c * x * x;
+        const double c = (double)sc.lab_l[v];
+        n += c;
+        if (channel == 0) {
+            const double x = (double)((float)v / 2.55f);
+            s1 += c * x; s2 += c * x * x;
+        }
+    }
+    if (channel != 0) {
+        const double sv = (double)sc.ab[2 * (channel - 1)], svv = (double)sc.ab[2 * (channel - 1) + 1];
+        s1 = sv - 128.0 * n;
+        s2 = svv - 256.0 * sv + 16384.0 * n;
     }
     mean = s1 / n;
     const double var = s2 / n - mean * mean;
@@ -222,7 +237,7 @@ static __global__ __launch_bounds__(64) void k_lab_stats(const LabScratch* __res
     double* o = stats_out + 8 * (size_t)tile;
     if (t < 3) {
         double m, s;
-        mean_std_of_hist(sc[tile].lab[t], t, m, s);
+        mean_std_of_scratch(sc[tile], t, m, s);
         o[1 + t] = m; o[4 + t] = s;
     } else if (t == 3) {
         o[0] = standardize ? percentile_of_hist(sc[tile].bytes, 90.0) : nan("");
@@ -257,7 +272,7 @@ static __global__ __launch_bounds__(kLabWG) void k_lab_map(LabMapArgs a) {
     if (MODE == 0) {
         if (tid < 3) {
             double m, s;
-            mean_std_of_hist(sc.lab[tid], tid, m, s);
+            mean_std_of_scratch(sc, tid, m, s);
             s_ms[tid] = m; s_ms[3 + tid] = s;
         }
         __syncthreads();
@@ -270,7 +285,7 @@ static __global__ __launch_bounds__(kLabWG) void k_lab_map(LabMapArgs a) {
             s_ch[ch][tid] = (uint8_t)clip_trunc_u8(ch == 0 ? nrm * 2.55 : nrm + 128.0);
         }
     } else if (MODE == 1) {
-        if (tid == 0) s_p = percentile_of_hist(sc.lab[0], a.percentile);
+        if (tid == 0) s_p = percentile_of_hist(sc.lab_l, a.percentile);
         __syncthreads();
         s_ch[0][tid] = (uint8_t)clip_trunc_u8(255.0 * (double)tid / s_p);          // stain_utils.py:65: 255 * L_float / p
         if (part == 0 && tid == 0 && a.p_out) a.p_out[tile] = s_p;

@@ -1,24 +1,29 @@
 #!/bin/bash
 # Collects every measurement the docs cite into gpurun_out/ (run on the GPU box from the repo root):
-#   make -C tools && /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r02'
+#   make -C tools && /usr/local/graft/bin/gpurun --timeout 1800 -- 'bash tools/collect_profiles.sh r02'
+# then copy gpurun_out/r02_* to profiles/ (tracked).
 tag=${1:-r02}
 cd "$GRAFT_REPO_ROOT" || exit 1
 out=$PWD/gpurun_out
 mkdir -p "$out"
 export TMPDIR=/tmp
+dev=$PWD/stainlib_amd/csrc/libstainlib_hip_dev.so
 python bench.py --steps 20 --warmup 3 2>/dev/null | tail -1 > "$out/${tag}_bench_n1.json"
-python tools/bench_configs.py 2>/dev/null | tail -1 > "$out/${tag}_secondary_configs.json"
-python tools/crossover.py 2>/dev/null | grep "^size" > "$out/${tag}_crossover.txt"
-STAINLIB_HIP_LIB=$PWD/stainlib_amd/csrc/libstainlib_hip_dev.so python tools/phase_times.py 512 1024 2>/dev/null | grep -A12 "per-tile" > "$out/${tag}_phase_times.txt"
-rm -rf /tmp/kt; timeout 600 rocprofv3 --kernel-trace -d /tmp/kt -o p -- python bench.py --steps 20 --warmup 3 > /dev/null 2>&1
+python tools/crossover.py 2>/dev/null | grep "size" > "$out/${tag}_crossover.txt"
+python tools/phase_classes.py 1024 2>/dev/null | grep "^size" > "$out/${tag}_phase_classes.txt"
+[ -f "$dev" ] && STAINLIB_HIP_LIB=$dev python tools/phase_times.py 512 1024 2>/dev/null | grep -A12 "per-tile" > "$out/${tag}_phase_times.txt"
+python tools/bench_pipeline.py 2>/dev/null | tail -3 > "$out/${tag}_pipeline.txt"
+# rocprofv3 kernel trace of the same bench command (no CPU baseline / secondary: the trace is about the headline kernels)
+rm -rf /tmp/kt; timeout 600 rocprofv3 --kernel-trace -d /tmp/kt -o p -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary > /dev/null 2>&1
 python tools/rocpd_stats.py "$(ls /tmp/kt/*/*.db /tmp/kt/*.db 2>/dev/null | head -1)" > "$out/${tag}_kernel_stats.md" 2>&1
-# Vahadane, 128 tiles (BASELINE configs[2]): per-kernel times of the one-launch-per-phase schedule
-cat > /tmp/vah128.py <<'PY'
+# Vahadane, 128 tiles (BASELINE configs[2]) and 512 tiles: per-kernel times
+cat > /tmp/vah.py <<'PY'
 import sys, torch
 sys.path.insert(0, ".")
 from stainlib_amd import engine
 from tools.synth import synth_tiles
-rgb = synth_tiles(128, 1024, 1024, seed=5)
+n = int(sys.argv[1])
+rgb = synth_tiles(n, 1024, 1024, seed=5)
 tgt = synth_tiles(1, 1024, 1024, seed=1001)
 out = torch.empty_like(rgb)
 p = engine.make_params(dl_tol=1e-6, dl_max_sweeps=100)
@@ -27,14 +32,22 @@ for _ in range(10):
     engine.vahadane_transform(rgb, Mt[0], mct[0], params=p, out=out)
 torch.cuda.synchronize()
 PY
-rm -rf /tmp/ktv; timeout 600 rocprofv3 --kernel-trace -d /tmp/ktv -o p -- python /tmp/vah128.py > /dev/null 2>&1
-python tools/rocpd_stats.py "$(ls /tmp/ktv/*/*.db /tmp/ktv/*.db 2>/dev/null | head -1)" 2>&1 | grep -v "at::native\|rocclr\|Cijk" > "$out/${tag}_kernel_stats_vahadane128.md"
+for n in 128 512; do
+  rm -rf /tmp/ktv; timeout 600 rocprofv3 --kernel-trace -d /tmp/ktv -o p -- python /tmp/vah.py $n > /dev/null 2>&1
+  python tools/rocpd_stats.py "$(ls /tmp/ktv/*/*.db /tmp/ktv/*.db 2>/dev/null | head -1)" 2>&1 | grep -v "at::native\|rocclr\|Cijk" > "$out/${tag}_kernel_stats_vahadane$n.md"
+done
+# PMC passes (each in its own run, --pmc only): HBM traffic, SQ activity, instruction mix
 for pass in "f:FETCH_SIZE" "w:WRITE_SIZE" "s1:SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA" "s2:SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"; do
   t=${pass%%:*}; c=${pass#*:}
   rm -rf /tmp/pmc_$t; timeout 400 rocprofv3 --pmc $c -d /tmp/pmc_$t -o p -- python tools/run_fused_once.py 512 > /dev/null 2>&1
   python tools/pmc_summary.py "$(ls /tmp/pmc_$t/*/*.db /tmp/pmc_$t/*.db 2>/dev/null | head -1)" > "$out/${tag}_pmc_$t.txt" 2>&1
 done
+# the same two traffic counters on the one-launch-per-phase schedule at 64 tiles (192 MB: fits the Infinity Cache) and 512
+for n in 64 512; do
+  rm -rf /tmp/pm_$n; timeout 300 rocprofv3 --pmc FETCH_SIZE -d /tmp/pm_$n -o p -- python tools/run_multi.py $n 1 > /dev/null 2>&1
+  python tools/pmc_summary.py "$(ls /tmp/pm_$n/*/*.db /tmp/pm_$n/*.db 2>/dev/null | head -1)" > "$out/${tag}_pmc_phase_fetch_n$n.txt" 2>&1
+done
 [ -x tools/bin/ubench_ops ] && timeout 120 tools/bin/ubench_ops > "$out/${tag}_ubench_ops.txt" 2>&1
 [ -x tools/bin/ubench_issue ] && timeout 120 tools/bin/ubench_issue > "$out/${tag}_ubench_issue.txt" 2>&1
 [ -x tools/bin/kbench_stream ] && timeout 120 tools/bin/kbench_stream > "$out/${tag}_kbench_stream.txt" 2>&1
-ls -la "$out" | tail -20
+ls -la "$out" | tail -30
