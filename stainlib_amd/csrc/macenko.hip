@@ -385,7 +385,7 @@ extern "C" int sl_vahadane_transform(const uint8_t* rgb, uint8_t* out, int n, in
 // Development aids, compiled ONLY into libstainlib_hip_dev.so (make dev): not part of the public header, backed by
 // process-global state, never in the product library (tests/test_host_api.py checks the export list).
 // where the per-tile state lives in the workspace
-extern "C" int sl_debug_layout(int n, int h, int w, size_t* off_state, size_t* sizeof_state, int* group,
+extern "C" SL_API int sl_debug_layout(int n, int h, int w, size_t* off_state, size_t* sizeof_state, int* group,
                                size_t* off_diag, int* fused) {
     const Layout L = make_layout(n, (long)h * w);
     if (off_state) *off_state = L.off_state;
@@ -396,19 +396,19 @@ extern "C" int sl_debug_layout(int n, int h, int w, size_t* off_state, size_t* s
     return SL_OK;
 }
 
-extern "C" void sl_debug_set_phase_clock(long long* device_buf) { g_phase_clock = device_buf; }
-extern "C" void sl_debug_set_stop(int phase) { g_debug_stop = phase; }
-extern "C" void sl_debug_set_dyn_lds(unsigned bytes) { g_debug_dyn_lds = bytes; }
+extern "C" SL_API void sl_debug_set_phase_clock(long long* device_buf) { g_phase_clock = device_buf; }
+extern "C" SL_API void sl_debug_set_stop(int phase) { g_debug_stop = phase; }
+extern "C" SL_API void sl_debug_set_dyn_lds(unsigned bytes) { g_debug_dyn_lds = bytes; }
 
 #ifdef SL_DEBUG_INNER
-extern "C" void sl_debug_inner(unsigned long long* out, int reset) {
+extern "C" SL_API void sl_debug_inner(unsigned long long* out, int reset) {
     hipMemcpyFromSymbol(out, HIP_SYMBOL(sl::g_dbg_inner), 32);
     if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; hipMemcpyToSymbol(HIP_SYMBOL(sl::g_dbg_inner), z, 32); }
 }
 #endif
 
 #ifdef SL_DEBUG_SUBCLK
-extern "C" void sl_debug_bclk(unsigned long long* out, int reset) {
+extern "C" SL_API void sl_debug_bclk(unsigned long long* out, int reset) {
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(sl::g_bclk), 128);
     if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(sl::g_bclk), z, 128); }
 }
