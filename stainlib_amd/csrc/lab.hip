@@ -179,7 +179,8 @@ static __global__ __launch_bounds__(kLabWG) void k_lab_hist(const uint8_t* __res
     const int nch = (P + 3) >> 2;
     const int span = (nch + parts - 1) / parts;
     const int c0 = part * span, c1 = min(nch, c0 + span);
-    uint32_t n_tissue = 0, sa = 0, saa = 0, sb = 0, sbb = 0;     // a part holds <= 32 Ki pixels = 128 per thread: 128 * 255^2 < 2^32
+    uint32_t n_tissue = 0, sa = 0, sb = 0;                       // a thread sees <= 2^30 / 256 pixels: the plain sums fit 32 bits
+    unsigned long long saa = 0, sbb = 0;
     for (int c = c0 + (int)threadIdx.x; c < c1; c += kLabWG) {
         const Chunk in = load_chunk<ALIGNED>(src, nbytes, c);
 #pragma unroll
@@ -403,6 +404,15 @@ using namespace sl;
 
 namespace {
 
+// Workgroups per tile of the Lab sweeps: every workgroup merges a 256-bin histogram into the tile's with global atomics and
+// rebuilds the per-tile tables (a few hundred serial binary64 operations) before it touches a pixel, so a tile is split only
+// as far as it takes to put ~8 workgroups on every CU (1 250 tiles of 512^2: one workgroup per tile, 2.4 -> 1.1 ms).
+int lab_parts(int n, long P) {
+    const long want = (2048 + n - 1) / n;
+    const int full = parts_for(P);
+    return (int)(want < 1 ? 1 : (want < full ? want : full));
+}
+
 size_t lab_ws_bytes(int n) { return (sizeof(LabScratch) * (size_t)n + 255) & ~(size_t)255; }
 
 int lab_check(const void* rgb, const void* out, int n, int h, int w, const void* ws, size_t ws_bytes) {
@@ -415,7 +425,7 @@ int lab_check(const void* rgb, const void* out, int n, int h, int w, const void*
 // the two statistics sweeps shared by the entry points below
 int lab_statistics(const uint8_t* rgb, int n, long P, int standardize, int want_ab, double thr, LabScratch* sc, hipStream_t s) {
     SL_HIP_TRY(hipMemsetAsync(sc, 0, sizeof(LabScratch) * (size_t)n, s));
-    const int parts = parts_for(P);
+    const int parts = lab_parts(n, P);
     const dim3 grid((unsigned)((long)n * parts)), block(kLabWG);
     const bool al = aligned4(rgb, P);
     if (standardize) {
@@ -498,7 +508,7 @@ extern "C" int sl_standardize_brightness(const uint8_t* rgb, uint8_t* out, int n
     rc = lab_statistics(rgb, n, P, 1, -1, 0.0, sc, s);
     if (rc) return rc;
     LabMapArgs a{};
-    a.rgb = rgb; a.out = out; a.P = (int)P; a.parts = parts_for(P); a.sc = sc; a.p_out = p_out;
+    a.rgb = rgb; a.out = out; a.P = (int)P; a.parts = lab_parts(n, P); a.sc = sc; a.p_out = p_out;
     return lab_map<2>(a, n, s);
 }
 
@@ -527,7 +537,7 @@ extern "C" int sl_reinhard_transform(const uint8_t* rgb, uint8_t* out, int n, in
     if (rc) return rc;
     if (stats_out) hipLaunchKernelGGL(k_lab_stats, dim3((unsigned)n), dim3(64), 0, s, sc, 1, stats_out);
     LabMapArgs a{};
-    a.rgb = rgb; a.out = out; a.P = (int)P; a.parts = parts_for(P); a.sc = sc;
+    a.rgb = rgb; a.out = out; a.P = (int)P; a.parts = lab_parts(n, P); a.sc = sc;
     a.target_means = target_means; a.target_stds = target_stds;
     a.mask_background = mask_background ? 1 : 0; a.thr = luminosity_threshold;
     return lab_map<0>(a, n, s);
@@ -543,6 +553,6 @@ extern "C" int sl_luminosity_standardize(const uint8_t* rgb, uint8_t* out, int n
     rc = lab_statistics(rgb, n, P, 0, 0, 0.8, sc, s);
     if (rc) return rc;
     LabMapArgs a{};
-    a.rgb = rgb; a.out = out; a.P = (int)P; a.parts = parts_for(P); a.sc = sc; a.percentile = percentile; a.p_out = p_out;
+    a.rgb = rgb; a.out = out; a.P = (int)P; a.parts = lab_parts(n, P); a.sc = sc; a.percentile = percentile; a.p_out = p_out;
     return lab_map<1>(a, n, s);
 }

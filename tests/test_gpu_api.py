@@ -306,3 +306,36 @@ def test_grayscale_augmentor_matches_reference_golden():
     with pytest.raises(sl.TissueMaskException):
         sl.GrayscaleAugmentor().fit(np.full((16, 16, 3), 255, np.uint8))
 
+
+
+def test_configs3_tile_size_stain_augmentor_and_hed_batch():
+    """BASELINE configs[3] tile size (512 x 512), batched: StainAugmentor.pop and HedLighterColorAugmenter with per-tile
+    draws from the global numpy stream, every tile against the oracle."""
+    import stainlib_amd as sl
+    from stainlib_amd import engine
+    tiles = [so.synth_tile(512, 512, 700 + s) for s in range(4)]
+    dev = to_dev(tiles)
+    M, _, st = engine.macenko_fit(dev)
+    assert (st.cpu().numpy() == 0).all()
+    np.random.seed(11)
+    ab = np.array([[np.random.uniform(0.8, 1.2), np.random.uniform(-0.2, 0.2), np.random.uniform(0.8, 1.2), np.random.uniform(-0.2, 0.2)]
+                   for _ in tiles])
+    for bg in (False, True):
+        out = engine.stain_augment(dev, M, ab, augment_background=bg).cpu().numpy()
+        for i, I in enumerate(tiles):
+            a = so.StainAugmentor("macenko", augment_background=bg)
+            a.image_shape, a.stain_matrix = I.shape, M[i].cpu().numpy()           # the device's own stain matrix: isolates pop
+            a.source_concentrations, a.tissue_mask = so.get_concentrations(I, a.stain_matrix), so.tissue_mask(I).ravel()
+            u8_parity(out[i], a.pop_with([ab[i, 0], ab[i, 2]], [ab[i, 1], ab[i, 3]]), label=f"pop 512^2 bg={bg}")
+    aug = sl.HedLighterColorAugmenter()
+    sig, bia = aug.randomize_batch(len(tiles))
+    o, applied = aug.transform_batch(dev, sig, bia)
+    assert applied.cpu().numpy().all()
+    for i, I in enumerate(tiles):
+        u8_parity(o[i].cpu().numpy(), so.hed_transform(I, sig[i], bia[i]), label="hed 512^2")
+    r, orr = sl.ReinhardStainNormalizer(), so.ReinhardStainNormalizer()
+    r.fit(tiles[3])
+    orr.fit(tiles[3])
+    ro, _ = r.transform_batch(dev[:3], mask_background=True)
+    for i in range(3):
+        assert np.array_equal(ro[i].cpu().numpy(), orr.transform(tiles[i], mask_background=True))
