@@ -327,6 +327,32 @@ def secondary_configs(dev, Mt, mct):
         "ms_per_slide": round(ms, 4), "tiles_per_s": round(512 / ms * 1e3, 1), "selection_paths": list(sn.last_path),
         "parity_8_tile_slide": {"M_max_abs_err": float(np.abs(Mp - Mo).max()), "maxC_max_rel_err": float(np.abs(cp / co - 1).max())},
         "note": "host-driven: 4 full sweeps + 6 over a pixel sample with a host read-back between stages (wall clock, not event time)"}
+    del rgb, out
+
+    # ---- configs[4] at the size of ONE GPU's shard: 100 k tiles / 8 GPUs = 12 500 tiles (39 GB in, 39 GB out, resident in HBM);
+    # the fixed cost of the host-driven stages is amortised here.  Checked against the per-tile path: the pooled statistics of a
+    # slide of i.i.d. tiles must sit inside the spread of its tiles' own statistics.
+    free_b = torch.cuda.mem_get_info(dev)[0]
+    n_big = 12500 if free_b > 100e9 else 0
+    if n_big:
+        rgb = synth_tiles(n_big, 1024, 1024, seed=11, device=dev)
+        out = torch.empty_like(rgb)
+        sn.transform_shard(rgb[:1024], out=out[:1024])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _, M_s, mc_s, _ = sn.transform_shard(rgb, out=out)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3
+        Mf, mcf, stf = engine.macenko_fit(rgb[:64])
+        Mf, mcf = Mf.cpu().numpy(), mcf.cpu().numpy()
+        inside = bool((M_s.cpu().numpy() >= Mf.min(0) - 1e-3).all() and (M_s.cpu().numpy() <= Mf.max(0) + 1e-3).all())
+        sec["configs4_pooled_slide_shard_12500x1024"] = {
+            "ms_per_shard": round(ms, 3), "tiles_per_s": round(n_big / ms * 1e3, 1), "selection_paths": list(sn.last_path),
+            "bytes_resident": int(2 * rgb.numel()), "M_slide": [round(float(x), 6) for x in M_s.reshape(-1).tolist()],
+            "M_slide_within_per_tile_range_of_64_tiles": inside,
+            "note": "one rank's share of a 100 k-tile slide: moments sweep, two window sweeps (angle, concentrations), apply; "
+                    "in the 8-GPU run each stage adds one tiny all-reduce (bench.py --slide-pooled)"}
+        del rgb, out
     return sec
 
 

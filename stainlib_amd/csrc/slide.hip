@@ -18,6 +18,9 @@
 // per-pixel is stored: every round is one more sweep over the uint8 tiles.
 #include "stats_kernels.hpp"
 #include "sl_host.hpp"
+#include <cmath>
+#include <cstring>
+#include <type_traits>
 
 using namespace sl;
 
@@ -37,6 +40,7 @@ struct SlideArgs {
     int prefix_bits;
     uint32_t above[2];       // next_above: keys strictly greater than these
     uint32_t window_lo[2];   // window mode: histogram of key - window_lo over [window_lo, window_lo + 65536), count of keys below
+    float win_flo[2], win_fhi[2];   // the same bounds as binary32 values (-inf / +inf: no cheap zone test for that target)
     uint32_t sample_mask;    // 0: every pixel; 2^s - 1: one 64-chunk row in 2^s (stratified over rows and items)
 };
 
@@ -54,15 +58,11 @@ struct BinRun {
 
 // MODE 0: 256-bin histogram of the next 8 bits (LDS, merged into hist at the end); 1: smallest key above a.above;
 // 2: the LOW 16 bits of the keys whose top 16 bits match, counted straight into hist[2][65536] with global atomics
-// (a 16-bit prefix leaves ~0.2 % of the pixels: two rounds in one sweep); 3: a 65536-key WINDOW at an arbitrary
-// position (hist[2][65536] of key - window_lo) plus the number of keys below it (hist[2 * 65536 + t]): with the
-// window centred on an estimate from a pixel sample, one sweep pins an order statistic
+// (a 16-bit prefix leaves ~0.2 % of the pixels: two rounds in one sweep).  (The window sweep is k_slide_window below.)
 template <int KEYSET, int MODE, bool ALIGNED>
 __global__ __launch_bounds__(kSweepThreads, 4) void k_slide_keys(SlideArgs a, unsigned long long* hist, uint32_t* min_out) {
     constexpr bool NEXT_ABOVE = MODE == 1;
     constexpr bool LOW16 = MODE == 2;
-    constexpr bool WINDOW = MODE == 3;
-    unsigned long long nb0 = 0, nb1 = 0;             // window mode: keys below the window (per lane)
     __shared__ RowTab s_tab;
     __shared__ uint32_t s_hist[2][256];
     __shared__ uint32_t s_min[2];
@@ -108,12 +108,6 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_slide_keys(SlideArgs a, un
             } else if (LOW16) {
                 if ((o0 >> 16) == p0) atomicAdd(&hist[o0 & 0xffffu], 1ull);
                 if ((o1 >> 16) == p1) atomicAdd(&hist[65536u + (o1 & 0xffffu)], 1ull);
-            } else if (WINDOW) {
-                const uint32_t d0 = o0 - a.window_lo[0], d1 = o1 - a.window_lo[1];
-                nb0 += o0 < a.window_lo[0] ? 1u : 0u;
-                nb1 += o1 < a.window_lo[1] ? 1u : 0u;
-                if (o0 >= a.window_lo[0] && d0 < 65536u) atomicAdd(&hist[d0], 1ull);
-                if (o1 >= a.window_lo[1] && d1 < 65536u) atomicAdd(&hist[65536u + d1], 1ull);
             } else {
                 if (all || (o0 >> hs) == p0) r0.add(s_hist[0], (o0 >> sh) & 255u);
                 if (all || (o1 >> hs) == p1) r1.add(s_hist[1], (o1 >> sh) & 255u);
@@ -202,9 +196,6 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_slide_keys(SlideArgs a, un
         if ((tid & 63) == 0) { atomicMin(&s_min[0], best0); atomicMin(&s_min[1], best1); }
         __syncthreads();
         if (tid < 2 && s_min[tid] != 0xffffffffu) atomicMin(&min_out[tid], s_min[tid]);
-    } else if (WINDOW) {
-        nb0 = wave_sum(nb0); nb1 = wave_sum(nb1);
-        if ((tid & 63) == 0) { if (nb0) atomicAdd(&hist[2u * 65536u], nb0); if (nb1) atomicAdd(&hist[2u * 65536u + 1u], nb1); }
     } else if (!LOW16) {
         r0.flush(s_hist[0]); r1.flush(s_hist[1]);
         __syncthreads();
@@ -215,33 +206,205 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_slide_keys(SlideArgs a, un
     }
 }
 
-// per-tile moment sums in a fixed order (run-to-run identical): sweep -> partials -> one thread per (tile, moment)
+// ---- the WINDOW sweep: a 65536-key window per target at an arbitrary position (hist[2][65536] of key - window_lo) plus the
+// number of keys below it (hist[2 * 65536 + t]).  With the window centred on an estimate from a pixel sample, one sweep
+// pins an order statistic.  Like the per-tile selection sweeps it does NOT evaluate the ordered key of every pixel: cheap
+// tests in the binary32 domain prove on which side of both windows a pixel lies; proven pixels are counted on the scalar
+// unit (ballot popcounts), the few others (inside or next to a window: ~0.1 %) take the exact path under the exec mask.
+//   angle (one key p = y / (x + |y|), x > 0, for both windows, window 0 below window 1):
+//       p < lo0 - eps | hi0 + eps < p < lo1 - eps | p > hi1 + eps      tested as y <> bound * d, without the division
+//   concentrations (the keys ARE cheap: max(min(a, s), 0) when g12 >= 0): c < lo or c > hi, compared as binary32 --
+//       equivalent to the ordered-integer comparison except at +-0, which neither strict test claims
+struct WinAcc {
+    unsigned long long l_nb0 = 0, l_nb1 = 0;     // per lane: keys below window 0 / window 1
+};
+
+template <int KEYSET, bool ALIGNED, int kTrip, bool STREAM>
+__device__ __forceinline__ void window_sweep(const uint8_t* src, int P, int c0, int c1, int t, const TabReaderB& T, const SlideArgs& a,
+                                             const float* V, const LassoK& L, const float* thr, unsigned long long* hist, WinAcc& acc) {
+    constexpr int nthreads = kSweepThreads;
+    const size_t nbytes = (size_t)P * 3;
+    const int lane = t & 63;
+    const int w0 = __builtin_amdgcn_readfirstlane(c0 + (t & ~63));
+    const uint32_t wlo0 = a.window_lo[0], wlo1 = a.window_lo[1];
+    struct G { float2 v[12]; };
+    struct Gc { float v[12]; };
+    using GT = typename std::conditional<KEYSET == SL_KEYSET_ANGLE, G, Gc>::type;
+    const float ylimf = in_vgpr(a.ylimf);
+    uint32_t lc0 = 0, lc1 = 0;                  // per lane: pixels proven below window 0 / (angle: between the windows; conc: below window 1)
+    auto g_at = [](const GT& g, int i) { return g.v[i]; };
+    auto fetch = [&](int cc) { return load_chunk_clamped<ALIGNED, STREAM>(src, nbytes, cc, c1); };
+    auto gather = [&](const Chunk& ch) {
+        GT g;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            if constexpr (KEYSET == SL_KEYSET_ANGLE) g.v[i] = T.gam_odf(T.addr(ch, i));
+            else g.v[i] = T.odf(T.addr(ch, i));
+        }
+        return g;
+    };
+    auto exact = [&](uint32_t o0, uint32_t o1, bool counted0, bool counted1) {     // under the exec mask of the unproven lanes
+        acc.l_nb0 += ((o0 < wlo0) & !counted0) ? 1u : 0u;
+        acc.l_nb1 += ((o1 < wlo1) & !counted1) ? 1u : 0u;
+        const uint32_t d0 = o0 - wlo0, d1 = o1 - wlo1;
+        if (o0 >= wlo0 && d0 < 65536u) atomicAdd(&hist[d0], 1ull);
+        if (o1 >= wlo1 && d1 < 65536u) atomicAdd(&hist[65536u + d1], 1ull);
+    };
+    // Scalar instructions are as scarce as vector ones here (one issue slot per SIMD visit), so the proven pixels are
+    // counted per LANE (one add-with-carry off the compare's mask each) and the unproven ones are looked for once per
+    // CHUNK: the exact path of a chunk's four pixels sits behind one branch.
+    auto compute = [&](auto tail_tag, const GT& g, int cc) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+        bool flag[4], cnt0[4], cnt1[4];
+        auto inb = [&](int px) { return (cc < c1) & (ALIGNED | ((size_t)cc * 4 + px < (size_t)P)); };
+        auto xy = [&](float odr, float odg, float odb, float& x, float& y) {                 // the operations of angle_key
+            x = fmaf(V[4], odb, fmaf(V[2], odg, V[0] * odr));
+            y = fmaf(V[5], odb, fmaf(V[3], odg, V[1] * odr));
+        };
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            if constexpr (KEYSET == SL_KEYSET_ANGLE) {
+                const float2 er = g_at(g, 3 * px), eg = g_at(g, 3 * px + 1), eb = g_at(g, 3 * px + 2);
+                // is_tissue_f as a number: tv > 0 <=> tissue (integers below 2^24: exact); it rides in the min chains
+                float tv = ylimf - fmaf(871.0f, er.x, fmaf(2929.0f, eg.x, 296.0f * eb.x));
+                if (TAIL) tv = inb(px) ? tv : -1.0f;
+                float x, y;
+                xy(er.y, eg.y, eb.y, x, y);
+                const float d = x + fabsf(y);
+                const float tl0 = fmaf(thr[0], d, y), th0 = fmaf(thr[1], d, y), tl1 = fmaf(thr[2], d, y), th1 = fmaf(thr[3], d, y);
+                const bool z0 = fminf(fminf(x, -tl0), tv) > 0.0f;                      // tissue, x > 0, p < lo0 - eps: below both windows
+                const bool z1 = fminf(fminf(fminf(x, th0), -tl1), tv) > 0.0f;          // between the windows
+                const bool z2 = fminf(fminf(x, th1), tv) > 0.0f;                       // above both
+                cnt0[px] = z0; cnt1[px] = z0 | z1;
+                lc0 += z0 ? 1u : 0u;
+                lc1 += z1 ? 1u : 0u;
+                flag[px] = (tv > 0.0f) & !(z0 | z1 | z2);
+            } else {
+                float c1f, c2f;
+                lasso2(L, g_at(g, 3 * px), g_at(g, 3 * px + 1), g_at(g, 3 * px + 2), c1f, c2f);
+                bool b0 = c1f < thr[0], b1 = c2f < thr[2];
+                bool fast = (b0 | (c1f > thr[1])) & (b1 | (c2f > thr[3]));
+                if (TAIL) { const bool in = inb(px); b0 = b0 & in; b1 = b1 & in; fast = fast | !in; }
+                cnt0[px] = b0; cnt1[px] = b1;
+                lc0 += b0 ? 1u : 0u;
+                lc1 += b1 ? 1u : 0u;
+                flag[px] = !fast;
+            }
+        }
+        if (flag[0] | flag[1] | flag[2] | flag[3]) {
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                if (!flag[px]) continue;
+                if constexpr (KEYSET == SL_KEYSET_ANGLE) {
+                    float x, y;
+                    xy(g_at(g, 3 * px).y, g_at(g, 3 * px + 1).y, g_at(g, 3 * px + 2).y, x, y);
+                    const uint32_t o = f2ord(pseudo_angle(x, y));
+                    exact(o, o, false, false);
+                } else {
+                    float c1f, c2f;
+                    lasso2(L, g_at(g, 3 * px), g_at(g, 3 * px + 1), g_at(g, 3 * px + 2), c1f, c2f);
+                    exact(f2ord(c1f), f2ord(c2f), cnt0[px], cnt1[px]);
+                }
+            }
+        }
+    };
+    Chunk cur[kTrip], nx[kTrip];
+#pragma unroll
+    for (int k = 0; k < kTrip; ++k) { cur[k] = fetch(w0 + lane + k * nthreads); nx[k] = fetch(w0 + lane + (kTrip + k) * nthreads); }
+    GT g[2];
+    g[0] = gather(cur[0]);
+    auto trip = [&](auto tail_tag, int cb) {
+#pragma unroll
+        for (int k = 0; k < kTrip; ++k) {
+            if (k + 1 < kTrip) {
+                g[(k + 1) & 1] = gather(cur[k + 1]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < kTrip; ++j) { cur[j] = nx[j]; nx[j] = fetch(cb + lane + (2 * kTrip + j) * nthreads); }
+                g[0] = gather(cur[0]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            compute(tail_tag, g[k & 1], cb + k * nthreads + lane);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    const int lim = ALIGNED ? c1 : min(c1, P >> 2);          // chunks made of in-range pixels only
+    int cb = w0;
+    for (; cb + (kTrip - 1) * nthreads + 64 <= lim; cb += nthreads * kTrip) trip(std::false_type{}, cb);
+    if (cb < c1) trip(std::true_type{}, cb);                    // at most one ragged trip per wave
+    // angle: window 1 lies above window 0, so "below window 1" = below window 0 or between the two
+    acc.l_nb0 += lc0;
+    acc.l_nb1 += KEYSET == SL_KEYSET_ANGLE ? lc0 + lc1 : lc1;
+}
+
+template <int KEYSET, bool ALIGNED>
+__global__ __launch_bounds__(kSweepThreads, 4) void k_slide_window(SlideArgs a, unsigned long long* hist) {
+    __shared__ RowTab s_tab;
+    s_tab.fill_b();
+    __syncthreads();
+    const TabReaderB T = TabReaderB::make(s_tab);
+    const int tid = threadIdx.x;
+    float V[6] = {0, 0, 0, 0, 0, 0}, thr[4];
+    LassoK L{};
+    if (KEYSET == SL_KEYSET_ANGLE) {
+        for (int i = 0; i < 6; ++i) V[i] = in_vgpr(a.V[i]);
+        // thr: -(lo0 - eps), -(hi0 + eps), -(lo1 - eps), -(hi1 + eps)   (t = y - bound * d)
+        thr[0] = in_vgpr(-(a.win_flo[0] - kAngleMargin)); thr[1] = in_vgpr(-(a.win_fhi[0] + kAngleMargin));
+        thr[2] = in_vgpr(-(a.win_flo[1] - kAngleMargin)); thr[3] = in_vgpr(-(a.win_fhi[1] + kAngleMargin));
+    } else {
+        lasso_consts(a.M, a.lam, L);
+        vgpr(L);
+        thr[0] = in_vgpr(a.win_flo[0]); thr[1] = in_vgpr(a.win_fhi[0]); thr[2] = in_vgpr(a.win_flo[1]); thr[3] = in_vgpr(a.win_fhi[1]);
+    }
+    WinAcc acc;
+    const bool stream = (size_t)a.P * 3 >= kStreamBytes;      // uniform
+    for (int item = blockIdx.x; item < a.n_items; item += gridDim.x) {
+        const int tile = item / a.parts, part = item % a.parts;
+        const uint8_t* src = a.rgb + (size_t)tile * a.P * 3;
+        int c0, c1;
+        part_range((a.P + 3) >> 2, a.parts, part, c0, c1);
+        if (c0 >= c1) continue;
+        if (stream) window_sweep<KEYSET, ALIGNED, kPhaseTrip, true>(src, a.P, c0, c1, tid, T, a, V, L, thr, hist, acc);
+        else window_sweep<KEYSET, ALIGNED, kPhaseTrip, false>(src, a.P, c0, c1, tid, T, a, V, L, thr, hist, acc);
+    }
+    const unsigned long long nb0 = wave_sum(acc.l_nb0), nb1 = wave_sum(acc.l_nb1);
+    if ((tid & 63) == 0) { if (nb0) atomicAdd(&hist[2u * 65536u], nb0); if (nb1) atomicAdd(&hist[2u * 65536u + 1u], nb1); }
+}
+
+// per-tile moment sums in a fixed order (run-to-run identical): sweep -> partials -> one thread per (tile, moment).
+// Persistent like the sweep kernels of the per-phase schedule: the 64 KB table is written once per workgroup.
 template <bool ALIGNED>
-__global__ __launch_bounds__(kSweepThreads, 4) void k_tile_moment_partials(const uint8_t* rgb, int P, int parts, float ylimf, double* partials) {
+__global__ __launch_bounds__(kSweepThreads, 4) void k_tile_moment_partials(const uint8_t* rgb, int P, int parts, int n_items, float ylimf, double* partials) {
     __shared__ RowTab s_tab;
     __shared__ double s_red[kSweepThreads / 64][10];
     s_tab.fill_b();
     __syncthreads();
     const TabReaderB T = TabReaderB::make(s_tab);
-    const int tile = blockIdx.x / parts, part = blockIdx.x % parts;
     const int tid = threadIdx.x, lane = tid & 63;
-    const uint8_t* src = rgb + (size_t)tile * P * 3;
-    int c0, c1;
-    part_range((P + 3) >> 2, parts, part, c0, c1);
-    Moments mo;
-    uint32_t n_tissue = 0;
-    if (c0 < c1) moments_sweep_b<ALIGNED, kPhaseTrip>(src, P, c0, c1, tid, kSweepThreads, T, ylimf, 6, nullptr, mo, n_tissue);   // (block-uniform)
-    double v[10];
-    mo.to_array(v, n_tissue, lane);
+    const bool stream = (size_t)P * 3 >= kStreamBytes;            // uniform
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int tile = item / parts, part = item % parts;
+        const uint8_t* src = rgb + (size_t)tile * P * 3;
+        int c0, c1;
+        part_range((P + 3) >> 2, parts, part, c0, c1);
+        Moments mo;
+        uint32_t n_tissue = 0;
+        if (c0 >= c1) {                                           // an empty trailing part (block-uniform): zeros
+        } else if (stream) moments_sweep_b<ALIGNED, kPhaseTrip, true>(src, P, c0, c1, tid, kSweepThreads, T, ylimf, 6, nullptr, mo, n_tissue);
+        else moments_sweep_b<ALIGNED, kPhaseTrip, false>(src, P, c0, c1, tid, kSweepThreads, T, ylimf, 6, nullptr, mo, n_tissue);
+        double v[10];
+        mo.to_array(v, n_tissue, lane);
 #pragma unroll
-    for (int i = 0; i < 10; ++i) v[i] = wave_sum(v[i]);
-    if (lane == 0)
-        for (int i = 0; i < 10; ++i) s_red[tid >> 6][i] = v[i];
-    __syncthreads();
-    if (tid < 10) {
-        double t = 0;
-        for (int w = 0; w < kSweepThreads / 64; ++w) t += s_red[w][tid];
-        partials[((size_t)tile * parts + part) * 10 + tid] = t;
+        for (int i = 0; i < 10; ++i) v[i] = wave_sum(v[i]);
+        if (lane == 0)
+            for (int i = 0; i < 10; ++i) s_red[tid >> 6][i] = v[i];
+        __syncthreads();
+        if (tid < 10) {
+            double t = 0;
+            for (int w = 0; w < kSweepThreads / 64; ++w) t += s_red[w][tid];
+            partials[((size_t)tile * parts + part) * 10 + tid] = t;
+        }
+        __syncthreads();                                          // s_red is reused by the next item
     }
 }
 __global__ void k_sum_partials(const double* partials, int n, int parts, double* out) {
@@ -251,6 +414,13 @@ __global__ void k_sum_partials(const double* partials, int n, int parts, double*
     double t = 0;
     for (int p = 0; p < parts; ++p) t += partials[((size_t)tile * parts + p) * 10 + m];
     out[i] = t;
+}
+
+float ord_to_float_host(uint32_t o) {
+    const uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
 }
 
 int fill_args(SlideArgs& a, const uint8_t* rgb, int n, int h, int w, const SlParams* params, int keyset, const double* basis_host) {
@@ -272,6 +442,7 @@ int fill_args(SlideArgs& a, const uint8_t* rgb, int n, int h, int w, const SlPar
     for (int i = 0; i < 6; ++i) { a.V[i] = (float)basis_host[i]; a.M[i] = basis_host[i]; }
     a.prefix[0] = a.prefix[1] = 0; a.prefix_bits = 0; a.above[0] = a.above[1] = 0;
     a.window_lo[0] = a.window_lo[1] = 0; a.sample_mask = 0;
+    a.win_flo[0] = a.win_flo[1] = -INFINITY; a.win_fhi[0] = a.win_fhi[1] = INFINITY;
     return SL_OK;
 }
 
@@ -295,20 +466,23 @@ extern "C" int sl_tile_moments(const uint8_t* rgb, int n, int h, int w, const Sl
     if (!rgb || !moments_out || n <= 0 || h <= 0 || w <= 0) return SL_ERR_BADARG;
     const long P = (long)h * w;
     if (P > (1L << 30)) return SL_ERR_BADARG;
-    const int parts = parts_for(P);
+    int parts = parts_for(P);
     const size_t need = sizeof(double) * 10 * (size_t)parts * (size_t)n;
     if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 7u)) return SL_ERR_WORKSPACE;
+    const int mg = max_resident_grid();
+    const long want = (4L * mg + n - 1) / n;                      // ~4 items per persistent workgroup
+    if (parts > want) parts = (int)(want < 1 ? 1 : want);
+    const long items = (long)n * parts;
     SlParams p;
     sl_default_params(&p);
     if (params) p = *params;
     const float ylimf = (float)y_limit_for_threshold(p.luminosity_threshold) - 2048.0f;
     hipStream_t s = (hipStream_t)stream;
+    const dim3 g((unsigned)(items < mg ? items : mg)), b(kSweepThreads);
     if (aligned4(rgb, P))
-        hipLaunchKernelGGL((k_tile_moment_partials<true>), dim3((unsigned)((long)n * parts)), dim3(kSweepThreads), 0, s, rgb, (int)P, parts,
-                           ylimf, (double*)workspace);
+        hipLaunchKernelGGL((k_tile_moment_partials<true>), g, b, 0, s, rgb, (int)P, parts, (int)items, ylimf, (double*)workspace);
     else
-        hipLaunchKernelGGL((k_tile_moment_partials<false>), dim3((unsigned)((long)n * parts)), dim3(kSweepThreads), 0, s, rgb, (int)P, parts,
-                           ylimf, (double*)workspace);
+        hipLaunchKernelGGL((k_tile_moment_partials<false>), g, b, 0, s, rgb, (int)P, parts, (int)items, ylimf, (double*)workspace);
     hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((n * 10 + 255) / 256)), dim3(256), 0, s, (const double*)workspace, n, parts,
                        moments_out);
     return launch_status();
@@ -360,7 +534,32 @@ extern "C" int sl_slide_key_window(const uint8_t* rgb, int n, int h, int w, cons
     if (rc) return rc;
     if (!hist_below || !window_lo) return SL_ERR_BADARG;
     a.window_lo[0] = window_lo[0]; a.window_lo[1] = window_lo[1];
-    launch_keys<3>(a, aligned4(rgb, (long)h * w), hist_below, nullptr, (hipStream_t)stream);
+    // the windows as binary32 values for the cheap zone tests; a target whose bounds are not ordinary numbers gets none
+    bool usable = true;
+    for (int t = 0; t < 2; ++t) {
+        const uint32_t hi = window_lo[t] > 0xffffffffu - 65535u ? 0xffffffffu : window_lo[t] + 65535u;
+        a.win_flo[t] = ord_to_float_host(window_lo[t]);
+        a.win_fhi[t] = ord_to_float_host(hi);
+        if (!std::isfinite(a.win_flo[t]) || !std::isfinite(a.win_fhi[t])) usable = false;
+    }
+    // angle: both targets share the key, and the zone tests assume window 0 lies below window 1
+    if (keyset == SL_KEYSET_ANGLE && !(a.win_flo[0] <= a.win_flo[1] && a.win_fhi[0] <= a.win_fhi[1])) usable = false;
+    // concentrations: the binary32 comparison stands in for the ordered-integer one only for c >= +0 (g12 < 0 included: exact keys either way)
+    if (!usable)
+        for (int t = 0; t < 2; ++t) { a.win_flo[t] = -INFINITY; a.win_fhi[t] = INFINITY; }
+    {
+        const bool al = aligned4(rgb, (long)h * w);
+        const int mg = max_resident_grid();
+        const dim3 g((unsigned)(a.n_items < mg ? a.n_items : mg)), b(kSweepThreads);
+        hipStream_t s = (hipStream_t)stream;
+        if (keyset == SL_KEYSET_ANGLE) {
+            if (al) hipLaunchKernelGGL((k_slide_window<SL_KEYSET_ANGLE, true>), g, b, 0, s, a, hist_below);
+            else    hipLaunchKernelGGL((k_slide_window<SL_KEYSET_ANGLE, false>), g, b, 0, s, a, hist_below);
+        } else {
+            if (al) hipLaunchKernelGGL((k_slide_window<SL_KEYSET_CONC, true>), g, b, 0, s, a, hist_below);
+            else    hipLaunchKernelGGL((k_slide_window<SL_KEYSET_CONC, false>), g, b, 0, s, a, hist_below);
+        }
+    }
     return launch_status();
 }
 

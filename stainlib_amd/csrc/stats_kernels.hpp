@@ -54,6 +54,7 @@ constexpr int kFinishThreads = 1024;
 constexpr int kFusedThreads = 512;  // 2 resident workgroups per CU (<=128 VGPRs, <80 KB LDS each)
 constexpr int kSweepThreads = 512;  // sweep kernels of the one-launch-per-phase schedule (same occupancy: 64 KB table each)
 constexpr int kFusedTrip = 4;       // chunks per lane and sweep trip in the fused kernel (even)
+constexpr int kBrkBatch = 8;       // sample words in flight per lane while the bracket keys are evaluated
 constexpr int kPhaseTrip = 4;       // ... in the one-sweep kernels (32 Ki-pixel parts: 8 chunks per lane)
 constexpr int kStageWave = 256;     // per-wave LDS staging entries for raw candidates (8 KB per 8 waves)
 constexpr float kBracketZ = 6.0f;   // bracket half-width in standard deviations of the sample rank
@@ -153,6 +154,10 @@ __device__ __forceinline__ long long sample_pixel(uint32_t b, int cps_log2) {
     const uint32_t h = sample_hash(chunk0 >> sample_group_shift(cps_log2));
     const uint32_t chunk = chunk0 + ((h >> 8) & ((1u << cps_log2) - 1u));
     return (long long)chunk * 4 + ((h >> 31) ? 3 : 0);
+}
+// only the LAST block of a tile can hold its draw beyond the tile: every other entry is present without looking
+__device__ __forceinline__ bool sample_absent(int b, int cps_log2, int P) {
+    return b >= ((P - 1) >> (cps_log2 + 2)) && sample_pixel((uint32_t)b, cps_log2) >= P;
 }
 
 // Monotone surrogate of arctan2(y, x) on (-pi, pi]: y/(|x|+|y|) in [-1,1] for x >= 0, mirrored to
@@ -868,7 +873,7 @@ __device__ __forceinline__ void select_sweep(const uint8_t* src, int P, int c0, 
 struct SampleAngleKey {
     const uint32_t* sample; TabView tab; float V[6]; int cps_log2; int P; float ylimf;
     __device__ __forceinline__ float operator()(int b) const {
-        if (sample_pixel((uint32_t)b, cps_log2) >= P) return nan_f();
+        if (sample_absent(b, cps_log2, P)) return nan_f();
         return of_word(sample[b]);
     }
     // the key of a sample word already in a register; branch-free (NaN = not a tissue pixel)
@@ -878,19 +883,19 @@ struct SampleAngleKey {
         const float k = angle_key(V, tab.odf(r), tab.odf(g), tab.odf(bl));
         return tissue ? k : nan_f();
     }
-    __device__ __forceinline__ bool present(int b, int n_sample) const { return b < n_sample && sample_pixel((uint32_t)b, cps_log2) < P; }
+    __device__ __forceinline__ bool present(int b, int n_sample) const { return b < n_sample && !sample_absent(b, cps_log2, P); }
 };
 // concentration `col` of sample entry b (all pixels, tissue or not)
 struct SampleConcKey {
     const uint32_t* sample; TabView tab; LassoK L; int cps_log2; int P; int col;
     __device__ __forceinline__ void both(int b, float& c1, float& c2) const {      // NaN, NaN: entry absent
-        if (sample_pixel((uint32_t)b, cps_log2) >= P) { c1 = c2 = nan_f(); return; }
+        if (sample_absent(b, cps_log2, P)) { c1 = c2 = nan_f(); return; }
         of_word(sample[b], c1, c2);
     }
     __device__ __forceinline__ void of_word(uint32_t s, float& c1, float& c2) const {
         lasso2(L, tab.odf(s & 255u), tab.odf((s >> 8) & 255u), tab.odf((s >> 16) & 255u), c1, c2);
     }
-    __device__ __forceinline__ bool present(int b, int n_sample) const { return b < n_sample && sample_pixel((uint32_t)b, cps_log2) < P; }
+    __device__ __forceinline__ bool present(int b, int n_sample) const { return b < n_sample && !sample_absent(b, cps_log2, P); }
     __device__ __forceinline__ float operator()(int b) const {
         float c1, c2;
         both(b, c1, c2);
@@ -946,7 +951,7 @@ __device__ __forceinline__ void wg_refine(int n_raw, const Key2& key2, const flo
     __syncthreads();
     const int lane = threadIdx.x & 63;
     uint32_t lt0 = 0, lt1 = 0;
-    constexpr int U = 4;                                            // entries per lane and trip: one list-head update per trip
+    constexpr int U = 4;                                            // entries per lane and trip: one list-head update per trip (8: slower)
     const int step = (int)blockDim.x * U;
     for (int i0 = (int)(threadIdx.x - lane) * U; i0 < n_raw; i0 += step) {      // wave-uniform trip count
         float k0[U], k1[U];
@@ -1254,7 +1259,7 @@ __device__ __forceinline__ void dict_sweep_sample_b(const uint32_t* samp, int n_
     if (t < 512) {                                                      // wave-uniform
         for (int b0 = t & ~63; b0 < n_sample; b0 += 512) {
             const int b = b0 + lane;
-            const bool have = b < n_sample && sample_pixel((uint32_t)b, cps_log2) < P;
+            const bool have = b < n_sample && !sample_absent(b, cps_log2, P);
             const uint32_t s = samp[have ? b : 0];                      // unconditional load (n_sample >= 1); `have` masks the result
             const float2 er = T.gam_odf(T.addr(s, 0)), eg = T.gam_odf(T.addr(s, 1)), eb = T.gam_odf(T.addr(s, 2));
             acc.pixel(L, have & is_tissue_f(er.x, eg.x, eb.x, ylimf), er.y, eg.y, eb.y);
@@ -1626,13 +1631,23 @@ __device__ __forceinline__ void angle_brackets(const SampleAngleKey& key, int n_
 #ifdef SL_DEBUG_SUBCLK
     long long bclk_t_ = wall_clock64();
 #endif
-    // (loading all sample words up front, so that the loads overlap, saves ~20 us here but measured 1-2 % SLOWER end to
-    // end: the extra live registers shift the allocator's spills into the sweep prologues)
+    // the sample words are loaded kBrkBatch at a time so that their latencies overlap (all 32 at once measured 1-2 % SLOWER end
+    // to end: the extra live registers shift the allocator's spills into the sweep prologues; 8 gains 1.5 %)
+    static_assert(KPT % kBrkBatch == 0, "");
 #pragma unroll
-    for (int j = 0; j < KPT; ++j) {
-        const int b = j * THREADS + (int)threadIdx.x;
-        const float k = b < n_sample ? key(b) : nan_f();
-        ord[0][j] = k == k ? f2ord(k) : kAbsent;
+    for (int j0 = 0; j0 < KPT; j0 += kBrkBatch) {
+        uint32_t w[kBrkBatch];
+#pragma unroll
+        for (int g = 0; g < kBrkBatch; ++g) {
+            const int b = (j0 + g) * THREADS + (int)threadIdx.x;
+            w[g] = b < n_sample ? key.sample[b] : 0u;
+        }
+#pragma unroll
+        for (int g = 0; g < kBrkBatch; ++g) {
+            const int b = (j0 + g) * THREADS + (int)threadIdx.x;
+            const float k = key.of_word(w[g]);
+            ord[0][j0 + g] = (k == k && key.present(b, n_sample)) ? f2ord(k) : kAbsent;
+        }
     }
     SL_BCLK(5);
     const int set_of[2] = {0, 0};
@@ -1647,13 +1662,24 @@ __device__ __forceinline__ void conc_brackets(const SampleConcKey& key, int n_sa
 #ifdef SL_DEBUG_SUBCLK
     long long bclk_t_ = wall_clock64();
 #endif
+    static_assert(KPT % kBrkBatch == 0, "");
 #pragma unroll
-    for (int j = 0; j < KPT; ++j) {
-        const int b = j * THREADS + (int)threadIdx.x;
-        float c1 = nan_f(), c2 = nan_f();
-        if (b < n_sample) key.both(b, c1, c2);
-        ord[0][j] = c1 == c1 ? f2ord(c1) : kAbsent;
-        ord[1][j] = c2 == c2 ? f2ord(c2) : kAbsent;
+    for (int j0 = 0; j0 < KPT; j0 += kBrkBatch) {
+        uint32_t w[kBrkBatch];
+#pragma unroll
+        for (int g = 0; g < kBrkBatch; ++g) {
+            const int b = (j0 + g) * THREADS + (int)threadIdx.x;
+            w[g] = b < n_sample ? key.sample[b] : 0u;
+        }
+#pragma unroll
+        for (int g = 0; g < kBrkBatch; ++g) {
+            const int b = (j0 + g) * THREADS + (int)threadIdx.x;
+            float c1, c2;
+            key.of_word(w[g], c1, c2);
+            const bool have = key.present(b, n_sample);
+            ord[0][j0 + g] = (have && c1 == c1) ? f2ord(c1) : kAbsent;
+            ord[1][j0 + g] = (have && c2 == c2) ? f2ord(c2) : kAbsent;
+        }
     }
     SL_BCLK(6);
     const int set_of[2] = {0, 1};
