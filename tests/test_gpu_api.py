@@ -339,3 +339,41 @@ def test_configs3_tile_size_stain_augmentor_and_hed_batch():
     ro, _ = r.transform_batch(dev[:3], mask_background=True)
     for i in range(3):
         assert np.array_equal(ro[i].cpu().numpy(), orr.transform(tiles[i], mask_background=True))
+
+
+@pytest.mark.parametrize("shape", [(33, 47), (96, 128), (61, 64)])
+def test_slide_window_sweep_agrees_with_the_radix_histograms(shape):
+    """The window sweep proves most pixels with cheap binary32 zone tests and takes the exact path for the rest; the radix
+    kernels evaluate the ordered key of every pixel.  With a window placed on a 16-bit prefix both must report the same
+    65536 bins and the same count below, on ragged / unaligned tiles (tail trips), with a white tile, for both key sets and
+    for a negatively correlated stain pair (general lasso path)."""
+    import torch
+    from stainlib_amd import engine, _ffi
+    h, w = shape
+    tiles = [so.synth_tile(h, w, 300 + s) for s in range(5)] + [np.full((h, w, 3), 255, np.uint8)]
+    flat = torch.zeros(len(tiles) * h * w * 3 + 1, dtype=torch.uint8, device="cuda")
+    for offset in (0, 1):                                   # offset 1: tile bytes not 4-byte aligned
+        dev = flat[offset:offset + len(tiles) * h * w * 3].view(len(tiles), h, w, 3)
+        dev.copy_(to_dev(tiles))
+        V = np.linalg.qr(np.random.default_rng(3).normal(size=(3, 2)))[0]
+        M_pos = so.M_TRUE_TGT / np.linalg.norm(so.M_TRUE_TGT, axis=1, keepdims=True)
+        M_neg = np.array([[0.8, 0.6, 0.0], [-0.2, 0.3, 0.93]])
+        M_neg /= np.linalg.norm(M_neg, axis=1, keepdims=True)
+        for keyset, basis in ((_ffi.KEYSET_ANGLE, V.reshape(6)), (_ffi.KEYSET_CONC, M_pos.reshape(6)), (_ffi.KEYSET_CONC, M_neg.reshape(6))):
+            h0 = engine.slide_key_histogram(dev, keyset, basis, (0, 0), 0).cpu().numpy()
+            total = int(h0[0].sum())
+            assert total > 0
+            # the 16-bit prefixes holding the 30 % and the 90 % key of target 0 / target 1
+            pre16 = []
+            for t, frac in ((0, 0.3), (1, 0.9)):
+                k = int(frac * (int(h0[t].sum()) - 1))
+                b8 = int(np.searchsorted(np.cumsum(h0[t]), k, side="right"))
+                h1 = engine.slide_key_histogram(dev, keyset, basis, (b8, b8), 8).cpu().numpy()
+                below8 = int(h0[t][:b8].sum())
+                b16 = int(np.searchsorted(np.cumsum(h1[t]), k - below8, side="right"))
+                pre16.append(((b8 << 8) | b16, below8 + int(h1[t][:b16].sum())))
+            want = engine.slide_key_histogram16(dev, keyset, basis, (pre16[0][0], pre16[1][0])).cpu().numpy().reshape(2, 65536)
+            got = engine.slide_key_window(dev, keyset, basis, (pre16[0][0] << 16, pre16[1][0] << 16)).cpu().numpy()
+            assert np.array_equal(got[:65536], want[0]) and np.array_equal(got[65536:131072], want[1])
+            assert int(got[131072]) == pre16[0][1] and int(got[131073]) == pre16[1][1]
+            assert int(want[0].sum()) > 0 and int(want[1].sum()) > 0
