@@ -146,20 +146,19 @@ int run_dict_group(const uint8_t* rgb, int g0, int m, long P, const SlParams& p,
     const long items = (long)m * L.parts;
     const dim3 gs((unsigned)(items < L.max_grid ? items : L.max_grid)), bs(kSweepThreads), gf((unsigned)m), bf(kFinishThreads), bd(kDictFinishThreads);
     SlProfile* prof = p.profile;
-    {
-        ProfScope ps(prof, SL_PROF_DICT, m, s);
-        if (al) hipLaunchKernelGGL((k_dict<true, true>), gs, bs, 0, s, a);
-        else    hipLaunchKernelGGL((k_dict<false, true>), gs, bs, 0, s, a);
+    {   // the sample, gathered without a sweep, and the dictionary iterated on it
+        ProfScope ps(prof, SL_PROF_FINISH, m, s);
+        if (al) hipLaunchKernelGGL((k_dict_start<true>), gf, bd, 0, s, a);
+        else    hipLaunchKernelGGL((k_dict_start<false>), gf, bd, 0, s, a);
     }
-    { ProfScope ps(prof, SL_PROF_FINISH, m, s); hipLaunchKernelGGL(k_dict_finish, gf, bd, 0, s, a, 1); }
-    const int fixed = a.dl_max_sweeps - 1 < kDictFixedSweeps ? a.dl_max_sweeps - 1 : kDictFixedSweeps;
+    const int fixed = a.dl_max_sweeps < kDictFixedSweeps ? a.dl_max_sweeps : kDictFixedSweeps;
     for (int i = 0; i < fixed; ++i) {
         {
             ProfScope ps(prof, SL_PROF_DICT, m, s);
-            if (al) hipLaunchKernelGGL((k_dict<true, false>), gs, bs, 0, s, a);
-            else    hipLaunchKernelGGL((k_dict<false, false>), gs, bs, 0, s, a);
+            if (al) hipLaunchKernelGGL((k_dict<true>), gs, bs, 0, s, a);
+            else    hipLaunchKernelGGL((k_dict<false>), gs, bs, 0, s, a);
         }
-        { ProfScope ps(prof, SL_PROF_FINISH, m, s); hipLaunchKernelGGL(k_dict_finish, gf, bd, 0, s, a, 0); }
+        { ProfScope ps(prof, SL_PROF_FINISH, m, s); hipLaunchKernelGGL(k_dict_finish, gf, bd, 0, s, a); }
     }
     {
         ProfScope ps(prof, SL_PROF_FINISH, m, s);

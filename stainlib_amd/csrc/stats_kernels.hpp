@@ -1197,12 +1197,11 @@ struct DictWaveAcc {
 // classify every tissue pixel of chunks [c0,c1) under the dictionary L and accumulate the class moments into acc (its row
 // must have been begun; the caller flushes nothing: the sweep ends flushed).  c0 must be a multiple of 64 (of
 // kDictBurstTrips trips for schedule-independent bursts).  Structure of moments_sweep_b.
-template <bool ALIGNED, bool SAMPLE, int kTrip, bool STREAM = false>
+template <bool ALIGNED, int kTrip, bool STREAM = false>
 __device__ __forceinline__ void dict_sweep_b(const uint8_t* src, int P, int c0, int c1, int t, int nthreads, const TabReaderB& T,
-                                             float ylimf, int stride_log2, const DictK& L, uint32_t* samp, DictWaveAcc& acc) {
+                                             float ylimf, const DictK& L, DictWaveAcc& acc) {
     const size_t nbytes = (size_t)P * 3;
     const int lane = t & 63;
-    const int cps_log2 = stride_log2 - 2;
     const int w0 = __builtin_amdgcn_readfirstlane(c0 + (t & ~63));
     struct G { float2 v[12]; };
     auto fetch = [&](int cc) { return load_chunk_clamped<ALIGNED, STREAM>(src, nbytes, cc, c1); };
@@ -1229,10 +1228,6 @@ __device__ __forceinline__ void dict_sweep_b(const uint8_t* src, int P, int c0, 
     for (int k = 0; k < kTrip; ++k) { cur[k] = fetch(w0 + lane + k * nthreads); nx[k] = fetch(w0 + lane + (kTrip + k) * nthreads); }
     int trips = 0;
     auto trip = [&](auto tail_tag, int cb) {
-        if (SAMPLE) {
-#pragma unroll
-            for (int k = 0; k < kTrip; ++k) sample_row<ALIGNED>(cur[k], cb + k * nthreads, cb + k * nthreads + lane, c1, P, cps_log2, samp);
-        }
 #pragma unroll
         for (int k = 0; k < kTrip; ++k) {
             const G g = gather(cur[k]);
@@ -1247,6 +1242,25 @@ __device__ __forceinline__ void dict_sweep_b(const uint8_t* src, int P, int c0, 
     for (; cb + (kTrip - 1) * nthreads + 64 <= lim; cb += nthreads * kTrip) trip(std::false_type{}, cb);
     if (cb < c1) trip(std::true_type{}, cb);
     if (trips) acc.flush(lane);
+}
+
+// The stratified sample of a tile WITHOUT a sweep: entry b is the pixel sample_row() would keep for block b, fetched directly
+// (one 4-byte load per entry from a different 128-byte line each: ~2/3 of the tile's lines are touched, but nothing is
+// computed).  The Vahadane path starts from it: the dictionary is first iterated on the sample, and every full sweep then
+// starts near the fixed point.  Entries whose pixel lies beyond the tile stay unwritten (readers test sample_absent).
+template <bool ALIGNED>
+__device__ __forceinline__ void gather_sample(const uint8_t* src, int P, int stride_log2, uint32_t* samp, int n_sample, int t, int nthreads) {
+    const int cps_log2 = stride_log2 - 2;
+    for (int b = t; b < n_sample; b += nthreads) {
+        const long long px = sample_pixel((uint32_t)b, cps_log2);
+        if (px >= P) continue;
+        const uint8_t* q = src + 3 * (size_t)px;
+        uint32_t v;
+        if (ALIGNED && (px & 3) == 0) v = *(const uint32_t*)q;                                   // pixel 0 of its chunk: {r, g, b, stray}
+        else if (ALIGNED) v = *(const uint32_t*)(q - 1) >> 8;                                   // pixel 3: {b of pixel 2, r, g, b} >> 8
+        else v = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16);
+        samp[b] = v;
+    }
 }
 
 // the same classification + accumulation over the tile's stratified SAMPLE (tissue entries only): a 1/64-cost stand-in for
@@ -1464,7 +1478,7 @@ __device__ __forceinline__ void dict_iter_init(DictIter& it) {
     it.inner_cap = 500;
 }
 // one lane: the dictionary update from the 31 class-moment sums of a sweep (sum[30] = tissue pixels seen).
-// stage: 0 first full sweep, 1 sample iteration, 2 full sweep; outer = steps already taken in this stage.
+// stage: 1 sample iteration, 2 full sweep; outer = steps already taken in this stage.
 // goal = the change of D below which the caller stops iterating this stage: the frozen-partition solve runs to
 // 1e-3 of it (at its ~0.7 linear rate the remaining error is ~2 steps), never below 1e-13.
 __device__ __forceinline__ void dict_iter_update(DictIter& it, const double* sum, double lam, int stage, int outer, double goal) {
@@ -1476,7 +1490,7 @@ __device__ __forceinline__ void dict_iter_update(DictIter& it, const double* sum
     double D[2][3];
     for (int j = 0; j < 2; ++j)
         for (int k = 0; k < 3; ++k) D[j][k] = it.D[3 * j + k];
-    const double delta = dict_inner_solve(sum, D, lam, stage == 0 && it.inner_cap > kDictFirstCap ? kDictFirstCap : it.inner_cap, fmax(1e-3 * goal, 1e-13));
+    const double delta = dict_inner_solve(sum, D, lam, stage == 1 && outer == 0 && it.inner_cap > kDictFirstCap ? kDictFirstCap : it.inner_cap, fmax(1e-3 * goal, 1e-13));
     // The frozen-partition solve is a Newton-like step on a piecewise-smooth map and can fall
     // into a 2-cycle between two partitions: the new iterate then returns to the one before
     // last.  In that case restart from the midpoint and shorten the inner solve; at one inner
@@ -1518,11 +1532,9 @@ __device__ __forceinline__ bool dict_advance(DictIter& it, DictProgress& pr, dou
     ++pr.outer;
     if (pr.stage != 1) ++pr.sweeps_used;
     if (it.status != SL_TILE_OK) return false;
-    if (pr.stage == 0) {
-        pr.stage = 1; pr.outer = 0;
-    } else if (pr.stage == 1) {
+    if (pr.stage == 1) {
         ++pr.sample_its;
-        if (it.delta < kDictSampleTol || pr.sample_its >= 40) {                // sample fixed point reached: back to the tile
+        if (it.delta < kDictSampleTol || pr.sample_its >= 40) {                // sample fixed point reached: on to the tile
             pr.stage = 2; pr.outer = 0;
             __syncthreads();
             if (tid == 0) dict_iter_restart(it);
@@ -1534,11 +1546,12 @@ __device__ __forceinline__ bool dict_advance(DictIter& it, DictProgress& pr, dou
     return true;
 }
 
-// One workgroup iterates a tile's dictionary from (it, pr) until it settles.  Schedule: one full sweep (it also drops
-// the sample), then the SAME fixed-point iteration on the 16 Ki-pixel sample until it settles (each step costs 1/64 of
-// a sweep), then full sweeps from that warm start until the dictionary moves by less than tol: ~4 full sweeps instead
-// of ~9.  red/sum are workgroup scratch.  Ends with a barrier.  SAMPLE_ONLY: only the
-// sample stage (the per-phase schedule runs the full sweeps as launches of their own).
+// One workgroup iterates a tile's dictionary from (it, pr) until it settles.  Schedule (pr starts at stage 1 with the
+// sample gathered: gather_sample): the fixed-point iteration on the 16 Ki-pixel sample until it settles (each step costs
+// 1/64 of a sweep), then full sweeps from that warm start until the dictionary moves by less than tol: ~3 full sweeps
+// instead of ~9 from the cold start.  (Round 1 spent one more full sweep up front, whose only lasting product was the
+// sample.)  red/sum are workgroup scratch.  Ends with a barrier.  SAMPLE_ONLY: only the sample stage (the per-phase
+// schedule runs the full sweeps as launches of their own).
 template <bool ALIGNED, int NT, bool SAMPLE_ONLY = false, bool STREAM = false>
 __device__ __forceinline__ void dict_learn(const uint8_t* src, int P, int nch, int tid, const TabReaderB& T, float ylimf,
                                            int stride_log2, uint32_t* samp, int n_sample, double lam, double tol, int max_sweeps,
@@ -1551,12 +1564,10 @@ __device__ __forceinline__ void dict_learn(const uint8_t* src, int P, int nch, i
         __syncthreads();                                             // previous iteration's readers of red are done
         DictWaveAcc acc;
         acc.begin(red[wave], lane);
-        if (!SAMPLE_ONLY && pr.stage == 0)
-            dict_sweep_b<ALIGNED, true, kDictTrip, STREAM>(src, P, 0, nch, tid, NT, T, ylimf, stride_log2, Ld, samp, acc);
-        else if (SAMPLE_ONLY || pr.stage == 1)
+        if (SAMPLE_ONLY || pr.stage == 1)
             dict_sweep_sample_b(samp, n_sample, stride_log2, P, tid, T, ylimf, Ld, acc);
         else
-            dict_sweep_b<ALIGNED, false, kDictTrip, STREAM>(src, P, 0, nch, tid, NT, T, ylimf, stride_log2, Ld, samp, acc);
+            dict_sweep_b<ALIGNED, kDictTrip, STREAM>(src, P, 0, nch, tid, NT, T, ylimf, Ld, acc);
         __syncthreads();
         if (tid < 31) {
             double t = 0;
@@ -1893,7 +1904,7 @@ struct DictState {
     int pad_;
 };
 
-template <bool ALIGNED, bool FIRST>
+template <bool ALIGNED>
 static __global__ __launch_bounds__(kSweepThreads, 4) void k_dict(StatsArgs a) {
     __shared__ RowTab s_tab;
     __shared__ double s_red[kSweepThreads / 64][32];
@@ -1904,24 +1915,17 @@ static __global__ __launch_bounds__(kSweepThreads, 4) void k_dict(StatsArgs a) {
     for (int item = blockIdx.x; item < a.n_items; item += gridDim.x) {
         const int tile = item / a.parts, part = item % a.parts;
         const DictState& ds = a.dstate[tile];
-        if (!FIRST && ds.done) continue;                                    // block-uniform
+        if (ds.done) continue;                                              // block-uniform
         DictK Ld;
-        if (FIRST) {
-            DictIter it0;
-            dict_iter_init(it0);
-            dict_consts(it0.D, a.dl_lambda, Ld);
-        } else {
-            dict_consts(ds.it.D, a.dl_lambda, Ld);
-        }
+        dict_consts(ds.it.D, a.dl_lambda, Ld);
         const uint8_t* src = a.rgb + (size_t)tile * a.P * 3;
-        uint32_t* samp = a.sample + (size_t)tile * a.n_sample;
         int c0, c1;
         part_range((a.P + 3) >> 2, a.parts, part, c0, c1, kDictAlignTrips);
         DictWaveAcc acc;
         acc.begin(s_red[tid >> 6], lane);
         if (c0 >= c1) {                          // an empty trailing part (block-uniform): zeros
-        } else if ((size_t)a.P * 3 >= kStreamBytes) dict_sweep_b<ALIGNED, FIRST, kDictTrip, true>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, a.stride_log2, Ld, samp, acc);
-        else dict_sweep_b<ALIGNED, FIRST, kDictTrip, false>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, a.stride_log2, Ld, samp, acc);
+        } else if ((size_t)a.P * 3 >= kStreamBytes) dict_sweep_b<ALIGNED, kDictTrip, true>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, Ld, acc);
+        else dict_sweep_b<ALIGNED, kDictTrip, false>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, Ld, acc);
         __syncthreads();
         if (tid < 31) {
             double t = 0;
@@ -1944,20 +1948,39 @@ __device__ __forceinline__ void dict_finalize(const DictIter& it, TileState& st)
 // (512 threads like the sweep kernels: the sample stage and the straggler sweeps then form the same binary32 bursts as the
 // fused kernel)
 constexpr int kDictFinishThreads = kSweepThreads;
-static __global__ __launch_bounds__(kDictFinishThreads) void k_dict_finish(StatsArgs a, int first) {
+// one workgroup per tile: gather the stratified sample, iterate the dictionary on it from the Ruifrok start
+template <bool ALIGNED>
+static __global__ __launch_bounds__(kDictFinishThreads) void k_dict_start(StatsArgs a) {
     __shared__ RowTab s_tab;
     __shared__ DictScratch<kDictFinishThreads> s_d;
     const int tile = blockIdx.x, tid = threadIdx.x;
     DictState& ds = a.dstate[tile];
-    if (!first && ds.done) return;
-    DictProgress pr{0, 0, 0, 0};
-    if (first) {
-        s_tab.fill_b();
-        if (tid == 0) dict_iter_init(s_d.it);
-    } else {
-        pr = ds.pr;
-        if (tid == 0) s_d.it = ds.it;
+    uint32_t* samp = a.sample + (size_t)tile * a.n_sample;
+    s_tab.fill_b();
+    gather_sample<ALIGNED>(a.rgb + (size_t)tile * a.P * 3, a.P, a.stride_log2, samp, a.n_sample, tid, kDictFinishThreads);
+    if (tid == 0) dict_iter_init(s_d.it);
+    __syncthreads();
+    DictProgress pr{1, 0, 0, 0};
+    const TabReaderB T = TabReaderB::make(s_tab);
+    dict_learn<true, kDictFinishThreads, true>(nullptr, a.P, 0, tid, T, a.ylimf, a.stride_log2, samp, a.n_sample, a.dl_lambda, a.dl_tol,
+                                           a.dl_max_sweeps, s_d.it, s_d.red, s_d.sum, pr);
+    if (tid == 0) {
+        const bool go = s_d.it.status == SL_TILE_OK && pr.stage == 2;
+        ds.it = s_d.it;
+        ds.pr = pr;
+        ds.done = go ? 0 : 1;
+        if (!go) dict_finalize(s_d.it, a.state[tile]);
     }
+}
+
+// one workgroup per tile: the dictionary update from the partial sums of a full-sweep launch
+static __global__ __launch_bounds__(kDictFinishThreads) void k_dict_finish(StatsArgs a) {
+    __shared__ DictScratch<kDictFinishThreads> s_d;
+    const int tile = blockIdx.x, tid = threadIdx.x;
+    DictState& ds = a.dstate[tile];
+    if (ds.done) return;
+    DictProgress pr = ds.pr;
+    if (tid == 0) s_d.it = ds.it;
     if (tid < 31) {                                   // fixed order => run-to-run identical sums
         double t = 0;
         for (int p = 0; p < a.parts; ++p) t += a.partials[((size_t)tile * a.parts + p) * 32 + tid];
@@ -1966,13 +1989,7 @@ static __global__ __launch_bounds__(kDictFinishThreads) void k_dict_finish(Stats
     __syncthreads();
     if (tid == 0) dict_iter_update(s_d.it, s_d.sum, a.dl_lambda, pr.stage, pr.outer, a.dl_tol);
     __syncthreads();
-    bool go = dict_advance(s_d.it, pr, a.dl_tol, tid) && pr.sweeps_used < a.dl_max_sweeps;
-    if (go && pr.stage == 1) {                        // block-uniform; only after the first sweep
-        const TabReaderB T = TabReaderB::make(s_tab);
-        dict_learn<true, kDictFinishThreads, true>(nullptr, a.P, 0, tid, T, a.ylimf, a.stride_log2, a.sample + (size_t)tile * a.n_sample,
-                                               a.n_sample, a.dl_lambda, a.dl_tol, a.dl_max_sweeps, s_d.it, s_d.red, s_d.sum, pr);
-        go = s_d.it.status == SL_TILE_OK && pr.stage == 2;
-    }
+    const bool go = dict_advance(s_d.it, pr, a.dl_tol, tid) && pr.sweeps_used < a.dl_max_sweeps;
     if (tid == 0) {
         ds.it = s_d.it;
         ds.pr = pr;
@@ -2222,12 +2239,13 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
             }
         } else {
             // ---------------- Vahadane: class-moment dictionary learning
+            gather_sample<ALIGNED>(src, a.P, a.stride_log2, samp, a.n_sample, tid, NT);
             if (tid == 0) {
                 dict_iter_init(sh.it);
                 sh.n_raw = 0; sh.overflow = 0;
             }
             __syncthreads();
-            DictProgress pr{0, 0, 0, 0};
+            DictProgress pr{1, 0, 0, 0};
             if (stream) dict_learn<ALIGNED, NT, false, true>(src, a.P, nch, tid, TB, a.ylimf, a.stride_log2, samp, a.n_sample, a.dl_lambda,
                                                              a.dl_tol, a.dl_max_sweeps, sh.it, sh.red, sh.sum, pr);
             else dict_learn<ALIGNED, NT, false, false>(src, a.P, nch, tid, TB, a.ylimf, a.stride_log2, samp, a.n_sample, a.dl_lambda,

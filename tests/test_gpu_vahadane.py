@@ -142,7 +142,7 @@ def test_vahadane_schedules_agree():
         d = np.abs(a[4].astype(np.int16) - b[4].astype(np.int16))
         assert d.max() <= 1 and (d != 0).mean() < 1e-4
         if tol == 1e-12:
-            assert a[3].max() > 5                                          # beyond first + fixed sweeps: the tail kernel ran
+            assert a[3].max() > 4                                          # more than the 4 full-sweep launches: the tail kernel ran
 
 
 @pytest.mark.parametrize("max_sweeps", [2, 3, 7])   # (after a single sweep the two atoms are still nearly collinear: the codes are ill-conditioned)
