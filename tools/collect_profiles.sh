@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collects every measurement the docs cite into gpurun_out/ (run on the GPU box from the repo root):
 #   make -C tools && /usr/local/graft/bin/gpurun --timeout 1800 -- 'bash tools/collect_profiles.sh r02'
-# then copy gpurun_out/r02_* to profiles/ (tracked).
+# then copy gpurun_out/r02_* to profiles/ (tracked); bench.py reads <tag>_pmc_traffic.json from there.
 tag=${1:-r02}
 cd "$GRAFT_REPO_ROOT" || exit 1
 out=$PWD/gpurun_out
@@ -47,6 +47,11 @@ for n in 64 512; do
   rm -rf /tmp/pm_$n; timeout 300 rocprofv3 --pmc FETCH_SIZE -d /tmp/pm_$n -o p -- python tools/run_multi.py $n 1 > /dev/null 2>&1
   python tools/pmc_summary.py "$(ls /tmp/pm_$n/*/*.db /tmp/pm_$n/*.db 2>/dev/null | head -1)" > "$out/${tag}_pmc_phase_fetch_n$n.txt" 2>&1
 done
+python tools/make_pmc_traffic.py "$tag" "$out" > "$out/${tag}_pmc_traffic.json" 2> /dev/null
+# configs[4] at one GPU's shard size, the Lab family's kernels
+python tools/slide_scale.py 512,2048,12500 2>/dev/null | grep -v amdgpu > "$out/${tag}_slide_scale.txt"
+rm -rf /tmp/kl; timeout 300 rocprofv3 --kernel-trace -d /tmp/kl -o p -- python tools/run_lab.py > /dev/null 2>&1
+python tools/rocpd_stats.py "$(ls /tmp/kl/*/*.db /tmp/kl/*.db 2>/dev/null | head -1)" 2>&1 | grep -v "at::native\|rocclr\|Cijk" > "$out/${tag}_kernel_stats_lab.md"
 [ -x tools/bin/ubench_ops ] && timeout 120 tools/bin/ubench_ops > "$out/${tag}_ubench_ops.txt" 2>&1
 [ -x tools/bin/ubench_issue ] && timeout 120 tools/bin/ubench_issue > "$out/${tag}_ubench_issue.txt" 2>&1
 [ -x tools/bin/kbench_stream ] && timeout 120 tools/bin/kbench_stream > "$out/${tag}_kbench_stream.txt" 2>&1
