@@ -377,3 +377,33 @@ def test_slide_window_sweep_agrees_with_the_radix_histograms(shape):
             assert np.array_equal(got[:65536], want[0]) and np.array_equal(got[65536:131072], want[1])
             assert int(got[131072]) == pre16[0][1] and int(got[131073]) == pre16[1][1]
             assert int(want[0].sum()) > 0 and int(want[1].sum()) > 0
+
+
+def test_calls_are_graph_capture_safe():
+    """engine.Graphed: the per-phase Macenko / Vahadane transforms and the HED augmentation captured into a HIP graph and
+    replayed on refilled inputs give the bytes of the direct calls."""
+    import torch
+    from stainlib_amd import engine
+    tiles_a = to_dev([so.synth_tile(96, 128, 500 + s) for s in range(6)])
+    tiles_b = to_dev([so.synth_tile(96, 128, 600 + s) for s in range(5)] + [np.full((96, 128, 3), 255, np.uint8)])
+    tgt = to_dev([so.synth_tile(128, 128, 1001, so.M_TRUE_TGT)])
+    Mt, mct, _ = engine.macenko_fit(tgt)
+    buf, out, ws = tiles_a.clone(), torch.empty_like(tiles_a), engine.Workspace()
+    for fn in (engine.macenko_transform, engine.vahadane_transform):
+        p = engine.make_params(schedule=1)
+        g = engine.Graphed(lambda: fn(buf, Mt[0], mct[0], params=p, out=out, ws=ws))
+        for src in (tiles_b, tiles_a):
+            buf.copy_(src)
+            o, M, mc, st = g.replay()
+            torch.cuda.synchronize()
+            o2, M2, mc2, st2 = fn(src, Mt[0], mct[0], params=p)
+            assert torch.equal(o, o2) and torch.equal(st, st2)
+            assert torch.equal(M.nan_to_num(), M2.nan_to_num()) and torch.equal(mc.nan_to_num(), mc2.nan_to_num())
+        assert list(st2.cpu().numpy()) == [0] * 6                       # tiles_a last; tiles_b ended with a white tile
+    sg = torch.as_tensor(np.tile(np.array([[0.01, -0.02, 0.015]]), (6, 1)), device="cuda")     # (host arrays would be copied under capture)
+    g = engine.Graphed(lambda: engine.hed_augment(buf, sg, sg, out=out, ws=ws))
+    buf.copy_(tiles_b)
+    o = g.replay()
+    torch.cuda.synchronize()
+    want = engine.hed_augment(tiles_b, sg, sg)
+    assert torch.equal(o if isinstance(o, torch.Tensor) else o[0], want if isinstance(want, torch.Tensor) else want[0])
