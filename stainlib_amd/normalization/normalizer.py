@@ -17,8 +17,10 @@ _METHODS = ("macenko", "vahadane")
 # A single image of this many pixels or more is not handled as ONE tile (whose finish steps run on one workgroup and
 # grow with the tile) but as the vertical concatenation of its row bands: the pooled slide statistics are, by
 # definition, the reference's statistics of that concatenation, i.e. of the image itself -- computed with chip-wide
-# sweeps only (8192 x 8192: 1.8 instead of 5.0 ms; stain matrix equal to 3e-15, maxC to the bit).
-BIG_IMAGE_PIXELS = 1 << 22
+# sweeps only (8192 x 8192: 1.9 instead of 4.9 ms; stain matrix equal to 3e-15, maxC to the bit).  The pooled path is
+# host-driven (~1.3 ms whatever the size), so it only pays from the measured crossover on (tools/big_image.py:
+# 4096^2 1.27 vs 1.58 ms, 6144^2 3.4 vs 1.9 ms).
+BIG_IMAGE_PIXELS = 5 << 22        # ~21 Mpx
 
 
 def _row_bands(dev_img):
