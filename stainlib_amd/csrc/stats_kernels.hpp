@@ -622,13 +622,16 @@ __device__ __forceinline__ bool stain_matrix_singular(const double* M) {
     return !(g11 * g22 - g12 * g12 > 1e-8 * g11 * g22);
 }
 
-// pseudo-angle order statistics -> stain matrix (macenko_stain_extractor.py:33-44)
-__device__ __forceinline__ void stain_matrix_from_angles(const double* Vd, const float* xs /*[4]*/, const double* gfrac, double* M) {
-    const double minPhi = np_lerp(angle_of_pseudo((double)xs[0]), angle_of_pseudo((double)xs[1]), gfrac[0]);
-    const double maxPhi = np_lerp(angle_of_pseudo((double)xs[2]), angle_of_pseudo((double)xs[3]), gfrac[1]);
-    double s1, c1, s2, c2;
-    sincos(minPhi, &s1, &c1);
-    sincos(maxPhi, &s2, &c2);
+// pseudo-angle order statistics -> stain matrix (macenko_stain_extractor.py:33-44).  Called by a whole wave (the result is
+// valid in every lane): the four arctan2 run in lanes 0-3 at once and the two sincos in lanes 0-1 -- this one-lane chain
+// of binary64 library calls was 31 us of every tile's finish step; the same calls on the same arguments, bit for bit.
+__device__ __forceinline__ void stain_matrix_from_angles(const double* Vd, const float* xs /*[4]*/, const double* gfrac, double* M, int lane) {
+    const double ang = angle_of_pseudo((double)xs[lane & 3]);
+    const int pair = (lane & 1) * 2;                      // even lanes: minPhi (xs[0], xs[1]); odd lanes: maxPhi (xs[2], xs[3])
+    const double phi = np_lerp(__shfl(ang, pair, 64), __shfl(ang, pair + 1, 64), (lane & 1) ? gfrac[1] : gfrac[0]);
+    double s, c;
+    sincos(phi, &s, &c);
+    const double s1 = __shfl(s, 0, 64), c1 = __shfl(c, 0, 64), s2 = __shfl(s, 1, 64), c2 = __shfl(c, 1, 64);
     double v1[3], v2[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {                         // :36-37
@@ -1806,9 +1809,10 @@ static __global__ SL_FINISH_BOUNDS void k_finish_angle(StatsArgs a) {
         if (tid == 0) { s_res[2 * li] = xa; s_res[2 * li + 1] = xb; }
         __syncthreads();
     }
+    double M[6];
+    if (tid < 64) stain_matrix_from_angles(st.Vd, s_res, gfrac, M, tid);     // (st.Vd: global memory, read-only here)
+    __syncthreads();                                     // every lane has read s_res before lane 0 reuses s_res[0]
     if (tid == 0) {
-        double M[6];
-        stain_matrix_from_angles(st.Vd, s_res, gfrac, M);
         const bool singular = stain_matrix_singular(M);
         if (singular) st.status = SL_TILE_DEGENERATE_COV;
         for (int i = 0; i < 6; ++i) st.M[i] = singular ? nan_d() : M[i];
@@ -2229,11 +2233,13 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
                     __syncthreads();
                     SL_SUB(4 + li);
                 }
-                if (tid == 0) {
+                if (tid < 64) {
                     double M[6];
-                    stain_matrix_from_angles(sh.Vd, sh.res, gfrac, M);
-                    for (int i = 0; i < 6; ++i) sh.M[i] = M[i];
-                    if (stain_matrix_singular(M)) sh.status = SL_TILE_DEGENERATE_COV;
+                    stain_matrix_from_angles(sh.Vd, sh.res, gfrac, M, tid);
+                    if (tid == 0) {
+                        for (int i = 0; i < 6; ++i) sh.M[i] = M[i];
+                        if (stain_matrix_singular(M)) sh.status = SL_TILE_DEGENERATE_COV;
+                    }
                 }
                 SL_SUB(6);
             }
