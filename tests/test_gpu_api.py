@@ -407,3 +407,50 @@ def test_calls_are_graph_capture_safe():
     torch.cuda.synchronize()
     want = engine.hed_augment(tiles_b, sg, sg)
     assert torch.equal(o if isinstance(o, torch.Tensor) else o[0], want if isinstance(want, torch.Tensor) else want[0])
+
+
+def test_c_abi_error_codes():
+    """The C ABI's own argument checks (include/stainlib_hip.h: SL_ERR_BADARG -1, SL_ERR_WORKSPACE -2), called raw through
+    ctypes: nothing is launched, nothing is written, and the error string names the cause."""
+    import ctypes as C
+    import torch
+    from stainlib_amd import _ffi, engine
+    lib = _ffi.lib()
+    n, h, w = 2, 32, 40
+    rgb = to_dev([so.synth_tile(h, w, 1), so.synth_tile(h, w, 2)])
+    out = torch.full_like(rgb, 7)
+    Mt = torch.tensor([[0.6, 0.7, 0.3], [0.1, 0.95, 0.2]], dtype=torch.float64, device="cuda")
+    mct = torch.tensor([1.5, 1.0], dtype=torch.float64, device="cuda")
+    need = lib.sl_workspace_bytes(_ffi.OP_MACENKO_TRANSFORM, n, h, w)
+    assert need > 0 and lib.sl_workspace_bytes(_ffi.OP_MACENKO_TRANSFORM, 0, h, w) == 0
+    ws = torch.zeros(need + 512, dtype=torch.uint8, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    null = C.c_void_p(0)
+
+    def transform(rgb_p=None, out_p=None, nn=n, ws_p=None, ws_bytes=need, fn=lib.sl_macenko_transform):
+        return fn(p(rgb) if rgb_p is None else rgb_p, p(out) if out_p is None else out_p, nn, h, w, None, p(Mt), p(mct), null, null, null,
+                  p(ws) if ws_p is None else ws_p, ws_bytes, null)
+    assert transform() == 0
+    torch.cuda.synchronize()
+    good = out.clone()
+    out.fill_(7)
+    for fn in (lib.sl_macenko_transform, lib.sl_vahadane_transform):
+        assert transform(rgb_p=null, fn=fn) == -1                                  # null input
+        assert transform(nn=0, fn=fn) == -1 and transform(nn=-3, fn=fn) == -1      # no tiles
+        assert transform(ws_bytes=need // 2, fn=fn) == -2                          # workspace too small
+        assert transform(ws_p=null, fn=fn) == -2                                   # no workspace
+        assert transform(ws_p=C.c_void_p(ws.data_ptr() + 8), fn=fn) == -2          # workspace not 256-byte aligned
+    assert lib.sl_macenko_transform(p(rgb), null, n, h, w, None, p(Mt), p(mct), null, null, null, p(ws), need, null) == -1   # no output
+    assert lib.sl_macenko_transform(p(rgb), p(out), n, h, w, None, null, p(mct), null, null, null, p(ws), need, null) == -1  # no target
+    torch.cuda.synchronize()
+    assert bool((out == 7).all())                                                  # none of the refused calls wrote anything
+    assert lib.sl_error_string(-1).decode() and "workspace" in lib.sl_error_string(-2).decode()
+    # the Python layer turns a refused call into an exception, never into a silent fallback
+    sg = torch.zeros((n, 3), dtype=torch.float64, device="cuda")
+    with pytest.raises(_ffi.StainlibHipError):
+        engine.hed_augment(rgb, sg, sg, skimage_mode=9)
+    with pytest.raises(_ffi.StainlibHipError):
+        engine.slide_key_histogram(rgb, 5, np.zeros(6), (0, 0), 0)                 # unknown key set
+    assert transform() == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out, good)
