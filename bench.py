@@ -268,7 +268,7 @@ def secondary_configs(dev, Mt, mct):
         "ms_per_batch": round(ms, 4), "tiles_per_s": round(128 / ms * 1e3, 1), "dictionary_sweeps_per_tile_mean": float(sw.float().mean()),
         "failed_tiles": int((st != 0).sum()),
         "parity_tile0": {"M_max_abs_err_vs_converged_oracle": float(np.abs(Mg[0].cpu().numpy() - Mo).max()), **_flips(out[0].cpu().numpy(), want)},
-        "note": "latency / issue bound (about 3 dependent full sweeps per tile after the sample stage, ~60 vector instructions per pixel each), not an HBM roofline case"}
+        "note": "latency / issue bound (about 2 dependent full sweeps per tile after the sample stage, ~60 vector instructions per pixel each), not an HBM roofline case"}
     del rgb, out
 
     # ---- configs[3]: 1250 tiles 512^2 per GPU: HedLighterColorAugmenter and StainAugmentor.pop

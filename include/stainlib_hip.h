@@ -110,7 +110,9 @@ typedef struct SlParams {
     double dl_lambda;           /* 0.1  (Vahadane) */
     int32_t dl_max_sweeps;      /* 200  (Vahadane; the reference is wall-clock budgeted) */
     int32_t schedule;           /* 0 = automatic; 1 = one launch per phase; 2 = persistent fused kernel */
-    double dl_tol;              /* 1e-7 max-abs change of the dictionary between sweeps */
+    double dl_tol;              /* 1e-7 the dictionary iteration stops when a full sweep moves D by less than this (max-abs), or
+                                        when the a-posteriori estimate of its distance to the fixed point (the step the next sweep would
+                                        take, predicted from the last two) is below it */
     SlProfile* profile;         /* NULL (default): no timing events */
     int32_t* fallbacks_out;     /* NULL (default) or DEVICE pointer to n ints: per tile, how many of its four order statistics
                                    (two angular, two concentration percentiles) needed the slow exact selection over the whole

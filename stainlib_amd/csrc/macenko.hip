@@ -15,8 +15,9 @@ constexpr size_t kGroupBytes = (size_t)2 << 30;   // uint8 bytes of one tile gro
 
 constexpr int kFusedMinTiles = 448;         // measured crossover (tools/crossover.py): below it one launch per phase wins
 constexpr int kFusedMinTilesSmall = 288;    // ... for tiles below 512 Ki pixels (256x256: 0.18 vs 0.20 ms at 256 tiles, 0.28 vs 0.25 at 384)
-constexpr int kDictFusedMinTiles = 480;     // Vahadane: below it the dictionary sweeps run one launch per phase too (measured: 1024^2 tiles 5.3 vs
-                                            // 6.3 ms at 384, 6.7 vs 6.6 at 512; a fused grid below 512 workgroups leaves slots idle)
+constexpr int kDictFusedMinTiles = 640;     // Vahadane: below it the dictionary sweeps run one launch per phase too (measured: 1024^2 tiles 3.70 vs
+                                            // 3.85 ms at 512, 6.24 vs 5.76 at 768; in a fused launch of one tile per workgroup the few tiles
+                                            // that need a third full sweep hold the whole launch, per phase they cost a short extra launch)
 constexpr int kDictFusedMinTilesSmall = 192;   // ... for tiles below 512 Ki pixels (512^2: 0.82 vs 1.34 ms at 64 tiles, 1.53 vs 1.46 at 256)
 constexpr int kDictFixedSweeps = 4;         // full sweeps launched after the sample stage; tiles that need more finish in k_dict_tail
 

@@ -19,7 +19,7 @@ def _oracle_fit(I):
     return M, np.percentile(C, 99, axis=0), info
 
 
-# both schedules: 1 = one launch per phase (automatic below 480 tiles), 2 = the persistent fused kernel
+# both schedules: 1 = one launch per phase (automatic below 640 tiles), 2 = the persistent fused kernel
 @pytest.mark.parametrize("schedule", [1, 2])
 @pytest.mark.parametrize("h,w", [(96, 96), (128, 160), (33, 47), (32, 40)])   # (32,40): waves without pixels
 def test_vahadane_fit_vs_converged_oracle(h, w, schedule):
@@ -126,10 +126,10 @@ def test_vahadane_schedules_agree():
     tiles[4] = rng.integers(0, 256, (192, 256, 3), dtype=np.uint8)       # no structure at all
     tgt = so.synth_tile(192, 256, 1001, so.M_TRUE_TGT)
     Mt, mct, _, _ = engine.vahadane_fit(to_dev([tgt]))
-    for tol in (1e-7, 1e-12):
+    for tol, cap in ((1e-7, 100), (1e-12, 100), (0.0, 7)):      # (tol 0 never settles: sweeps 5-7 run in the straggler kernel)
         res = []
         for schedule in (1, 2):
-            p = engine.make_params(dl_tol=tol, schedule=schedule)
+            p = engine.make_params(dl_tol=tol, dl_max_sweeps=cap, schedule=schedule)
             M, mc, st, sweeps = engine.vahadane_fit(to_dev(tiles), params=p)
             o, M2, mc2, st2 = engine.vahadane_transform(to_dev(tiles), Mt[0], mct[0], params=p)
             assert torch.equal(st, st2)
@@ -141,8 +141,9 @@ def test_vahadane_schedules_agree():
         np.testing.assert_allclose(a[1], b[1], rtol=1e-6, equal_nan=True)
         d = np.abs(a[4].astype(np.int16) - b[4].astype(np.int16))
         assert d.max() <= 1 and (d != 0).mean() < 1e-4
-        if tol == 1e-12:
-            assert a[3].max() > 4                                          # more than the 4 full-sweep launches: the tail kernel ran
+        if tol == 0.0:
+            ok = a[2] == 0
+            assert (a[3][ok] == 7).all() and (b[3][ok] == 7).all()         # more than the 4 full-sweep launches: the tail kernel ran
 
 
 @pytest.mark.parametrize("max_sweeps", [2, 3, 7])   # (after a single sweep the two atoms are still nearly collinear: the codes are ill-conditioned)
@@ -155,7 +156,29 @@ def test_vahadane_sweep_budget_both_schedules(max_sweeps):
     for schedule in (1, 2):
         p = engine.make_params(dl_tol=1e-14, dl_max_sweeps=max_sweeps, schedule=schedule)
         M, mc, st, sweeps = engine.vahadane_fit(to_dev(tiles), params=p)
-        assert (st.cpu().numpy() == 0).all() and (sweeps.cpu().numpy() == max_sweeps).all()
-        res.append((M.cpu().numpy(), mc.cpu().numpy()))
+        sw = sweeps.cpu().numpy()
+        # (two or three sweeps cannot reach 1e-14; seven can: the iteration is Newton-like and lands on the fixed point of the
+        #  binary32 bursts after four or five, where it stops on its own)
+        assert (st.cpu().numpy() == 0).all() and ((sw == max_sweeps).all() if max_sweeps <= 3 else ((sw >= 4) & (sw <= max_sweeps)).all())
+        swl = res[-1][2] if res else sw
+        assert (sw == swl).all()
+        res.append((M.cpu().numpy(), mc.cpu().numpy(), sw))
     np.testing.assert_allclose(res[0][0], res[1][0], rtol=0, atol=1e-11)
     np.testing.assert_allclose(res[0][1], res[1][1], rtol=1e-6)
+
+
+def test_vahadane_error_stays_within_the_tolerance():
+    """The iteration stops on an a-posteriori estimate of its distance to the fixed point (stats_kernels.hpp: dict_advance),
+    not after a confirming sweep: against the oracle converged to 1e-12 the dictionary error must stay within a few dl_tol
+    (plus the ~3e-8 floor of the binary32 class moments), for loose and tight tolerances, on tiles of two sizes."""
+    from stainlib_amd import engine
+    for size, seeds in ((192, (31, 32, 33, 34)), (512, (41, 42))):
+        tiles = [so.synth_tile(size, size, s) for s in seeds]
+        refs = [so.vahadane_stain_matrix(I, max_sweeps=600, tol=1e-12) for I in tiles]
+        for tol in (1e-4, 1e-5, 1e-6, 1e-7, 1e-9):
+            for schedule in (1, 2):
+                M, mc, st, sweeps = engine.vahadane_fit(to_dev(tiles), params=engine.make_params(dl_tol=tol, schedule=schedule))
+                err = max(float(np.abs(M[i].cpu().numpy() - refs[i]).max()) for i in range(len(tiles)))
+                print(f"size {size} dl_tol {tol:.0e} schedule {schedule}: sweeps {sweeps.cpu().numpy().tolist()} max |dM| {err:.1e}")
+                assert (st.cpu().numpy() == 0).all()
+                assert err <= 3.0 * tol + 1e-7
