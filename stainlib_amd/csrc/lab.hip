@@ -42,9 +42,10 @@ __device__ __forceinline__ int sat8(int v) {
     return v < 0 ? 0 : (v > 255 ? 255 : v);
 }
 
-// OpenCV RGB2Lab_b::operator(): coefficients cvRound(4096 * sRGB2XYZ_D65[i][j] / whitePt[i]), lab_shift 12, lab_shift2 15
-__device__ __forceinline__ void rgb_to_lab8(const LabTabs& t, uint32_t r, uint32_t g, uint32_t b, int& L, int& A, int& B) {
-    const int R = t.gamma[r], G = t.gamma[g], Bc = t.gamma[b];
+// OpenCV RGB2Lab_b::operator(): coefficients cvRound(4096 * sRGB2XYZ_D65[i][j] / whitePt[i]), lab_shift 12, lab_shift2 15.
+// R, G, Bc are the gamma-table values of the three bytes (the sweeps read them from a per-tile table that already
+// contains the brightness table: gamma[lut[v]]).
+__device__ __forceinline__ void gamma_to_lab8(const LabTabs& t, int R, int G, int Bc, int& L, int& A, int& B) {
     const int fX = t.cbrt[(R * 1777 + G * 1541 + Bc * 778 + 2048) >> 12];
     const int fY = t.cbrt[(R * 871 + G * 2929 + Bc * 296 + 2048) >> 12];
     const int fZ = t.cbrt[(R * 73 + G * 448 + Bc * 3575 + 2048) >> 12];
@@ -52,18 +53,25 @@ __device__ __forceinline__ void rgb_to_lab8(const LabTabs& t, uint32_t r, uint32
     A = sat8((500 * (fX - fY) + 128 * 32768 + 16384) >> 15);
     B = sat8((200 * (fY - fZ) + 128 * 32768 + 16384) >> 15);
 }
-
-// OpenCV abToXZ_b[i - minABvalue] evaluated instead of stored (36864 entries): C integer arithmetic, division truncates
-__device__ __forceinline__ int ab_to_xz(int i) {
-    if (i <= 3390) return (i * 108) / 841 - 290;          // 290 = BASE*16/116*108/841
-    return ((i * i) / 16384 * i) / 16384;
+__device__ __forceinline__ void rgb_to_lab8(const LabTabs& t, uint32_t r, uint32_t g, uint32_t b, int& L, int& A, int& B) {
+    gamma_to_lab8(t, t.gamma[r], t.gamma[g], t.gamma[b], L, A, B);
 }
 
-// OpenCV Lab2RGBinteger::process: coefficients cvRound(4096 * XYZ2sRGB_D65[i][j] * whitePt[j]), shift 14
-__device__ __forceinline__ void lab8_to_rgb(const LabTabs& t, int L, int a, int b, uint32_t& r, uint32_t& g, uint32_t& bl) {
-    const int y = t.yf[2 * L], ify = t.yf[2 * L + 1];
-    const int adiv = ((5 * a * 53687 + 128) >> 13) - 4194;          // 128*BASE/500
-    const int bdiv = ((b * 41943 + 16) >> 9) - 10485 + 1;           // 128*BASE/200
+// OpenCV abToXZ_b[i - minABvalue] evaluated instead of stored (36864 entries): C integer arithmetic, division truncates.
+// Both branches are evaluated for every lane; the cubic one only counts for i > 3390, where every operand is positive and
+// the two divisions by 16384 are plain shifts (as signed divisions they cost a sign fix-up each).
+__device__ __forceinline__ int ab_to_xz(int i) {
+    const int lin = (i * 108) / 841 - 290;                // 290 = BASE*16/116*108/841
+    const uint32_t u = (uint32_t)i;                       // (i < 2^17, (i*i) >> 14 < 2^20: 24-bit multiplies, the full-width ones run at quarter rate)
+    const int cub = (int)(__umul24(__umul24(u, u) >> 14, u) >> 14);
+    return i <= 3390 ? lin : cub;
+}
+
+// OpenCV Lab2RGBinteger::process: coefficients cvRound(4096 * XYZ2sRGB_D65[i][j] * whitePt[j]), shift 14.
+// lab_adiv / lab_bdiv: the a and b bytes on the table's scale (128*BASE/500 = 4194, 128*BASE/200 = 10485).
+__device__ __forceinline__ int lab_adiv(int a) { return ((5 * a * 53687 + 128) >> 13) - 4194; }
+__device__ __forceinline__ int lab_bdiv(int b) { return ((b * 41943 + 16) >> 9) - 10485 + 1; }
+__device__ __forceinline__ void yf_to_rgb(const LabTabs& t, int y, int ify, int adiv, int bdiv, uint32_t& r, uint32_t& g, uint32_t& bl) {
     const int x = ab_to_xz(ify + adiv), z = ab_to_xz(ify - bdiv);
     int ro = (12615 * x - 6296 * y - 2223 * z + 8192) >> 14;
     int go = (-3773 * x + 7684 * y + 185 * z + 8192) >> 14;
@@ -72,6 +80,9 @@ __device__ __forceinline__ void lab8_to_rgb(const LabTabs& t, int L, int a, int 
     go = go < 0 ? 0 : (go > 4095 ? 4095 : go);
     bo = bo < 0 ? 0 : (bo > 4095 ? 4095 : bo);
     r = t.invg[ro]; g = t.invg[go]; bl = t.invg[bo];
+}
+__device__ __forceinline__ void lab8_to_rgb(const LabTabs& t, int L, int a, int b, uint32_t& r, uint32_t& g, uint32_t& bl) {
+    yf_to_rgb(t, t.yf[2 * L], t.yf[2 * L + 1], lab_adiv(a), lab_bdiv(b), r, g, bl);
 }
 
 __device__ __forceinline__ Chunk pack12(const uint32_t (&ob)[12]) {
@@ -165,6 +176,7 @@ static __global__ __launch_bounds__(kLabWG) void k_lab_hist(const uint8_t* __res
     __shared__ LabTabs s_t;
     __shared__ uint32_t s_h[kLabWG / 64][256];
     __shared__ uint8_t s_lut[256];
+    __shared__ uint16_t s_g[256];
     __shared__ double s_p;
     __shared__ unsigned long long s_tissue, s_ab[4];
     const int tile = blockIdx.x / parts, part = blockIdx.x % parts, wave = threadIdx.x >> 6;
@@ -173,6 +185,8 @@ static __global__ __launch_bounds__(kLabWG) void k_lab_hist(const uint8_t* __res
     if (threadIdx.x == 0) s_tissue = 0;
     if (threadIdx.x < 4) s_ab[threadIdx.x] = 0;
     fill_brightness_lut(s_lut, sc[tile], standardize, &s_p);
+    for (int v = threadIdx.x; v < 256; v += kLabWG) s_g[v] = s_t.gamma[s_lut[v]];     // brightness table and gamma table in one lookup
+    __syncthreads();
     const int lim = l8_limit(thr);
     const size_t nbytes = (size_t)P * 3;
     const uint8_t* src = rgb + (size_t)tile * nbytes;
@@ -187,7 +201,7 @@ static __global__ __launch_bounds__(kLabWG) void k_lab_hist(const uint8_t* __res
         for (int px = 0; px < 4; ++px) {
             if (!ALIGNED && (size_t)c * 4 + px >= (size_t)P) break;
             int L, A, B;
-            rgb_to_lab8(s_t, s_lut[chunk_byte(in, 3 * px)], s_lut[chunk_byte(in, 3 * px + 1)], s_lut[chunk_byte(in, 3 * px + 2)], L, A, B);
+            gamma_to_lab8(s_t, s_g[chunk_byte(in, 3 * px)], s_g[chunk_byte(in, 3 * px + 1)], s_g[chunk_byte(in, 3 * px + 2)], L, A, B);
             atomicAdd(&s_h[wave][L], 1u);
             sa += (uint32_t)A; saa += (uint32_t)(A * A); sb += (uint32_t)B; sbb += (uint32_t)(B * B);
             n_tissue += L < lim ? 1u : 0u;
@@ -292,7 +306,25 @@ static __global__ __launch_bounds__(kLabWG) void k_lab_map(LabMapArgs a) {
         if (part == 0 && tid == 0 && a.p_out) a.p_out[tile] = s_p;
     }
     __syncthreads();
+    // Per-tile composed tables: one lookup where the pixel path had two or three.  s_g: byte -> gamma value (through the
+    // brightness table in MODE 0); s_yf: L8 -> (y, f(y)) of the MAPPED L byte, packed; s_ad / s_bd: a8 / b8 -> the mapped
+    // byte on abToXZ's scale.
+    __shared__ uint16_t s_g[256];
+    __shared__ uint32_t s_yf[256];
+    __shared__ int s_ad[256], s_bd[256];
+    if (MODE != 2) {
+        const int L2 = s_ch[0][tid], A2 = MODE == 0 ? s_ch[1][tid] : tid, B2 = MODE == 0 ? s_ch[2][tid] : tid;
+        s_g[tid] = MODE == 0 ? s_t.gamma[s_lut[tid]] : s_t.gamma[tid];
+        s_yf[tid] = (uint32_t)s_t.yf[2 * L2] | ((uint32_t)s_t.yf[2 * L2 + 1] << 16);
+        s_ad[tid] = lab_adiv(A2);
+        s_bd[tid] = lab_bdiv(B2);
+    }
+    __syncthreads();
     const int lim = MODE == 0 ? l8_limit(a.thr) : 256;
+    // background (normalizer.py:86-90): 254 + 0 on the L/2.55 scale -> clips to 255; a = b = 0 + 128
+    const uint32_t yf_bg = (uint32_t)s_t.yf[2 * 255] | ((uint32_t)s_t.yf[2 * 255 + 1] << 16);
+    const int ad_bg = lab_adiv(128), bd_bg = lab_bdiv(128);
+    const bool mask_bg = MODE == 0 && a.mask_background;
     const size_t nbytes = (size_t)a.P * 3;
     const uint8_t* src = a.rgb + (size_t)tile * nbytes;
     uint8_t* dst = a.out + (size_t)tile * nbytes;
@@ -310,17 +342,14 @@ static __global__ __launch_bounds__(kLabWG) void k_lab_map(LabMapArgs a) {
                 continue;
             }
             int L, A, B;
-            if (MODE == 0) rgb_to_lab8(s_t, s_lut[r], s_lut[g], s_lut[b], L, A, B);
-            else rgb_to_lab8(s_t, r, g, b, L, A, B);
-            int L2, A2, B2;
-            if (MODE == 0) {
-                // background (normalizer.py:86-90): 254 + 0 on the L/2.55 scale -> clips to 255; a = b = 0 + 128
-                const bool bg = a.mask_background && !(L < lim);
-                L2 = bg ? 255 : s_ch[0][L]; A2 = bg ? 128 : s_ch[1][A]; B2 = bg ? 128 : s_ch[2][B];
-            } else {
-                L2 = s_ch[0][L]; A2 = A; B2 = B;
+            gamma_to_lab8(s_t, s_g[r], s_g[g], s_g[b], L, A, B);
+            uint32_t yf = s_yf[L];
+            int ad = MODE == 0 ? s_ad[A] : lab_adiv(A), bd = MODE == 0 ? s_bd[B] : lab_bdiv(B);     // (MODE 1 leaves a and b alone: three operations each)
+            if (mask_bg) {
+                const bool bg = !(L < lim);
+                yf = bg ? yf_bg : yf; ad = bg ? ad_bg : ad; bd = bg ? bd_bg : bd;
             }
-            lab8_to_rgb(s_t, L2, A2, B2, ob[3 * px], ob[3 * px + 1], ob[3 * px + 2]);
+            yf_to_rgb(s_t, (int)(yf & 0xffffu), (int)(yf >> 16), ad, bd, ob[3 * px], ob[3 * px + 1], ob[3 * px + 2]);
         }
         store_chunk<ALIGNED>(dst, nbytes, c, pack12(ob));
     }
