@@ -660,7 +660,25 @@ def structured_tile(kind: str, h: int, w: int, seed: int) -> np.ndarray:
     """Synthetic tiles WITH spatial structure and colour ties (the i.i.d. generator above has neither):
       white_bg   saturated (255,255,255) background: a band on the left and a disc, ~35 % of the pixels
       palette12  11 tissue colours + white in 4x4 blocks (heavy ties in every order statistic)
-      quantized  colours snapped to multiples of 4 plus 2 (JPEG-like ties), white band on top"""
+      quantized  colours snapped to multiples of 4 plus 2 (JPEG-like ties), white band on top
+      blobs      smooth spatial structure: haematoxylin-rich nuclei (soft-edged discs) on an eosin background that varies
+                 slowly across the tile, a white lumen, little pixel noise -- neighbouring pixels are strongly correlated,
+                 as in a real slide (what a stratified pixel sample has to cope with)"""
+    if kind == "blobs":
+        rng = np.random.RandomState(seed + 104729)
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+        s = float(min(h, w))
+        cH = np.full((h, w), 0.08)
+        for _ in range(60):                                            # nuclei
+            cy, cx, r, a = rng.uniform(0, h), rng.uniform(0, w), rng.uniform(0.015, 0.045) * s, rng.uniform(0.9, 2.2)
+            cH += a / (1.0 + np.exp((np.hypot(yy - cy, xx - cx) - r) / (0.12 * r + 0.5)))
+        cE = 0.55 + 0.35 * np.sin(2 * np.pi * (yy / h + 0.3)) * np.cos(2 * np.pi * (0.7 * xx / w + 0.1)) + 0.25 * (xx / w)
+        cE = np.clip(cE, 0.05, None) * (1.0 - 0.5 * np.clip(cH / 2.0, 0, 1))
+        lumen = ((yy - 0.3 * h) / (0.18 * h)) ** 2 + ((xx - 0.7 * w) / (0.12 * w)) ** 2 < 1.0
+        C = np.stack([cH, cE], axis=-1).reshape(-1, 2)
+        C[lumen.ravel()] *= 0.01
+        OD = C @ normalize_rows(np.asarray(M_TRUE_SRC, dtype=np.float64)) + rng.normal(0.0, 0.004, size=(h * w, 3))
+        return np.clip(255.0 * np.exp(-OD), 0, 255).astype(np.uint8).reshape(h, w, 3)
     base = synth_tile(h, w, seed)
     rng = np.random.RandomState(seed + 7919)
     yy, xx = np.mgrid[0:h, 0:w]

@@ -297,6 +297,7 @@ def main():
     save("macenko_1024_s1", macenko_case(1024, 1))                        # BASELINE configs[1] tile size
     for kind in ("white_bg", "palette12", "quantized"):
         save("macenko_128_%s_s4" % kind, macenko_case(128, 4, kind))
+    save("macenko_256_blobs_s5", macenko_case(256, 5, "blobs"))           # smooth spatial structure (nuclei, gradients, lumen)
     save("hed_512_s4_np5", hed_case(512, 4, 5))                           # BASELINE configs[3] tile size
     save("hed_128_s2_np0", hed_case(128, 2, 0))
     save("hed_128_s3_np123", hed_case(128, 3, 123))
