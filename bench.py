@@ -304,6 +304,31 @@ def secondary_configs(dev, Mt, mct):
         "parity_tile0": _flips(o5[0].cpu().numpy(), orn.transform(I5)), "note": "OpenCV Lab restatement: parity unpinned against cv2 itself"}
     del t5, o5
 
+    # ---- the headline transform on batches that are NOT i.i.d. pixels (the i.i.d. batch is the best case for the sample
+    # brackets): 512 tiles cycled from four structured tiles per kind; rate, exact-fallback count, parity of tile 0
+    Mt_d, mct_d = torch.as_tensor(Mt_np, device=dev), torch.as_tensor(mct_np.reshape(2), device=dev)
+    out = torch.empty((512, 1024, 1024, 3), dtype=torch.uint8, device=dev)
+    wss = engine.Workspace()
+    structured = {}
+    for kind in ("blobs", "white_bg", "quantized"):
+        four = np.stack([so.structured_tile(kind, 1024, 1024, 20 + s) for s in range(4)])
+        rgb = torch.as_tensor(four, device=dev)[torch.arange(512, device=dev) % 4].contiguous()
+        p = engine.make_params()
+        fb = engine.attach_fallbacks(p, 512, device=dev)
+        ms = _timed(lambda: engine.macenko_transform(rgb, Mt_d, mct_d, params=p, out=out, ws=wss), reps=5)
+        o, Mg, mcg, st = engine.macenko_transform(rgb, Mt_d, mct_d, params=p, out=out, ws=wss)
+        on = so.ExtractiveStainNormalizer("macenko")
+        on.stain_matrix_target, on.maxC_target = Mt_np, mct_np.reshape(1, 2)
+        structured[kind] = {"ms_per_batch": round(ms, 4), "tiles_per_s": round(512 / ms * 1e3, 1), "failed_tiles": int((st != 0).sum()),
+                            "exact_fallbacks": int(fb.sum()), "of": 2048, "parity_tile0": _flips(o[0].cpu().numpy(), on.transform(four[0]))}
+        del rgb
+    structured["note"] = ("oracle.structured_tile: 'blobs' = nuclei, slow eosin gradients, a lumen, little noise (neighbouring pixels strongly "
+                          "correlated); 'white_bg' = 35 % saturated background; 'quantized' = JPEG-like colour ties.  A 12-colour palette "
+                          "image (every order statistic inside a run of ties) takes the exact fallback for all of them: 20 k tiles/s, "
+                          "tools/structured_rate.py")
+    sec["configs1_structured_512x1024"] = structured
+    del out
+
     # ---- pooled slide mode (configs[4] on one GPU): 512 tiles; parity on an 8-tile slide against the oracle on the concatenation
     rgb = synth_tiles(512, 1024, 1024, seed=9, device=dev)
     out = torch.empty_like(rgb)
