@@ -324,7 +324,7 @@ def secondary_configs(dev, Mt, mct):
         del rgb
     structured["note"] = ("oracle.structured_tile: 'blobs' = nuclei, slow eosin gradients, a lumen, little noise (neighbouring pixels strongly "
                           "correlated); 'white_bg' = 35 % saturated background; 'quantized' = JPEG-like colour ties.  A 12-colour palette "
-                          "image (every order statistic inside a run of ties) takes the exact fallback for all of them: 20 k tiles/s, "
+                          "image (every order statistic inside a run of ties) leaves the fast path for all of them (one census pass over the tile each): 68 k tiles/s, "
                           "tools/structured_rate.py")
     sec["configs1_structured_512x1024"] = structured
     del out

@@ -1006,6 +1006,31 @@ __device__ __forceinline__ void wg_refine(int n_raw, const Key2& key2, const flo
     __syncthreads();
 }
 
+// One pass over the n keys: how many lie below lo, how many inside [lo, hi], and the smallest and largest of those inside
+// (ordered integers; 0xffffffff / 0 when none).  Ends with a barrier.
+template <class KeyAt>
+__device__ __noinline__ void wg_bracket_census(int n, KeyAt key_at, float lo, float hi, uint32_t& n_below, uint32_t& n_in, uint32_t& omin,
+                                               uint32_t& omax, SelScratch& S) {
+    if (threadIdx.x == 0) { S.misc[4] = 0xffffffffu; S.misc[5] = 0; S.misc[6] = 0; S.misc[7] = 0; }
+    __syncthreads();
+    const uint32_t olo = f2ord(lo), ohi = f2ord(hi);
+    uint32_t mn = 0xffffffffu, mx = 0, nb = 0, ni = 0;
+    wg_for_each_key(n, key_at, [&](uint32_t o) {
+        nb += o < olo ? 1u : 0u;
+        if (o >= olo && o <= ohi) { ++ni; mn = min(mn, o); mx = max(mx, o); }
+    });
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
+        mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+        nb += __shfl_xor((int)nb, o, 64);
+        ni += __shfl_xor((int)ni, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&S.misc[4], mn); atomicMax(&S.misc[5], mx); atomicAdd(&S.misc[6], nb); atomicAdd(&S.misc[7], ni); }
+    __syncthreads();
+    omin = S.misc[4]; omax = S.misc[5]; n_below = S.misc[6]; n_in = S.misc[7];
+    __syncthreads();
+}
+
 // Exact order statistics (k, k+1) of one bracket of a selection stage from the refined lists:
 // lt = pixels proven or found below the bracket, n_in = members collected in cand[].  Falls back to
 // exact selection over the whole tile when the bracket missed or a list was incomplete.
@@ -1021,8 +1046,17 @@ __device__ __forceinline__ void stage_order_stats(const float* cand, uint32_t n_
         wg_select_pair_small((int)n_in, CandKey{cand}, (uint32_t)(k - lt), xa, xb, S);
         if (k2 == k) xb = xa;
     } else {                                           // exact, slow, rare
-        wg_select_pair(P, tile_key_at, (uint32_t)k, xa, xb, S);
-        if (k2 == k) xb = xa;
+        // Mostly this is a run of ties (few-colour images: more equal keys than the lists hold).  One census pass over the
+        // tile settles that case: if every key inside the bracket is the same value and both ranks fall on it, that value
+        // is the answer; only otherwise the windowed selection (about six more passes) runs.
+        uint32_t n_below, n_in_all, omin, omax;
+        wg_bracket_census(P, tile_key_at, lo, hi, n_below, n_in_all, omin, omax, S);
+        if (n_in_all > 0 && omin == omax && k >= (long long)n_below && k2 < (long long)n_below + (long long)n_in_all) {
+            xa = xb = ord2f(omin);
+        } else {
+            wg_select_pair(P, tile_key_at, (uint32_t)k, xa, xb, S);
+            if (k2 == k) xb = xa;
+        }
         fallbacks += 1;
     }
 }
