@@ -215,9 +215,15 @@ class HipEvents:
             self.hip.hipEventDestroy(self.ev[i])
 
 
-def _timed(fn, reps=10, warm=2):
-    """ms per call of fn() on torch's current stream (torch events: the stream the engine launches on)."""
+def _timed(fn, reps=10, warm=2, spin_up_ms=60.0):
+    """ms per call of fn() on torch's current stream (torch events: the stream the engine launches on).  The calls before the
+    timed ones last at least spin_up_ms: the GPU clocks drop during the host-side parity checks between two configs."""
+    import time
     import torch
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < spin_up_ms:
+        fn()
+        torch.cuda.synchronize()
     for _ in range(warm):
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -463,6 +469,16 @@ def main():
     def step(p):
         return engine.macenko_transform(rgb, Mt, mct, params=p, out=out, ws=ws)
 
+    # The GPU's clocks take ~25 ms of sustained load to come up after the idle seconds of the host-side setup above (the same
+    # launch: 2.6 ms cold, 1.94 ms from the twelfth on): bring them up first, then do the W warm-up steps the contract asks for.
+    # The timed region is still exactly K steps.
+    PREWARM_MS = 120.0
+    n_prewarm = 0
+    tp = time.perf_counter()
+    while (time.perf_counter() - tp) * 1e3 < PREWARM_MS:
+        step(params)
+        torch.cuda.synchronize()
+        n_prewarm += 1
     for _ in range(a.warmup):
         step(params)
     torch.cuda.synchronize()
@@ -622,6 +638,8 @@ def main():
             "config": {"workload": f"configs[1]: batch of {B} tiles {h}x{w}x3 uint8 per GPU, Macenko transform "
                                    "(fit once outside the timed region), tiles resident in HBM",
                        "tiles_per_gpu": B, "tile": [h, w, 3], "sharding": f"independent tiles x{world}, no data-path collective",
+                       "clock_spin_up": f"{n_prewarm} untimed launches ({PREWARM_MS:.0f} ms) before the {a.warmup} warm-up steps: after the idle "
+                                        "seconds of the host-side setup the first ~12 launches run at ramping clocks (2.6 -> 1.94 ms)",
                        "failed_tiles": n_bad},
             "arithmetic": "per-pixel arithmetic binary32 (optical-density table, lasso, exp2, truncating pack); moment sums, eigen-solve, "
                           "percentile interpolation, trigonometry and per-tile constants binary64; order statistics exact on binary32 keys. "
