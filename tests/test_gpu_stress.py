@@ -20,3 +20,45 @@ def test_random_cases_agree_across_schedules(seed, cases, method):
     assert r.returncode == 0, tail + r.stderr[-2000:]
     assert "mismatching cases: 0" in r.stdout, tail
     assert r.stdout.count(" OK") >= cases
+
+
+def test_random_small_tiles_against_the_oracle():
+    """Random shapes (ragged, down to a few rows), contents (i.i.d., white background, quantised, spatially smooth) and extractor
+    parameters: stain matrix, 99th-percentile concentrations and output bytes of the Macenko transform against the ORACLE (the
+    cross-schedule run above cannot see an error both schedules share).  Tiles whose statistics are ill-conditioned (fewer
+    than ~200 tissue pixels: one pixel moves a percentile) are drawn again."""
+    import numpy as np
+    import torch
+    from oracle import stain_oracle as so
+    from stainlib_amd import engine
+    from tests.gpu_util import to_dev, u8_parity
+    rng = np.random.RandomState(2024)
+    tgt = so.synth_tile(96, 96, 1001, so.M_TRUE_TGT)
+    Mt = so.macenko_stain_matrix(tgt)
+    mct = np.percentile(so.get_concentrations(tgt, Mt), 99, axis=0)
+    done = 0
+    while done < 24:
+        h, w = int(rng.randint(6, 220)), int(rng.randint(8, 260))
+        kind = rng.choice(["iid", "white_bg", "quantized", "blobs"])
+        seed = int(rng.randint(1 << 20))
+        I = so.synth_tile(h, w, seed) if kind == "iid" else so.structured_tile(kind, h, w, seed)
+        thr, pct = float(rng.choice([0.8, 0.8, 0.7, 0.9])), float(rng.choice([99.0, 99.0, 95.0, 99.5]))
+        try:
+            if int(so.tissue_mask(I, thr).sum()) < 200:
+                continue
+            Mo = so.macenko_stain_matrix(I, thr, pct)
+        except so.TissueMaskException:
+            continue
+        Co = so.get_concentrations(I, Mo)
+        mco = np.percentile(Co, 99, axis=0)
+        if not (mco > 1e-3).all():
+            continue
+        p = engine.make_params(luminosity_threshold=thr, angular_percentile=pct, schedule=int(rng.choice([1, 2])))
+        out, M, mc, st = engine.macenko_transform(to_dev([I]), torch.as_tensor(Mt, device="cuda"), torch.as_tensor(mct, device="cuda"), params=p)
+        label = f"{kind} {h}x{w} seed {seed} thr {thr} pct {pct} schedule {p.schedule}"
+        assert int(st[0]) == 0, label
+        np.testing.assert_allclose(M.cpu().numpy()[0], Mo, rtol=0, atol=5e-6, err_msg=label)
+        np.testing.assert_allclose(mc.cpu().numpy()[0], mco, rtol=5e-6, err_msg=label)
+        want = so.truncate_u8(255 * np.exp(-(Co * (mct / mco)) @ Mt)).reshape(I.shape)
+        u8_parity(out.cpu().numpy()[0], want, label=label)
+        done += 1
