@@ -50,6 +50,7 @@ done
 python tools/make_pmc_traffic.py "$tag" "$out" > "$out/${tag}_pmc_traffic.json" 2> /dev/null
 # configs[4] at one GPU's shard size, the Lab family's kernels
 python tools/slide_scale.py 512,2048,12500 2>/dev/null | grep -v amdgpu > "$out/${tag}_slide_scale.txt"
+timeout 200 python tools/power_classes.py 2>/dev/null | grep -v amdgpu > "$out/${tag}_power_classes.txt"
 python tools/structured_rate.py 2>/dev/null | grep -v amdgpu > "$out/${tag}_structured_rate.txt"
 rm -rf /tmp/kl; timeout 300 rocprofv3 --kernel-trace -d /tmp/kl -o p -- python tools/run_lab.py > /dev/null 2>&1
 python tools/rocpd_stats.py "$(ls /tmp/kl/*/*.db /tmp/kl/*.db 2>/dev/null | head -1)" 2>&1 | grep -v "at::native\|rocclr\|Cijk" > "$out/${tag}_kernel_stats_lab.md"
