@@ -15,7 +15,7 @@ python tools/phase_classes.py 1024 2>/dev/null | grep "^size" > "$out/${tag}_pha
 python tools/bench_pipeline.py 2>/dev/null | tail -3 > "$out/${tag}_pipeline.txt"
 # rocprofv3 kernel trace of the same bench command (no CPU baseline / secondary: the trace is about the headline kernels)
 rm -rf /tmp/kt; timeout 600 rocprofv3 --kernel-trace -d /tmp/kt -o p -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary > /dev/null 2>&1
-python tools/rocpd_stats.py "$(ls /tmp/kt/*/*.db /tmp/kt/*.db 2>/dev/null | head -1)" > "$out/${tag}_kernel_stats.md" 2>&1
+python tools/rocpd_stats.py "$(ls /tmp/kt/*/*.db /tmp/kt/*.db 2>/dev/null | head -1)" --last 20 "k_fused<0, true" > "$out/${tag}_kernel_stats.md" 2>&1
 # Vahadane, 128 tiles (BASELINE configs[2]) and 512 tiles: per-kernel times
 cat > /tmp/vah.py <<'PY'
 import sys, torch

@@ -19,3 +19,14 @@ for r in rows:
     name = r[0] if len(r[0]) < 110 else r[0][:107] + "..."
     print(f"| `{name}` | {r[1]} | {r[2] / 1e6:.3f} | {r[3] / 1e3:.2f} | {r[4] / 1e3:.2f} | {r[5] / 1e3:.2f} | {100 * r[2] / tot:.1f} | "
           f"{r[6]} | {r[7]} | {r[8]} | {r[9]} | {r[10]} | {r[11]} | {r[12]} |")
+
+# optional: --last N substring  -> the mean over the last N launches of the kernels whose name contains `substring`
+# (bench.py's timed region is its last K launches: the launches before them bring the clocks up and warm up)
+if "--last" in sys.argv:
+    i = sys.argv.index("--last")
+    n_last, sub = int(sys.argv[i + 1]), sys.argv[i + 2]
+    d = [r[0] for r in cur.execute("select duration from kernels where name like ? order by start", (f"%{sub}%",)).fetchall()]
+    if d:
+        tail = d[-n_last:]
+        print(f"\nlast {len(tail)} of {len(d)} launches of `*{sub}*`: avg {sum(tail) / len(tail) / 1e3:.2f} us, min {min(tail) / 1e3:.2f}, max {max(tail) / 1e3:.2f} "
+              f"(the {len(d) - len(tail)} before them: avg {sum(d[:-n_last]) / max(1, len(d) - len(tail)) / 1e3:.2f} us -- clock spin-up and warm-up launches)")
