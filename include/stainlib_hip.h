@@ -118,6 +118,11 @@ typedef struct SlParams {
                                    (two angular, two concentration percentiles) needed the slow exact selection over the whole
                                    tile because the sampled bracket missed or its candidate list overflowed (diagnostics;
                                    results never depend on it).  Written by sl_macenko_* / sl_vahadane_*. */
+    int32_t* resweeps_out;      /* NULL (default) or DEVICE pointer to n ints: 1 for a tile whose concentration percentiles needed a
+                                   selection sweep of their own (the persistent Macenko kernel collects the angular and the
+                                   concentration candidates in ONE sweep under a sample estimate of the stain matrix and repeats
+                                   the concentration part when the exact matrix falls outside the assumed box; diagnostics).
+                                   Written by the fused schedule of sl_macenko_*; left untouched otherwise. */
 } SlParams;
 
 SL_API int sl_version(void);

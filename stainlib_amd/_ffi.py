@@ -42,6 +42,7 @@ class SlParams(C.Structure):
         ("dl_tol", C.c_double),
         ("profile", C.POINTER(SlProfile)),
         ("fallbacks_out", C.c_void_p),
+        ("resweeps_out", C.c_void_p),
     ]
 
 

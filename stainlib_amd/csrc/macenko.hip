@@ -68,8 +68,9 @@ Layout make_layout(int n, long P, int method = kMethodMacenko, int schedule = 0)
     L.off_diag = o;     o = align_up(o + sizeof(int32_t) * (size_t)n);
     L.off_partials = o; o = align_up(o + sizeof(double) * 32 * (size_t)L.parts * L.G);     // 10 (Macenko) / 32 (Vahadane) per item
     L.off_sample = o;   o = align_up(o + sizeof(uint32_t) * (size_t)L.n_sample * slots);
-    // list capacities scale with the tile: ~3 % of the pixels are raw candidates, ~1 % end up in a bracket
-    L.cap_raw = (int)(P / 12 > kMinCapRaw ? P / 12 : kMinCapRaw);
+    // list capacities scale with the tile: ~7 % of the pixels are raw candidates of the merged selection sweep (angle ~2.5 %,
+    // concentrations ~4.5 %), ~1 % end up in a bracket
+    L.cap_raw = (int)(P / 8 > kMinCapRaw ? P / 8 : kMinCapRaw);
     L.cap_list = (int)(P / 40 > kMinCapList ? P / 40 : kMinCapList);
     L.off_cand = o;     o = align_up(o + sizeof(uint32_t) * (size_t)L.cap_raw * slots);
     L.off_list = o;     o = align_up(o + sizeof(float) * 2 * (size_t)L.cap_list * slots);
@@ -203,6 +204,7 @@ int run_fused(int method, const uint8_t* rgb, uint8_t* out, int n, long P, const
     a.maxC_out = maxC_all;
     a.status_out = status_all;
     a.diag_out = p.fallbacks_out ? p.fallbacks_out : (int32_t*)(ws + L.off_diag);
+    a.resweep_out = p.resweeps_out;
 #ifdef SL_DEVTOOLS
     a.phase_clock = g_phase_clock;
     a.debug_stop = g_debug_stop;

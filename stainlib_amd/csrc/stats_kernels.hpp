@@ -252,8 +252,12 @@ __device__ __forceinline__ void wg_for_each_key(int n, const KeyAt& key_at, Fn f
 // Exact 0-based k-th smallest of the n keys key_at(i) (NaN = absent).  count_le = #keys <= result,
 // n_valid = #non-NaN keys.  Narrowing windows in the ordered-integer domain: each pass histograms
 // the live window into <= 1024 bins, so a pass contends on LDS atomics only under real ties.
+// (results come back by value: a reference to a caller's local would reach this out-of-line function as a generic pointer to
+//  private memory, and this hipcc mis-folds the null check of that cast into an illegal v_cmp with src_private_base)
+struct SelResult { float x; uint32_t count_le, n_valid; };
 template <class KeyAt>
-__device__ __noinline__ float wg_select(int n, KeyAt key_at, uint32_t k, uint32_t& count_le, uint32_t& n_valid, SelScratch& S) {
+__device__ __noinline__ SelResult wg_select(int n, KeyAt key_at, uint32_t k, SelScratch& S) {
+    uint32_t count_le = 0, n_valid = 0;
     // pass 0: window = [min, max]
     if (threadIdx.x == 0) { S.misc[4] = 0xffffffffu; S.misc[5] = 0; S.misc[6] = 0; }
     __syncthreads();
@@ -271,7 +275,7 @@ __device__ __noinline__ float wg_select(int n, KeyAt key_at, uint32_t k, uint32_
     uint32_t wlo = S.misc[4], whi = S.misc[5];
     n_valid = S.misc[6];
     __syncthreads();
-    if (n_valid == 0) { count_le = 0; return nan_f(); }
+    if (n_valid == 0) return SelResult{nan_f(), 0u, 0u};
     if (k >= n_valid) k = n_valid - 1;
     uint32_t below = 0, in_win = n_valid;
     for (int guard = 0; guard < 8; ++guard) {
@@ -297,7 +301,7 @@ __device__ __noinline__ float wg_select(int n, KeyAt key_at, uint32_t k, uint32_
         if (s == 0) break;
     }
     count_le = below + in_win;
-    return ord2f(wlo);
+    return SelResult{ord2f(wlo), count_le, n_valid};
 }
 
 // smallest key strictly greater than v (v itself if none)
@@ -319,9 +323,9 @@ __device__ __noinline__ float wg_next_above(int n, KeyAt key_at, float v, SelScr
 // order statistics k and k2 = min(k+1, n_valid-1)
 template <class KeyAt>
 __device__ void wg_select_pair(int n, KeyAt key_at, uint32_t k, float& xa, float& xb, SelScratch& S) {
-    uint32_t cle, nv;
-    xa = wg_select(n, key_at, k, cle, nv, S);
-    xb = (k + 1 < cle || k + 1 >= nv) ? xa : wg_next_above(n, key_at, xa, S);
+    const SelResult r = wg_select(n, key_at, k, S);
+    xa = r.x;
+    xb = (k + 1 < r.count_le || k + 1 >= r.n_valid) ? xa : wg_next_above(n, key_at, xa, S);
 }
 
 // min / max / count of the valid keys (ordered-integer domain)
@@ -649,6 +653,187 @@ __device__ __forceinline__ void stain_matrix_from_angles(const double* Vd, const
 }
 
 // ------------------------------------------------------------------------------------------
+// ONE selection sweep for the angular AND the concentration percentiles (round 3)
+// ------------------------------------------------------------------------------------------
+// normalizer.py:45-47 computes the concentrations with the tile's own stain matrix M, and M is exact only once the angular
+// order statistics are (macenko_stain_extractor.py:33-37): that dependency cost a whole sweep (collect angle candidates,
+// finish, collect concentration candidates).  Both selection sweeps only PROVE pixels plain and append the rest as raw RGB
+// whose exact keys the finish step evaluates, so the concentration test can run before M is known, against every M the
+// sample leaves possible:
+//   * the sample's angular brackets [lo, hi] bound the two percentile angles; a box of kBoxFrac of their width around
+//     the mid-points (about +-3.6 sigma of the sample rank) is where the exact angles will fall in all but ~1e-3 of the tiles;
+//   * for M in that box the interior solution of a pixel is a(M; x) = T a(M~; x) + r with M~ the box centre (the rows of
+//     G^-1 M always span the plane of V, so T is 2x2).  |T - I| <= eps and |r| <= rho over the box (nine grid points,
+//     inflated) give  a_i(M; x) <= a~_i + eps_i (|a~_1| + |a~_2|) + rho_i  for every pixel;
+//   * c_i <= max(0, a_i) when g12 >= 0, so  a~_i + eps_i (|a~_1| + |a~_2|) < L_i - rho_i  for both stains proves both
+//     concentrations below their brackets [L_i, H_i] (the sample's brackets under M~, widened by the same bound);
+//   * a~ = u t + k~ costs four FMAs on the two projections t = V^T od the angle test needs anyway.
+// After the sweep the finish step computes the exact M, then CHECKS the assumption: T(M), r(M) against the eps, rho the sweep
+// used (merged_verify).  If it holds, every uncollected pixel is proven below both brackets under the exact M and the exact
+// keys of the collected ones complete the counts; if it does not (or a bracket missed, or a list overflowed) the tile takes
+// sweep 3 of the four-sweep schedule with brackets from the exact M.  Results never depend on the box, the sample or the
+// pre-filter: the order statistics are exact on the same binary32 keys either way.
+constexpr double kBoxFrac = 0.6;        // box half-width as a fraction of the 6-sigma bracket half-width
+constexpr double kBoxInflate = 1.25;    // safety factor on the nine-point maxima (curvature inside the box)
+constexpr double kBoxMaxEps = 0.25;     // a box over which the map changes by more than this is not worth a merged sweep
+
+struct LassoD { double W[2][3], k[2], g12; };          // a(M; x) = W x + k, binary64 (lasso_consts' interior solution)
+__device__ __forceinline__ void lasso_affine_d(const double* M, double lam, LassoD& o) {
+    const double g11 = M[0] * M[0] + M[1] * M[1] + M[2] * M[2];
+    const double g22 = M[3] * M[3] + M[4] * M[4] + M[5] * M[5];
+    const double g12 = M[0] * M[3] + M[1] * M[4] + M[2] * M[5];
+    const double det = g11 * g22 - g12 * g12;
+    const double i11 = g22 / det, i12 = -g12 / det, i22 = g11 / det;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        o.W[0][c] = i11 * M[c] + i12 * M[3 + c];
+        o.W[1][c] = i12 * M[c] + i22 * M[3 + c];
+    }
+    o.k[0] = -lam * (i11 + i12);
+    o.k[1] = -lam * (i12 + i22);
+    o.g12 = g12;
+}
+// T (2x2), r with  A.W x + A.k = T (C.W x + C.k) + r  for every x (least squares over the rows; exact when the rows of both
+// maps span the same plane)
+__device__ __forceinline__ void relate_affine(const LassoD& A, const LassoD& C, double (&T)[2][2], double (&r)[2]) {
+    double g[2][2], b[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            g[i][j] = C.W[i][0] * C.W[j][0] + C.W[i][1] * C.W[j][1] + C.W[i][2] * C.W[j][2];
+            b[i][j] = A.W[i][0] * C.W[j][0] + A.W[i][1] * C.W[j][1] + A.W[i][2] * C.W[j][2];
+        }
+    const double rd = 1.0 / (g[0][0] * g[1][1] - g[0][1] * g[1][0]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        T[i][0] = (b[i][0] * g[1][1] - b[i][1] * g[1][0]) * rd;
+        T[i][1] = (b[i][1] * g[0][0] - b[i][0] * g[0][1]) * rd;
+        r[i] = A.k[i] - T[i][0] * C.k[0] - T[i][1] * C.k[1];
+    }
+}
+// the stain matrix of two percentile angles (macenko_stain_extractor.py:36-44), one lane
+__device__ __forceinline__ void stain_matrix_from_phi(const double* Vd, double phi_min, double phi_max, double* M) {
+    double s1, c1, s2, c2;
+    sincos(phi_min, &s1, &c1);
+    sincos(phi_max, &s2, &c2);
+    double v1[3], v2[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        v1[c] = Vd[c * 2] * c1 + Vd[c * 2 + 1] * s1;
+        v2[c] = Vd[c * 2] * c2 + Vd[c * 2 + 1] * s2;
+    }
+    const bool first = v1[0] > v2[0];
+    double h[3], e[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { h[c] = first ? v1[c] : v2[c]; e[c] = first ? v2[c] : v1[c]; }
+    const double nh = sqrt(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]);
+    const double ne = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { M[c] = h[c] / nh; M[3 + c] = e[c] / ne; }
+}
+
+struct MergedConc {
+    int ok;                    // the merged sweep collects concentration candidates for this tile
+    int pad_;
+    float u[2][2], kt[2];      // a~_i = u[i][0] t0 + u[i][1] t1 + kt[i],  t = Vf^T od
+    float eps[2], thr[2];      // plain_i <=> a~_i + eps[i] (|a~_1| + |a~_2|) < thr[i]
+    float L[2], H[2];          // brackets of the exact concentration keys
+    double rho[2], eta[2];     // rho: bound on |r| + eta over the box; eta: rounding allowance of the binary32 evaluations
+    LassoD C;                  // the box centre's map, binary64
+    LassoK Lc;                 // the box centre's lasso constants (sample keys)
+};
+
+// Called by one whole wave after the angular brackets are known: lanes 0..8 evaluate the 3 x 3 grid of the box.
+__device__ __forceinline__ void merged_box(const double* Vd, const float* lo, const float* hi, double lam, int lane, MergedConc& mk) {
+    const bool finite = (lo[0] > -INFINITY) & (hi[0] < INFINITY) & (lo[1] > -INFINITY) & (hi[1] < INFINITY);
+    const int i0 = lane % 3, i1 = (lane / 3) % 3;
+    const double m0 = 0.5 * ((double)lo[0] + (double)hi[0]), r0 = kBoxFrac * 0.5 * ((double)hi[0] - (double)lo[0]);
+    const double m1 = 0.5 * ((double)lo[1] + (double)hi[1]), r1 = kBoxFrac * 0.5 * ((double)hi[1] - (double)lo[1]);
+    const double p0 = finite ? m0 + (double)(i0 - 1) * r0 : -0.25;
+    const double p1 = finite ? m1 + (double)(i1 - 1) * r1 : 0.25;
+    double M[6];
+    stain_matrix_from_phi(Vd, angle_of_pseudo(p0), angle_of_pseudo(p1), M);
+    LassoD A, C;
+    lasso_affine_d(M, lam, A);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) C.W[i][c] = __shfl(A.W[i][c], 4, 64);
+        C.k[i] = __shfl(A.k[i], 4, 64);
+    }
+    C.g12 = __shfl(A.g12, 4, 64);
+    double Mc[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) Mc[i] = __shfl(M[i], 4, 64);
+    double T[2][2], r[2];
+    relate_affine(A, C, T, r);
+    double e0 = fmax(fabs(T[0][0] - 1.0), fabs(T[0][1])), e1 = fmax(fabs(T[1][1] - 1.0), fabs(T[1][0]));
+    double q0 = fabs(r[0]), q1 = fabs(r[1]);
+    const bool lane_bad = (lane < 9) & !((e0 <= kBoxMaxEps) & (e1 <= kBoxMaxEps) & (q0 <= 1.0) & (q1 <= 1.0) & (A.g12 >= 0.0));
+    const bool any_bad = __ballot(lane_bad) != 0ull;
+    if (lane >= 9 || lane_bad) e0 = e1 = q0 = q1 = 0.0;
+    for (int o = 8; o > 0; o >>= 1) {
+        e0 = fmax(e0, __shfl_xor(e0, o, 64)); e1 = fmax(e1, __shfl_xor(e1, o, 64));
+        q0 = fmax(q0, __shfl_xor(q0, o, 64)); q1 = fmax(q1, __shfl_xor(q1, o, 64));
+    }
+    if (lane == 0) {
+        mk.ok = (finite && !any_bad) ? 1 : 0;
+        mk.pad_ = 0;
+        mk.C = C;
+        LassoK Lc;
+        lasso_consts(Mc, lam, Lc);
+        mk.Lc = Lc;
+        const double e[2] = {e0, e1}, q[2] = {q0, q1};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) mk.u[i][k] = (float)(C.W[i][0] * Vd[k] + C.W[i][1] * Vd[2 + k] + C.W[i][2] * Vd[4 + k]);
+            mk.kt[i] = (float)C.k[i];
+            mk.eta[i] = 4e-6 * (kOdMax * (fabs(C.W[i][0]) + fabs(C.W[i][1]) + fabs(C.W[i][2])) + fabs(C.k[i]) + 1.0);
+            mk.eps[i] = (float)(kBoxInflate * e[i] + 1e-7);
+            mk.rho[i] = kBoxInflate * q[i] + mk.eta[i];
+        }
+    }
+}
+// thread 0, after the sample's concentration brackets [lo, hi] under the box centre are known
+__device__ __forceinline__ void merged_thresholds(MergedConc& mk, float lo0, float lo1, float hi0, float hi1) {
+    const float lo[2] = {lo0, lo1}, hi[2] = {hi0, hi1};
+    bool ok = mk.ok != 0;
+    float ref[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) ref[i] = hi[i] < INFINITY ? hi[i] : 2.0f * lo[i] + 1.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float delta = mk.eps[i] * (ref[i] + 1.5f * ref[1 - i]) + (float)mk.rho[i];
+        mk.L[i] = lo[i] - delta;
+        mk.H[i] = hi[i] + delta;
+        ok = ok & (mk.L[i] > 0.0f) & (lo[i] > -INFINITY);
+        mk.thr[i] = mk.L[i] - (float)mk.rho[i] - 1e-6f * fabsf(mk.L[i]);
+    }
+    if (!ok) {
+        mk.ok = 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { mk.u[i][0] = mk.u[i][1] = mk.kt[i] = mk.eps[i] = 0.0f; mk.thr[i] = INFINITY; mk.L[i] = mk.H[i] = INFINITY; }
+    }
+}
+// thread 0, with the exact stain matrix: do the bounds the sweep relied on hold?
+__device__ __forceinline__ bool merged_verify(const MergedConc& mk, const double* M, double lam) {
+    if (!mk.ok) return false;
+    LassoD A;
+    lasso_affine_d(M, lam, A);
+    double T[2][2], r[2];
+    relate_affine(A, mk.C, T, r);
+    bool ok = A.g12 >= 0.0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const double e = fmax(fabs(T[i][i] - 1.0), fabs(T[i][1 - i]));
+        ok = ok & (e <= (double)mk.eps[i]) & (fabs(r[i]) + mk.eta[i] <= mk.rho[i]);
+    }
+    return ok;
+}
+
+// ------------------------------------------------------------------------------------------
 // per-pixel bodies shared by both schedules
 // ------------------------------------------------------------------------------------------
 struct Moments {
@@ -766,12 +951,14 @@ __device__ __forceinline__ void moments_sweep_b(const uint8_t* src, int P, int c
     if (cb < c1) trip(std::true_type{}, cb);                    // at most one ragged trip per wave
 }
 
-enum { kStageAngle = 0, kStageConc = 1 };
+enum { kStageAngle = 0, kStageConc = 1, kStageMerged = 2 };
 
 struct SelConsts {          // everything VGPR-resident (in_vgpr)
     float V[6];
     LassoK L;
     float lo0, hi0, lo1, hi1;
+    // merged stage (see MergedConc): at_i = u[i][0] t0 + u[i][1] t1 + kt[i] with t = V^T od; plain <=> at_i + eps[i] (|at_1| + |at_2|) < thr[i]
+    float u[2][2], kt[2], eps[2], thr[2];
 };
 
 // Sweeps 2/3.  The sweep does NOT evaluate the selection keys of every pixel.  A cheap conservative
@@ -787,6 +974,7 @@ struct SelConsts {          // everything VGPR-resident (in_vgpr)
 template <int STAGE> struct SelGather;
 template <> struct SelGather<kStageAngle> { float2 v[12]; };      // {gamma, od32} per byte
 template <> struct SelGather<kStageConc> { float v[12]; };        // od32 per byte
+template <> struct SelGather<kStageMerged> { float2 v[12]; };
 
 template <int STAGE, bool ALIGNED, int kTrip, bool STREAM = false, class TR, class Sink>
 __device__ __forceinline__ void select_sweep(const uint8_t* src, int P, int c0, int c1, int t, int nthreads,
@@ -803,7 +991,7 @@ __device__ __forceinline__ void select_sweep(const uint8_t* src, int P, int c0, 
         SelGather<STAGE> g;
 #pragma unroll
         for (int i = 0; i < 12; ++i) {
-            if constexpr (STAGE == kStageAngle) g.v[i] = T.gam_odf(T.addr(ch, i));
+            if constexpr (STAGE != kStageConc) g.v[i] = T.gam_odf(T.addr(ch, i));
             else g.v[i] = T.odf(T.addr(ch, i));
         }
         return g;
@@ -823,6 +1011,22 @@ __device__ __forceinline__ void select_sweep(const uint8_t* src, int P, int c0, 
                 const float t0 = fmaf(nhi0m, d, y), t1 = fmaf(nlo1m, d, y);
                 const bool pp = fminf(fminf(x, t0), -t1) > 0.0f;             // x > 0, y > hi0m d, y < lo1m d
                 m = __builtin_amdgcn_ballot_w64(tc) & ~__builtin_amdgcn_ballot_w64(pp);
+            } else if constexpr (STAGE == kStageMerged) {
+                // the angle test of sweep 2 and, from the same two projections, a conservative test on the concentrations
+                // under a stain matrix that is only known to lie in a box around its sample estimate (MergedConc)
+                const float2 er = g.v[3 * px], eg = g.v[3 * px + 1], eb = g.v[3 * px + 2];
+                const bool tc = is_tissue_f(er.x, eg.x, eb.x, ylimf);
+                const float x = fmaf(K.V[4], eb.y, fmaf(K.V[2], eg.y, K.V[0] * er.y));
+                const float y = fmaf(K.V[5], eb.y, fmaf(K.V[3], eg.y, K.V[1] * er.y));
+                const float d = x + fabsf(y);
+                const float t0 = fmaf(nhi0m, d, y), t1 = fmaf(nlo1m, d, y);
+                const bool pp = fminf(fminf(x, t0), -t1) > 0.0f;
+                const float a1 = fmaf(K.u[0][1], y, fmaf(K.u[0][0], x, K.kt[0]));
+                const float a2 = fmaf(K.u[1][1], y, fmaf(K.u[1][0], x, K.kt[1]));
+                const float sa = fabsf(a1) + fabsf(a2);
+                const bool g1 = fmaf(K.eps[0], sa, a1) >= K.thr[0], g2 = fmaf(K.eps[1], sa, a2) >= K.thr[1];
+                m = (__builtin_amdgcn_ballot_w64(tc) & ~__builtin_amdgcn_ballot_w64(pp)) | __builtin_amdgcn_ballot_w64(g1) |
+                    __builtin_amdgcn_ballot_w64(g2);
             } else {
                 float a1, a2;
                 lasso_interior(K.L, g.v[3 * px], g.v[3 * px + 1], g.v[3 * px + 2], a1, a2);
@@ -930,6 +1134,18 @@ struct RawAngleKey2 {                 // one pseudo-angle serves both brackets; 
         k0 = k1 = angle_key(V, tab.odf(s & 255u), tab.odf((s >> 8) & 255u), tab.odf((s >> 16) & 255u));
     }
 };
+// the same when the raw list also holds pixels the merged sweep collected for their concentrations: those may be background
+// (NaN: no angle key)
+struct RawAngleKeyT {
+    const uint32_t* raw; TabView tab; float V[6]; float ylimf;
+    __device__ __forceinline__ void operator()(int i, float& k0, float& k1) const {
+        const uint32_t s = raw[i];
+        const uint32_t r = s & 255u, g = (s >> 8) & 255u, b = (s >> 16) & 255u;
+        const bool tissue = is_tissue_f(tab.gam(r), tab.gam(g), tab.gam(b), ylimf);
+        const float k = angle_key(V, tab.odf(r), tab.odf(g), tab.odf(b));
+        k0 = k1 = tissue ? k : nan_f();
+    }
+};
 struct RawConcKey2 {
     const uint32_t* raw; TabView tab; LassoK L;
     __device__ __forceinline__ void operator()(int i, float& k0, float& k1) const {
@@ -949,11 +1165,12 @@ struct CandKey {
 template <class Key2>
 __device__ __forceinline__ void wg_refine(int n_raw, const Key2& key2, const float* lo, const float* hi, float* cand0,
                                           float* cand1, uint32_t cap_list, uint32_t* n_lt /*[2]*/, uint32_t* n_in /*[2]*/,
-                                          SelScratch& S) {
+                                          SelScratch& S, uint32_t* n_valid = nullptr /* entries whose first key is not NaN */) {
     if (threadIdx.x < 4) S.misc[12 + threadIdx.x] = 0;
+    if (threadIdx.x == 4) S.misc[8] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    uint32_t lt0 = 0, lt1 = 0;
+    uint32_t lt0 = 0, lt1 = 0, nv = 0;
     constexpr int U = 4;                                            // entries per lane and trip: one list-head update per trip (8: slower)
     const int step = (int)blockDim.x * U;
     for (int i0 = (int)(threadIdx.x - lane) * U; i0 < n_raw; i0 += step) {      // wave-uniform trip count
@@ -970,6 +1187,7 @@ __device__ __forceinline__ void wg_refine(int n_raw, const Key2& key2, const flo
         for (int u = 0; u < U; ++u) {
             lt0 += k0[u] < lo[0] ? 1u : 0u;
             lt1 += k1[u] < lo[1] ? 1u : 0u;
+            nv += k0[u] == k0[u] ? 1u : 0u;
             m0[u] = __ballot((k0[u] >= lo[0]) & (k0[u] <= hi[0]));
             m1[u] = __ballot((k1[u] >= lo[1]) & (k1[u] <= hi[1]));
             tot0 += (uint32_t)__popcll(m0[u]);
@@ -998,19 +1216,20 @@ __device__ __forceinline__ void wg_refine(int n_raw, const Key2& key2, const flo
             }
         }
     }
-    for (int o = 32; o > 0; o >>= 1) { lt0 += __shfl_xor((int)lt0, o, 64); lt1 += __shfl_xor((int)lt1, o, 64); }
-    if (lane == 0) { if (lt0) atomicAdd(&S.misc[12], lt0); if (lt1) atomicAdd(&S.misc[13], lt1); }
+    for (int o = 32; o > 0; o >>= 1) { lt0 += __shfl_xor((int)lt0, o, 64); lt1 += __shfl_xor((int)lt1, o, 64); nv += __shfl_xor((int)nv, o, 64); }
+    if (lane == 0) { if (lt0) atomicAdd(&S.misc[12], lt0); if (lt1) atomicAdd(&S.misc[13], lt1); if (nv) atomicAdd(&S.misc[8], nv); }
     __threadfence_block();
     __syncthreads();
     n_lt[0] = S.misc[12]; n_lt[1] = S.misc[13]; n_in[0] = S.misc[14]; n_in[1] = S.misc[15];
+    if (n_valid) *n_valid = S.misc[8];
     __syncthreads();
 }
 
 // One pass over the n keys: how many lie below lo, how many inside [lo, hi], and the smallest and largest of those inside
 // (ordered integers; 0xffffffff / 0 when none).  Ends with a barrier.
+struct Census { uint32_t n_below, n_in, omin, omax; };
 template <class KeyAt>
-__device__ __noinline__ void wg_bracket_census(int n, KeyAt key_at, float lo, float hi, uint32_t& n_below, uint32_t& n_in, uint32_t& omin,
-                                               uint32_t& omax, SelScratch& S) {
+__device__ __noinline__ Census wg_bracket_census(int n, KeyAt key_at, float lo, float hi, SelScratch& S) {
     if (threadIdx.x == 0) { S.misc[4] = 0xffffffffu; S.misc[5] = 0; S.misc[6] = 0; S.misc[7] = 0; }
     __syncthreads();
     const uint32_t olo = f2ord(lo), ohi = f2ord(hi);
@@ -1027,8 +1246,9 @@ __device__ __noinline__ void wg_bracket_census(int n, KeyAt key_at, float lo, fl
     }
     if ((threadIdx.x & 63) == 0) { atomicMin(&S.misc[4], mn); atomicMax(&S.misc[5], mx); atomicAdd(&S.misc[6], nb); atomicAdd(&S.misc[7], ni); }
     __syncthreads();
-    omin = S.misc[4]; omax = S.misc[5]; n_below = S.misc[6]; n_in = S.misc[7];
+    const Census c{S.misc[6], S.misc[7], S.misc[4], S.misc[5]};
     __syncthreads();
+    return c;
 }
 
 // Exact order statistics (k, k+1) of one bracket of a selection stage from the refined lists:
@@ -1049,10 +1269,9 @@ __device__ __forceinline__ void stage_order_stats(const float* cand, uint32_t n_
         // Mostly this is a run of ties (few-colour images: more equal keys than the lists hold).  One census pass over the
         // tile settles that case: if every key inside the bracket is the same value and both ranks fall on it, that value
         // is the answer; only otherwise the windowed selection (about six more passes) runs.
-        uint32_t n_below, n_in_all, omin, omax;
-        wg_bracket_census(P, tile_key_at, lo, hi, n_below, n_in_all, omin, omax, S);
-        if (n_in_all > 0 && omin == omax && k >= (long long)n_below && k2 < (long long)n_below + (long long)n_in_all) {
-            xa = xb = ord2f(omin);
+        const Census c = wg_bracket_census(P, tile_key_at, lo, hi, S);
+        if (c.n_in > 0 && c.omin == c.omax && k >= (long long)c.n_below && k2 < (long long)c.n_below + (long long)c.n_in) {
+            xa = xb = ord2f(c.omin);
         } else {
             wg_select_pair(P, tile_key_at, (uint32_t)k, xa, xb, S);
             if (k2 == k) xb = xa;
@@ -2128,6 +2347,7 @@ struct FusedArgs {
     double* maxC_out;        // [n_tiles][2]
     int32_t* status_out;     // [n_tiles]
     int32_t* diag_out;       // [n_tiles] fallbacks (may be NULL)
+    int32_t* resweep_out;    // [n_tiles] 1 when the tile needed the separate concentration sweep (may be NULL)
 #ifdef SL_DEVTOOLS
     long long* phase_clock;  // [n_tiles][8] wall_clock64() at phase boundaries (development build only, may be NULL)
     int debug_stop;          // development build only: leave the tile after phase marker debug_stop-1 (0 = run everything)
@@ -2156,6 +2376,8 @@ struct FusedShared {
     float res[4];
     LassoK L;
     int status;
+    int conc_done;           // the merged sweep's candidates settled maxC: sweep 3 is skipped
+    MergedConc mk;
 };
 
 enum { kMethodMacenko = 0, kMethodVahadane = 1 };
@@ -2186,6 +2408,29 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
         __syncthreads();
     };
 
+    // ---- sharing the CU.  Two workgroups live on a CU and the instruction arbiter serves the OLDER one's waves first: left alone,
+    // the first-launched workgroup of every CU runs its sweeps ~20 % faster than its partner, whose latency-bound finish steps
+    // stretch by half (measured: tile latency 1.50 vs 1.83 ms; the launch ends when the slow half does, with the CU
+    // half empty for the last 0.3 ms).  s_setprio overrides age: the finish steps (few instructions, long dependent
+    // latencies) always run at top priority, and the sweeps' priorities alternate between the two workgroups by sweep.
+    uint32_t lds_alloc_;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_LDS_ALLOC)" : "=s"(lds_alloc_));
+    const bool younger = (lds_alloc_ & 0xffu) != 0u;          // the workgroup that got the upper half of the CU's LDS was launched second
+#ifndef SL_PRIO_SCHEME
+#define SL_PRIO_SCHEME 0
+#endif
+    auto prio_finish = [&]() { if (SL_PRIO_SCHEME >= 1) __builtin_amdgcn_s_setprio(3); };
+    auto prio_sweep = [&](int which) {              // which: 0 moments, 1 select, 2 conc resweep / dictionary, 3 apply
+        if (SL_PRIO_SCHEME == 1) __builtin_amdgcn_s_setprio(0);
+        if (SL_PRIO_SCHEME == 2) {
+            if (younger) __builtin_amdgcn_s_setprio(1);
+            else if (which & 1) __builtin_amdgcn_s_setprio(2);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+        if (SL_PRIO_SCHEME == 3) {
+            if (younger) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        }
+    };
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         const size_t nbytes = (size_t)a.P * 3;
 #ifdef SL_DEBUG_SAMETILE
@@ -2211,6 +2456,7 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
 
         if (METHOD == kMethodMacenko) {
             // ---------------- sweep 1: moments + sample
+            prio_sweep(0);
             {
                 Moments mo;
                 uint32_t n_tissue = 0;
@@ -2223,6 +2469,7 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
                 if (lane == 0)
                     for (int i = 0; i < 10; ++i) sh.red[wave][i] = v[i];
             }
+            prio_finish();
             __syncthreads();
             if (tid < 10) {
                 double t = 0;
@@ -2239,6 +2486,7 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
                 sh.status = eigvecs_from_moments(sh.sum, Vd, Vf);
                 for (int i = 0; i < 6; ++i) { sh.Vd[i] = Vd[i]; sh.Vf[i] = Vf[i]; }
                 sh.n_raw = 0; sh.overflow = 0;
+                sh.conc_done = 0;
             }
             __syncthreads();
             SL_SUB(1);
@@ -2252,13 +2500,36 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
                     if (tid == 0) { sh.lo[0] = lo[0]; sh.hi[0] = hi[0]; sh.lo[1] = lo[1]; sh.hi[1] = hi[1]; }
                     __syncthreads();
                 }
+                SL_SUB(12);
+                // ---------------- the box of stain matrices the sample leaves possible, concentration brackets under its centre
+                if (tid < 64) merged_box(sh.Vd, sh.lo, sh.hi, a.lam, tid, sh.mk);
+                __syncthreads();
+                SL_SUB(13);
+                if (sh.mk.ok) {                                               // block-uniform
+                    SampleConcKey ckey;
+                    ckey.sample = samp; ckey.tab = view_of_b(sh.tab); ckey.L = sh.mk.Lc; ckey.cps_log2 = a.stride_log2 - 2;
+                    ckey.P = a.P; ckey.col = 0;
+                    float lo[2], hi[2];
+                    conc_brackets<NT>(ckey, a.n_sample, lo, hi, sh.S);
+                    if (tid == 0) merged_thresholds(sh.mk, lo[0], lo[1], hi[0], hi[1]);
+                } else if (tid == 0) {
+                    merged_thresholds(sh.mk, -INFINITY, -INFINITY, -INFINITY, -INFINITY);       // disarms the concentration test
+                }
+                __syncthreads();
                 SL_PHASE(2);
-                // ---------------- sweep 2: angle select
+                // ---------------- sweep 2: angle select + concentration select under the box
                 {
                     SelConsts K;
                     for (int i = 0; i < 6; ++i) K.V[i] = in_vgpr(sh.Vf[i]);
                     K.L.g12 = 0.0f;
-                    run_select(std::integral_constant<int, kStageAngle>{}, src, K);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        K.u[i][0] = in_vgpr(sh.mk.u[i][0]); K.u[i][1] = in_vgpr(sh.mk.u[i][1]); K.kt[i] = in_vgpr(sh.mk.kt[i]);
+                        K.eps[i] = in_vgpr(sh.mk.eps[i]); K.thr[i] = in_vgpr(sh.mk.thr[i]);
+                    }
+                    prio_sweep(1);
+                    run_select(std::integral_constant<int, kStageMerged>{}, src, K);
+                    prio_finish();
                 }
                 SL_PHASE(3);
                 // ---------------- finish 2: exact angular percentiles -> M
@@ -2269,17 +2540,19 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
                 percentile_pos((double)T, a.pct, k[1], gfrac[1]);
                 AngleTileKey tkey;
                 tkey.src = src; tkey.tab = view_of_b(sh.tab); tkey.ylimf = a.ylimf;
-                RawAngleKey2 rkey;
-                rkey.raw = rawl; rkey.tab = view_of_b(sh.tab);
+                RawAngleKeyT rkey;
+                rkey.raw = rawl; rkey.tab = view_of_b(sh.tab); rkey.ylimf = a.ylimf;
                 for (int i = 0; i < 6; ++i) { tkey.V[i] = sh.Vf[i]; rkey.V[i] = sh.Vf[i]; }
                 const bool complete = sh.n_raw <= (uint32_t)a.cap_raw && sh.overflow == 0;
                 const uint32_t n_raw = sh.n_raw < (uint32_t)a.cap_raw ? sh.n_raw : (uint32_t)a.cap_raw;
                 const float los[2] = {sh.lo[0], sh.lo[1]}, his[2] = {sh.hi[0], sh.hi[1]};
-                const long long base[2] = {0, (long long)T - (long long)sh.n_raw};   // plain = tissue pixels not collected
-                uint32_t n_lt[2], n_in[2];
+                uint32_t n_lt[2], n_in[2], n_tis;
                 SL_SUB(2);
-                wg_refine((int)n_raw, rkey, los, his, cand0, cand1, (uint32_t)a.cap_list, n_lt, n_in, sh.S);
+                wg_refine((int)n_raw, rkey, los, his, cand0, cand1, (uint32_t)a.cap_list, n_lt, n_in, sh.S, &n_tis);
                 SL_SUB(3);
+                // plain = tissue pixels the sweep did not collect: they sit between the two brackets (the list also holds
+                // pixels collected for their concentrations; those with an angle key count like any other candidate)
+                const long long base[2] = {0, (long long)T - (long long)n_tis};
                 for (int li = 0; li < 2; ++li) {
                     float xa, xb;
                     stage_order_stats(li ? cand1 : cand0, n_in[li], (uint32_t)a.cap_list, complete, los[li], his[li], base[li] + n_lt[li], a.P, tkey,
@@ -2294,16 +2567,64 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
                     if (tid == 0) {
                         for (int i = 0; i < 6; ++i) sh.M[i] = M[i];
                         if (stain_matrix_singular(M)) sh.status = SL_TILE_DEGENERATE_COV;
+                        // the concentration candidates of the merged sweep are usable iff the exact M lies where the sweep assumed
+                        const bool use = sh.status == SL_TILE_OK && complete && merged_verify(sh.mk, M, a.lam);
+                        sh.conc_done = use ? 1 : 0;
+                        if (use) { LassoK L; lasso_consts(M, a.lam, L); sh.L = L; }
                     }
                 }
+                __syncthreads();
                 SL_SUB(6);
+                if (sh.conc_done) {                                           // block-uniform
+                    // ---------------- finish 2b: exact 99th percentiles of the concentrations from the same raw list
+                    long long kc;
+                    double gc;
+                    percentile_pos((double)a.P, 99.0, kc, gc);
+                    const long long kc2 = kc + 1 < (long long)a.P ? kc + 1 : kc;
+                    RawConcKey2 ckey2;
+                    ckey2.raw = rawl; ckey2.tab = view_of_b(sh.tab); ckey2.L = sh.L;
+                    const float cl[2] = {sh.mk.L[0], sh.mk.L[1]}, chh[2] = {sh.mk.H[0], sh.mk.H[1]};
+                    uint32_t c_lt[2], c_in[2];
+                    wg_refine((int)n_raw, ckey2, cl, chh, cand0, cand1, (uint32_t)a.cap_list, c_lt, c_in, sh.S);
+                    SL_SUB(14);
+                    const long long n_plain = (long long)a.P - (long long)sh.n_raw;       // proven below both brackets
+                    bool covered = true;
+#pragma unroll
+                    for (int col = 0; col < 2; ++col) {
+                        const long long lt = n_plain + c_lt[col];
+                        covered = covered & (kc >= lt) & (kc2 < lt + (long long)c_in[col]) & (c_in[col] <= (uint32_t)a.cap_list);
+                    }
+                    if (covered) {
+                        ConcTileKey ctk;
+                        ctk.src = src; ctk.tab = view_of_b(sh.tab); ctk.L = sh.L;
+                        for (int col = 0; col < 2; ++col) {
+                            ctk.col = col;
+                            float xa, xb;
+                            stage_order_stats(col ? cand1 : cand0, c_in[col], (uint32_t)a.cap_list, true, cl[col], chh[col], n_plain + c_lt[col], a.P,
+                                              ctk, (uint32_t)a.P, kc, xa, xb, fallbacks, sh.S);
+                            if (tid == 0) { sh.res[2 * col] = xa; sh.res[2 * col + 1] = xb; }
+                            __syncthreads();
+                        }
+                        if (tid == 0) {
+                            sh.maxC[0] = np_lerp((double)sh.res[0], (double)sh.res[1], gc);   // normalizer.py:36,47
+                            sh.maxC[1] = np_lerp((double)sh.res[2], (double)sh.res[3], gc);
+                            if (!(sh.maxC[0] > 0.0) || !(sh.maxC[1] > 0.0)) sh.status = SL_TILE_ZERO_MAXC;
+                        }
+                    } else if (tid == 0) {
+                        sh.conc_done = 0;                                     // a bracket missed: sweep 3 settles it
+                    }
+                    __syncthreads();
+                    SL_SUB(15);
+                }
             }
         } else {
             // ---------------- Vahadane: class-moment dictionary learning
+            prio_sweep(0);
             gather_sample<ALIGNED>(src, a.P, a.stride_log2, samp, a.n_sample, tid, NT);
             if (tid == 0) {
                 dict_iter_init(sh.it);
                 sh.n_raw = 0; sh.overflow = 0;
+                sh.conc_done = 0;
             }
             __syncthreads();
             DictProgress pr{1, 0, 0, 0};
@@ -2322,7 +2643,8 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
         }
         __syncthreads();
         const bool bad = sh.status != SL_TILE_OK;                               // block-uniform
-        if (!bad) {
+        const bool resweep = !bad && !sh.conc_done;                             // block-uniform: sweep 3 of the four-sweep schedule
+        if (resweep) {
             if (tid == 0) {
                 LassoK L;
                 lasso_consts(sh.M, a.lam, L);
@@ -2347,7 +2669,9 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
                 SelConsts K;
                 K.L = sh.L;
                 vgpr(K.L);
+                prio_sweep(2);
                 run_select(std::integral_constant<int, kStageConc>{}, src, K);
+                prio_finish();
             }
             SL_PHASE(5);
             // ---------------- finish 3: exact 99th percentiles -> maxC
@@ -2383,11 +2707,12 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
                 }
                 __syncthreads();
             }
-        } else if (tid == 0) {
+        } else if (bad && sh.status != SL_TILE_ZERO_MAXC && tid == 0) {     // (a zero maxC keeps its M and maxC, as after finish 3)
             for (int i = 0; i < 6; ++i) sh.M[i] = nan_d();
             sh.maxC[0] = sh.maxC[1] = nan_d();
         }
         __syncthreads();
+        if (tid == 0 && a.resweep_out) a.resweep_out[tile] = (METHOD == kMethodMacenko && resweep) ? 1 : 0;
         if (tid < 6 && a.M_out) a.M_out[(size_t)tile * 6 + tid] = sh.M[tid];
         if (tid < 2 && a.maxC_out) a.maxC_out[(size_t)tile * 2 + tid] = sh.maxC[tid];
         if (tid == 0 && a.status_out) a.status_out[tile] = sh.status;
@@ -2402,6 +2727,7 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
             } else {
                 ApplyK K;
                 apply_consts(sh.M, sh.maxC, a.M_tgt, a.maxC_tgt, a.lam, K);
+                prio_sweep(3);
                 if (stream) {
                     if (K.fast) apply_sweep<ALIGNED, true, TabReaderB, true>(src, dst, a.P, 0, nch, tid, NT, TB, K);
                     else apply_sweep<ALIGNED, false, TabReaderB, true>(src, dst, a.P, 0, nch, tid, NT, TB, K);
