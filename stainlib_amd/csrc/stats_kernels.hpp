@@ -2587,6 +2587,12 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
                     uint32_t c_lt[2], c_in[2];
                     wg_refine((int)n_raw, ckey2, cl, chh, cand0, cand1, (uint32_t)a.cap_list, c_lt, c_in, sh.S);
                     SL_SUB(14);
+#ifdef SL_DEBUG_SUBCLK
+                    if (a.phase_clock && tid == 0) {      // list sizes beside the clocks (slots 8..11 are clocks only on the resweep path)
+                        long long* q = a.phase_clock + (size_t)a.n_tiles * 8 + (size_t)tile * 16;
+                        q[8] = n_raw; q[9] = n_raw; q[10] = n_in[0] + n_in[1]; q[11] = c_in[0] + c_in[1];
+                    }
+#endif
                     const long long n_plain = (long long)a.P - (long long)sh.n_raw;       // proven below both brackets
                     bool covered = true;
 #pragma unroll

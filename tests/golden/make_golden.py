@@ -246,6 +246,76 @@ def reinhard_case(size, seed, kind=None):
     return rec
 
 
+def tissue_case(I, seed):
+    """A REAL stained-tissue image (scikit-image's immunohistochemistry() sample, `ihc.png`: "no known copyright restrictions")
+    through every class of the reference a user would put it through -- the notebook's usage (stainlib_augmentation.ipynb cells
+    4-15).  The input array itself is stored: the GPU box has no scikit-image."""
+    I = np.ascontiguousarray(I)
+    h, w = I.shape[:2]
+    tgt = so.synth_tile(128, 128, 1000 + seed, so.M_TRUE_TGT)
+    rec = {"input": I, "seed": seed, "input_sha": sha(I), "target_sha": sha(tgt)}
+
+    def keep(name, a):                                    # whole images: SHA-256 + every 13th pixel (the oracle reproduces them in full)
+        rec[name + "_sha"] = sha(a)
+        rec[name + "_sub13"] = np.ascontiguousarray(a.reshape(-1, 3)[::13])
+    # --- Macenko stages + fit / transform (macenko_stain_extractor.py:16-44, normalizer.py:27-50)
+    mask = su.LuminosityThresholdTissueLocator.get_tissue_mask(I)
+    rec["mask_count"] = int(mask.sum())
+    rec["mask_bits"] = np.packbits(mask.ravel())
+    M = MacenkoStainExtractor.get_stain_matrix(I)
+    rec["M"] = M
+    C = su.get_concentrations(I, M)
+    rec["C_sub"] = np.ascontiguousarray(C[::97])
+    rec["maxC"] = np.percentile(C, 99, axis=0).reshape((1, 2))
+    nrm = ExtractiveStainNormalizer("macenko")
+    nrm.fit(tgt)
+    rec["M_target"] = nrm.stain_matrix_target
+    rec["maxC_target"] = nrm.maxC_target
+    rec["out"] = nrm.transform(I)
+    Cs = C * (nrm.maxC_target / rec["maxC"])
+    rec["prequant_sub"] = (255 * np.exp(-1 * np.dot(Cs, nrm.stain_matrix_target)))[::97]
+    nrm2 = ExtractiveStainNormalizer("macenko")
+    nrm2.fit(I)                                           # the tissue as the TARGET, a synthetic tile as the source
+    src = so.synth_tile(128, 128, seed)
+    rec["out_as_target"] = nrm2.transform(src)                # (128 x 128: kept whole)
+    # --- StainAugmentor (augmenter.py:334-449)
+    for bg in (False, True):
+        aug = StainAugmentor("macenko", augment_background=bg)
+        aug.fit(I)
+        np.random.seed(7 + seed)
+        st = np.random.get_state()
+        keep("aug_out0_bg%d" % bg, aug.pop())
+        keep("aug_out1_bg%d" % bg, aug.pop())
+        np.random.set_state(st)
+        rec["aug_draws0"] = np.array([np.random.uniform(0.8, 1.2), np.random.uniform(-0.2, 0.2),
+                                      np.random.uniform(0.8, 1.2), np.random.uniform(-0.2, 0.2)])
+    # --- HedLighterColorAugmenter with the real scikit-image 0.18.3 (augmenter.py:276-331)
+    hed = HedLighterColorAugmenter()
+    keep("hed_out_unrandomized", hed.transform(I))
+    np.random.seed(5 + seed)
+    hed.randomize()
+    rec["hed_sigmas"] = np.array(hed._sigmas)
+    rec["hed_biases"] = np.array(hed._biases)
+    keep("hed_out", hed.transform(I))
+    # --- Reinhard, LuminosityStandardizer, GrayscaleAugmentor (normalizer.py:54-94, stain_utils.py:146-194, augmenter.py:20-60)
+    #     (on top of the cv2 stand-in: see the module docstring)
+    rn = ReinhardStainNormalizer()
+    rn.fit(tgt)
+    keep("reinhard_out", rn.transform(I))
+    keep("reinhard_out_masked", rn.transform(I, mask_background=True))
+    rn2 = ReinhardStainNormalizer()
+    rn2.fit(I)
+    rec["reinhard_means"] = np.array([float(m) for m in rn2.target_means])
+    rec["reinhard_stds"] = np.array([float(v) for v in rn2.target_stds])
+    keep("lum_std", stainlib.LuminosityStandardizer.standardize(I))
+    from stainlib.augmentation.augmenter import GrayscaleAugmentor
+    ga = GrayscaleAugmentor()
+    ga.fit(I)
+    np.random.seed(11 + seed)
+    keep("gray_out0", ga.pop())
+    return rec
+
+
 def errors_case():
     rec = {}
     try:
@@ -307,7 +377,19 @@ def main():
     save("reinhard_128_s2", reinhard_case(128, 2))
     save("reinhard_128_white_bg_s4", reinhard_case(128, 4, "white_bg"))
     save("errors", errors_case())
+    tissue_main()
+
+
+def tissue_main():
+    """Real stained tissue: the 512 x 512 sample image of scikit-image and an odd crop of it."""
+    from skimage import data
+    ihc = np.ascontiguousarray(data.immunohistochemistry()[:, :, :3])
+    save("tissue_ihc_512", tissue_case(ihc, 1))
+    save("tissue_ihc_crop_383x509", tissue_case(ihc[3:386, 2:511], 2))
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "tissue":
+        tissue_main()
+    else:
+        main()

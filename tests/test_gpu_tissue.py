@@ -1,0 +1,143 @@
+"""-m gpu: the HIP path on a REAL stained-tissue image (scikit-image's `ihc.png` and an odd crop of it; fixtures
+tests/golden/tissue_*.npz hold the input and what the reference produced: make_golden.py `tissue_case`) -- every class the
+reference's notebook exercises (stainlib_augmentation.ipynb cells 4-15), both Macenko schedules, batches of the tile."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import stain_oracle as so
+from tests.gpu_util import to_dev, u8_parity
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TISSUE = sorted(glob.glob(os.path.join(GOLDEN, "tissue_*.npz")))
+M_ATOL = 2e-6
+MAXC_RTOL = 2e-6
+
+
+def mirror_tile(I, size):
+    """A size x size tile from a smaller image by mirror tiling (what bench.py's real-tissue batch is made of)."""
+    h, w = I.shape[:2]
+    row = np.concatenate([I, I[:, ::-1]], axis=1)
+    full = np.concatenate([row, row[::-1]], axis=0)
+    reps = (-(-size // (2 * h)), -(-size // (2 * w)), 1)
+    return np.ascontiguousarray(np.tile(full, reps)[:size, :size])
+
+
+@pytest.mark.parametrize("path", TISSUE, ids=[os.path.basename(p)[:-4] for p in TISSUE])
+def test_macenko_on_real_tissue(path):
+    import stainlib_amd as sl
+    from stainlib_amd import engine
+    from stainlib_amd.utils import stain_utils as su
+    g = np.load(path)
+    I, seed = g["input"], int(g["seed"])
+    tgt = so.synth_tile(128, 128, 1000 + seed, so.M_TRUE_TGT)
+    # the reference's class surface
+    n = sl.MacenkoNormalizer()
+    n.fit(tgt)
+    np.testing.assert_allclose(n.stain_matrix_target, g["M_target"], rtol=0, atol=M_ATOL)
+    out = n.transform(I)
+    assert out.dtype == np.uint8 and out.shape == I.shape
+    u8_parity(out, g["out"], label=os.path.basename(path) + " (reference output)")
+    M = sl.MacenkoStainExtractor.get_stain_matrix(I)
+    np.testing.assert_allclose(M, g["M"], rtol=0, atol=M_ATOL)
+    assert np.array_equal(np.packbits(su.LuminosityThresholdTissueLocator.get_tissue_mask(I).ravel()), g["mask_bits"])
+    C = su.get_concentrations(I, g["M"])
+    np.testing.assert_allclose(C[::97], g["C_sub"], rtol=0, atol=2e-5)
+    # the tissue as the target of a synthetic source
+    n2 = sl.MacenkoNormalizer()
+    n2.fit(I)
+    u8_parity(n2.transform(so.synth_tile(128, 128, seed)), g["out_as_target"], label="tissue as target")
+    # batch entry point, both schedules, a batch of rolled copies: statistics per tile, same bytes from both schedules
+    tiles = [I, np.ascontiguousarray(np.roll(I, 37, axis=0)), np.ascontiguousarray(I[::-1])]
+    Mt, mct, _ = engine.macenko_fit(to_dev([tgt]))
+    outs = []
+    for sched in (1, 2):
+        o, Mb, mcb, st = engine.macenko_transform(to_dev(tiles), Mt[0], mct[0], params=engine.make_params(schedule=sched))
+        assert (st.cpu().numpy() == 0).all()
+        np.testing.assert_allclose(Mb.cpu().numpy()[0], g["M"], rtol=0, atol=M_ATOL)
+        np.testing.assert_allclose(mcb.cpu().numpy()[0], g["maxC"].reshape(2), rtol=MAXC_RTOL)
+        # a permutation of the pixels leaves the statistics where they are (up to the binary32 burst sums)
+        np.testing.assert_allclose(Mb.cpu().numpy()[1:], np.broadcast_to(g["M"], (2, 2, 3)), rtol=0, atol=M_ATOL)
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1])
+    u8_parity(outs[0][0].cpu().numpy(), g["out"], label="batch")
+
+
+@pytest.mark.parametrize("path", TISSUE, ids=[os.path.basename(p)[:-4] for p in TISSUE])
+def test_augmenters_and_lab_family_on_real_tissue(path):
+    import stainlib_amd as sl
+    g = np.load(path)
+    I, seed = g["input"], int(g["seed"])
+    tgt = so.synth_tile(128, 128, 1000 + seed, so.M_TRUE_TGT)
+
+    def check(a, name, exact=False):
+        sub = a.reshape(-1, 3)[::13]
+        if exact:
+            assert np.array_equal(sub, g[name + "_sub13"]), name
+        else:
+            u8_parity(sub, g[name + "_sub13"], label=name + " (1/13 of the reference output)")
+
+    for bg in (0, 1):
+        a = sl.StainAugmentor("macenko", augment_background=bool(bg))
+        a.fit(I)
+        np.testing.assert_allclose(a.stain_matrix, g["M"], rtol=0, atol=M_ATOL)
+        np.random.seed(7 + seed)
+        o0, o1 = a.pop(), a.pop()
+        check(o0, "aug_out0_bg%d" % bg)
+        check(o1, "aug_out1_bg%d" % bg)
+        oa = so.StainAugmentor("macenko", augment_background=bool(bg))
+        oa.fit(I)
+        d = g["aug_draws0"]
+        u8_parity(o0, oa.pop_with([d[0], d[2]], [d[1], d[3]]), label="StainAugmentor (oracle, full)")
+    h = sl.HedLighterColorAugmenter()
+    check(h.transform(I), "hed_out_unrandomized")
+    np.random.seed(5 + seed)
+    h.randomize()
+    np.testing.assert_array_equal(np.array(h._sigmas), g["hed_sigmas"])
+    ho = h.transform(I)
+    check(ho, "hed_out")
+    u8_parity(ho, so.hed_transform(I, g["hed_sigmas"], g["hed_biases"]), label="HED (oracle, full)")
+    rn = sl.ReinhardStainNormalizer()
+    rn.fit(tgt)
+    check(rn.transform(I), "reinhard_out", exact=True)
+    check(rn.transform(I, mask_background=True), "reinhard_out_masked", exact=True)
+    rn2 = sl.ReinhardStainNormalizer()
+    rn2.fit(I)
+    np.testing.assert_allclose([float(np.asarray(m).reshape(-1)[0]) for m in rn2.target_means], g["reinhard_means"], rtol=1e-13)
+    np.testing.assert_allclose([float(np.asarray(v).reshape(-1)[0]) for v in rn2.target_stds], g["reinhard_stds"], rtol=1e-12)
+    check(sl.LuminosityStandardizer.standardize(I), "lum_std", exact=True)
+    ga = sl.GrayscaleAugmentor()
+    ga.fit(I)
+    np.random.seed(11 + seed)
+    check(ga.pop(), "gray_out0")
+
+
+def test_full_size_tile_of_mirrored_tissue_both_schedules():
+    """1024 x 1024 (BASELINE configs[1] tile size) made of the real image by mirror tiling, as bench.py's real-tissue batch:
+    both schedules agree to the byte, no fallback, and the statistics match the oracle."""
+    from stainlib_amd import engine
+    g = np.load(os.path.join(GOLDEN, "tissue_ihc_512.npz"))
+    T = mirror_tile(g["input"], 1024)
+    tgt = so.synth_tile(128, 128, 1001, so.M_TRUE_TGT)
+    Mt, mct, _ = engine.macenko_fit(to_dev([tgt]))
+    outs = []
+    for sched in (1, 2):
+        p = engine.make_params(schedule=sched)
+        fb = engine.attach_fallbacks(p, 2)
+        o, M, mc, st = engine.macenko_transform(to_dev([T, np.ascontiguousarray(T[::-1])]), Mt[0], mct[0], params=p)
+        assert (st.cpu().numpy() == 0).all() and int(fb.sum()) == 0
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1])
+    Mo = so.macenko_stain_matrix(T)
+    np.testing.assert_allclose(M.cpu().numpy()[0], Mo, rtol=0, atol=M_ATOL)
+    # mirror tiling repeats every pixel four times: the statistics of the tile are those of the image
+    np.testing.assert_allclose(M.cpu().numpy()[0], g["M"], rtol=0, atol=M_ATOL)
+    np.testing.assert_allclose(mc.cpu().numpy()[0], g["maxC"].reshape(2), rtol=MAXC_RTOL)
+    on = so.ExtractiveStainNormalizer("macenko")
+    on.stain_matrix_target, on.maxC_target = Mt[0].cpu().numpy(), mct[0].cpu().numpy().reshape(1, 2)
+    u8_parity(outs[0][0].cpu().numpy(), on.transform(T), label="mirrored tissue 1024^2 (oracle)")

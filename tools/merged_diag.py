@@ -42,13 +42,27 @@ print("fused  ms (median, min):", med(lambda: engine.macenko_transform(rgb, Mt[0
 print("phases ms (median, min):", med(lambda: engine.macenko_transform(rgb, Mt[0], mct[0], out=out, params=p1, ws=ws)))
 lib = _ffi.lib()
 if hasattr(lib, "sl_debug_set_phase_clock"):
-    buf = torch.zeros((n, 8), dtype=torch.int64, device="cuda")
+    sub_build = hasattr(lib, "sl_debug_bclk")
+    buf = torch.zeros((n * 24,), dtype=torch.int64, device="cuda")
     lib.sl_debug_set_phase_clock.argtypes = [C.c_void_p]
     lib.sl_debug_set_phase_clock(C.c_void_p(buf.data_ptr()))
     engine.macenko_transform(rgb, Mt[0], mct[0], out=out, params=p)
     torch.cuda.synchronize()
     lib.sl_debug_set_phase_clock(C.c_void_p(0))
-    t = buf.cpu().numpy().astype(np.float64) * 0.01
+    tall = buf.cpu().numpy().astype(np.float64) * 0.01
+    t = tall[: n * 8].reshape(n, 8)
+    if sub_build:
+        sub = tall[n * 8:].reshape(n, 16)
+        ph = t
+        steps = [("F1 eig", sub[:, 1] - sub[:, 0]), ("F1 angle brackets", sub[:, 12] - sub[:, 1]), ("F1 box", sub[:, 13] - sub[:, 12]),
+                 ("F1 conc brackets", ph[:, 2] - sub[:, 13]), ("F2 pre", sub[:, 2] - ph[:, 3]), ("F2 refine angle", sub[:, 3] - sub[:, 2]),
+                 ("F2 pick angle", sub[:, 5] - sub[:, 3]), ("F2 M + verify", sub[:, 6] - sub[:, 5]), ("F2b refine conc", sub[:, 14] - sub[:, 6]),
+                 ("F2b pick conc", sub[:, 15] - sub[:, 14]), ("F2b tail -> apply", ph[:, 6] - sub[:, 15])]
+        cnt = tall[n * 8:].reshape(n, 16)[:, 8:12] * 100.0       # slots 8..11: raw counts written by the kernel (not clocks)
+        print("    per tile: angle candidates %.0f, concentration candidates %.0f, angle members %.0f, concentration members %.0f" % tuple(cnt.mean(0)))
+        h2 = n // 2
+        for nm, v in steps:
+            print(f"    {nm:20s} {v.mean():8.1f}   first half {v[:h2].mean():8.1f}  second half {v[h2:].mean():8.1f}")
     d = np.diff(t, axis=1)
     names = ["sweep1 moments", "finish1 eig+brackets+box", "sweep2 merged", "finish2 M (+maxC)", "sweep3 conc (resweep)", "finish3 maxC", "sweep4 apply"]
     for i, nm in enumerate(names):
