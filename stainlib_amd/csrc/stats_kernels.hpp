@@ -197,7 +197,7 @@ __device__ __forceinline__ float ord2f(uint32_t o) {
 // ------------------------------------------------------------------------------------------
 struct SelScratch {
     uint32_t hist[1024];
-    uint32_t misc[16];
+    uint32_t misc[64];        // [0,16) the windowed selection primitives; [16,64) the one-pass primitives (wg_refine_s, wg_pick2)
 };
 
 // Locate the histogram bin holding 0-based rank k: out = {bin, count below bin, count in bin}.
@@ -476,6 +476,37 @@ __device__ __forceinline__ void wg_brackets_regs(const uint32_t (&ord)[NSETS][KP
         const bool none = nv[set_of[b]] == 0;
         lo[b] = (none || open[2 * b]) ? -INFINITY : ord2f(wlo[2 * b]);
         hi[b] = (none || open[2 * b + 1]) ? INFINITY : ord2f(whi[2 * b + 1]);
+    }
+}
+
+// inclusive prefix sum over the 64 lanes of a wave with DPP row shifts / broadcasts (gfx9)
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+// One wave: the bin of `hist[0..nb)` (nb a multiple of 64, <= 1024) holding 0-based rank k -> out = {bin, count below, count in bin};
+// k beyond the total gives {nb - 1, total - count(last bin), count(last bin)}.
+__device__ __forceinline__ void wave_locate(const uint32_t* hist, int nb, uint32_t k, uint32_t* out, int lane) {
+    const int per = nb >> 6;
+    uint32_t s = 0;
+    for (int j = 0; j < per; ++j) s += hist[lane * per + j];
+    const uint32_t inc = wave_inclusive_scan(s), exc = inc - s;
+    const uint32_t total = (uint32_t)__shfl((int)inc, 63, 64);
+    const uint32_t kk = total ? (k < total ? k : total - 1) : 0u;
+    if (total == 0) { if (lane == 0) { out[0] = 0; out[1] = 0; out[2] = 0; } return; }
+    if (kk >= exc && kk < inc) {
+        uint32_t acc = exc;
+        for (int j = 0; j < per; ++j) {
+            const uint32_t h = hist[lane * per + j];
+            if (kk < acc + h) { out[0] = (uint32_t)(lane * per + j); out[1] = acc; out[2] = h; break; }
+            acc += h;
+        }
     }
 }
 
@@ -1280,15 +1311,116 @@ __device__ __forceinline__ void stage_order_stats(const float* cand, uint32_t n_
     }
 }
 
-// inclusive prefix sum over the 64 lanes of a wave with DPP row shifts / broadcasts (gfx9)
-__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
-    return v;
+// bin_b(k) = clamp((k - lo_b) sc_b, 0, 511): the 512-bin histogram of bracket b's members that wg_refine_s fills and wg_pick2 reads
+struct PickScale { float lo[2], sc[2]; };
+__device__ __forceinline__ int pick_bin(float k, float lo, float sc) { return min(511, max(0, (int)((k - lo) * sc))); }
+
+// Exact order statistics krel[b] and krel[b] + 1 (0-based among the members of bracket b, both < n_in[b] unless has2[b] is
+// false) for the brackets with want[b], from the histograms wg_refine_s left in S.hist: locate the bin of rank krel, gather
+// that bin's keys (one pass over the member list, next trip in flight) and the smallest key beyond it, rank by brute force.
+// done[b] = false when the bin holds more than 512 keys (ties / a degenerate spread): the caller takes the windowed path.
+__device__ __forceinline__ void wg_pick2(const float* cand0, const float* cand1, const uint32_t* n_in, const bool* want, const uint32_t* krel,
+                                         const PickScale& ps, float* xa /*[2]*/, float* xb /*[2]*/, bool* done /*[2]*/, SelScratch& S) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+        if (wave == b && want[b]) wave_locate(S.hist + 512 * b, 512, krel[b], &S.misc[16 + 3 * b], lane);
+    if (tid < 2) { S.misc[24 + tid] = 0; S.misc[26 + tid] = 0xffffffffu; }      // list fill, smallest key beyond the bin (ordered)
+    __syncthreads();
+    uint32_t bin[2], below[2], cnt[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) { bin[b] = S.misc[16 + 3 * b]; below[b] = S.misc[17 + 3 * b]; cnt[b] = S.misc[18 + 3 * b]; done[b] = want[b] && cnt[b] <= 512u && cnt[b] > 0u; }
+    __syncthreads();                                                          // the histograms become the two key lists
+    float* list = reinterpret_cast<float*>(S.hist);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        if (!done[b]) continue;                                               // block-uniform
+        const float* cand = b ? cand1 : cand0;
+        const int n = (int)n_in[b];
+        constexpr int U = 4;
+        const int bd = blockDim.x;
+        uint32_t best = 0xffffffffu;
+        float kn[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int i = tid + u * bd; kn[u] = cand[i < n ? i : 0]; }
+        for (int i0 = tid; i0 < n; i0 += U * bd) {
+            float k[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                k[u] = kn[u];
+                const int i = i0 + (U + u) * bd;
+                kn[u] = cand[i < n ? i : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (i0 + u * bd >= n) continue;
+                const int kb = pick_bin(k[u], ps.lo[b], ps.sc[b]);
+                if (kb == (int)bin[b]) { const uint32_t pos = atomicAdd(&S.misc[24 + b], 1u); if (pos < 512u) list[512 * b + pos] = k[u]; }
+                else if (kb > (int)bin[b]) best = min(best, f2ord(k[u]));
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, o, 64));
+        if (lane == 0 && best != 0xffffffffu) atomicMin(&S.misc[26 + b], best);
+    }
+    __syncthreads();
+    if (tid < 4) S.misc[28 + tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        if (!done[b]) continue;
+        const uint32_t m = cnt[b], ra = krel[b] - below[b];
+        if ((uint32_t)tid < m) {
+            const float me = list[512 * b + tid];
+            uint32_t r = 0;
+            for (uint32_t j = 0; j < m; ++j) {
+                const float o = list[512 * b + j];
+                r += (o < me || (o == me && j < (uint32_t)tid)) ? 1u : 0u;
+            }
+            if (r == ra) S.misc[28 + 2 * b] = __float_as_uint(me);
+            if (r == ra + 1) S.misc[29 + 2 * b] = __float_as_uint(me);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        if (!done[b]) continue;
+        xa[b] = __uint_as_float(S.misc[28 + 2 * b]);
+        const bool same_bin = krel[b] - below[b] + 1 < cnt[b];
+        const uint32_t nx = S.misc[26 + b];
+        xb[b] = same_bin ? __uint_as_float(S.misc[29 + 2 * b]) : (nx != 0xffffffffu ? ord2f(nx) : xa[b]);
+    }
+    __syncthreads();
+}
+
+// Both brackets of a selection stage: the one-pass path where the bracket covers the wanted ranks and its member list is
+// complete, the windowed / whole-tile paths of stage_order_stats otherwise.  lt[b] = pixels below bracket b (proven or counted).
+template <bool TWO_COLS, class TileKeyAt>
+__device__ __forceinline__ void stage_pick2(const float* cand0, const float* cand1, const uint32_t* n_in, uint32_t cap_list, bool complete,
+                                            const float* lo, const float* hi, const long long* lt, int P, TileKeyAt tile_key_at, uint32_t n,
+                                            const long long* k, const PickScale& ps, float* res /*[4]: xa0, xb0, xa1, xb1*/, int& fallbacks, SelScratch& S) {
+    bool fast[2], has2[2];
+    uint32_t krel[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const long long k2 = (k[b] + 1 < (long long)n) ? k[b] + 1 : k[b];
+        has2[b] = k2 != k[b];
+        const bool covered = complete && k[b] >= lt[b] && k2 < lt[b] + (long long)n_in[b];
+        fast[b] = covered && lo[b] < hi[b] && n_in[b] <= cap_list;
+        krel[b] = fast[b] ? (uint32_t)(k[b] - lt[b]) : 0u;
+    }
+    float xa[2] = {0, 0}, xb[2] = {0, 0};
+    bool done[2] = {false, false};
+    if (fast[0] | fast[1]) wg_pick2(cand0, cand1, n_in, fast, krel, ps, xa, xb, done, S);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        if (done[b]) {
+            if (!has2[b]) xb[b] = xa[b];
+        } else {
+            if constexpr (TWO_COLS) tile_key_at.col = b;
+            stage_order_stats(b ? cand1 : cand0, n_in[b], cap_list, complete, lo[b], hi[b], lt[b], P, tile_key_at, n, k[b], xa[b], xb[b], fallbacks, S);
+        }
+        res[2 * b] = xa[b]; res[2 * b + 1] = xb[b];
+    }
 }
 
 // Raw candidates are staged per wave in LDS and written out in dense bursts; the tile's list head is
@@ -1319,6 +1451,7 @@ struct RawSink {
     unsigned int* head;         // list head (LDS in the fused kernel, global otherwise)
     unsigned int* overflow;     // (unused by this sink: an over-full list shows as head > cap)
     uint32_t cap;               // capacity of dst
+    uint32_t stage_cap;         // entries of the staging buffer (>= 64)
     __device__ __forceinline__ void flush(int) {
         if (n != 0) raw_flush(buf, n, dst, head, cap);
         n = 0;
@@ -1327,22 +1460,178 @@ struct RawSink {
     // path: the masked LDS write is an asm block that swaps EXEC itself (measured: the three branches per row of
     // the structured version cost more than all the arithmetic of the sweep).
     __device__ __forceinline__ void put(unsigned long long m, const Chunk& ch, int px, int lane) {
+        put_value(m, chunk_pixel(ch, px) & 0xffffffu, lane);
+    }
+    // the same for any 32-bit value of the flagged lanes
+    __device__ __forceinline__ void put_value(unsigned long long m, uint32_t value, int lane) {
         const uint32_t cnt = (uint32_t)__popcll(m);
-        if (__builtin_expect(n + cnt > (uint32_t)kStageWave, 0)) flush(lane);   // rare, out of line; a row holds <= 64 entries
+        if (__builtin_expect(n + cnt > stage_cap, 0)) flush(lane);   // rare, out of line; a row holds <= 64 entries
         // fill level + rank of this lane among the flagged lanes: the fill level rides in as v_mbcnt's addend
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, n));
 #if defined(__HIP_DEVICE_COMPILE__)
         const uint32_t addr = buf + 4u * rank;
-        const uint32_t raw = chunk_pixel(ch, px) & 0xffffffu;
         unsigned long long saved;
         asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_write_b32 %2, %3\n\ts_mov_b64 exec, %0"
-                     : "=&s"(saved) : "s"(m), "v"(addr), "v"(raw) : "memory");
+                     : "=&s"(saved) : "s"(m), "v"(addr), "v"(value) : "memory");
 #else
-        (void)rank; (void)ch; (void)px;
+        (void)rank; (void)value;
 #endif
         n += cnt;
     }
 };
+
+// ------------------------------------------------------------------------------------------
+// Finish 2 of the fused kernel, one pass per key family (round 3).
+//
+// What the first version of this step cost was not its arithmetic but its memory round trips: every trip of the refine loop
+// loaded its raw words, appended the bracket members to the global lists (an LDS atomic with return per list, then global
+// stores) and -- vmcnt completes in order on gfx9 and the number of conditional stores is unknown at compile time -- waited
+// for ALL of it at the top of the next trip: ~5 us per trip on a chip whose memory system is saturated by the neighbours'
+// sweeps, 31 trips per pass.  Here the hot loop issues no global store at all:
+//   * the 64 KB row table is not needed between the sweeps, so during finish 2 its space holds a 2 KB one-copy table
+//     {gamma, od32}[256] (bank conflicts instead of 32 copies: the finish steps are not LDS bound) and, per wave, two staging
+//     lists of 992 keys; a list is written out when it fills (about twice per wave and pass) and at the end;
+//   * the next trip's raw words are in flight while a trip is evaluated;
+//   * the members are counted into a 512-bin histogram per bracket on the way (masked ds_add, no return), from which
+//     wg_pick2 takes the order statistics with ONE more pass over the member list instead of three;
+//   * all counts are popcounts of ballots on the scalar unit.
+// The row table is rebuilt (fill_b) before the next sweep.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kFinTabBytes = 2048;                                  // 256 x {gamma, od32}
+__device__ __forceinline__ uint32_t fin_stage_bytes(int nthreads) { return (uint32_t)((sizeof(RowTab) - kFinTabBytes) / (size_t)(nthreads / 64)); }   // per wave
+
+struct FinTab {                 // reader of the one-copy table at LDS byte address `base`
+    uint32_t base;
+    // byte offset of the entry of byte k (0..2) of a raw word r | g << 8 | b << 16
+    __device__ __forceinline__ uint32_t addr(uint32_t w, int k) const { return k == 0 ? ((w << 3) & 0x7f8u) : ((w >> (8 * k - 3)) & 0x7f8u); }
+#if defined(__HIP_DEVICE_COMPILE__)
+    __device__ __forceinline__ float2 gam_odf(uint32_t a) const {
+        const v2f v = *(SL_LDS const v2f*)(base + a);
+        return make_float2(v.x, v.y);
+    }
+    __device__ __forceinline__ float odf(uint32_t a) const { return *(SL_LDS const float*)(base + a + 4u); }
+#else
+    float2 gam_odf(uint32_t) const { return float2{}; }
+    float odf(uint32_t) const { return 0.0f; }
+#endif
+    __device__ __forceinline__ TabView view() const { return TabView{base, 8u, 4u, 0u}; }      // for the TabView key functors (exact fallbacks)
+};
+// all threads: builds the one-copy table in the first 2 KB of the row table from the row table itself (layout B)
+__device__ __forceinline__ void fin_tab_build(RowTab& tab) {
+    float2* p = reinterpret_cast<float2*>(tab.e);
+    float2 e = make_float2(0.0f, 0.0f);
+    if (threadIdx.x < 256) e = p[threadIdx.x * 32];
+    __syncthreads();
+    if (threadIdx.x < 256) p[threadIdx.x] = e;
+    __syncthreads();
+}
+
+// all threads: the row table (layout B) back from the one-copy table -- LDS to LDS, the constants are not fetched again
+template <int NT>
+__device__ __forceinline__ void fin_tab_expand(RowTab& tab) {
+    float2* p = reinterpret_cast<float2*>(tab.e);
+    constexpr int PER = 256 * 32 / NT;                    // entries per thread; thread t writes t, t + NT, ...: values t/32 + j NT/32
+    float2 e[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) e[j] = p[threadIdx.x / 32 + j * (NT / 32)];
+    __syncthreads();                                      // every read of the one-copy table precedes the first write over it
+#pragma unroll
+    for (int j = 0; j < PER; ++j) p[threadIdx.x + j * NT] = e[j];
+    __syncthreads();
+}
+
+// keys of a raw word (same arithmetic as RawAngleKeyT / RawConcKey2: the per-phase schedule must select the same values)
+struct WordAngleKey {           // one pseudo-angle serves both brackets; valid = tissue
+    FinTab T; float V[6]; float ylimf;
+    __device__ __forceinline__ void of_word(uint32_t s, float& k0, float& k1, bool& valid) const {
+        const float2 er = T.gam_odf(T.addr(s, 0)), eg = T.gam_odf(T.addr(s, 1)), eb = T.gam_odf(T.addr(s, 2));
+        valid = is_tissue_f(er.x, eg.x, eb.x, ylimf);
+        k0 = k1 = angle_key(V, er.y, eg.y, eb.y);
+    }
+};
+struct WordConcKey {
+    FinTab T; LassoK L;
+    __device__ __forceinline__ void of_word(uint32_t s, float& k0, float& k1, bool& valid) const {
+        lasso2(L, T.odf(T.addr(s, 0)), T.odf(T.addr(s, 1)), T.odf(T.addr(s, 2)), k0, k1);
+        valid = true;
+    }
+};
+
+// ds_add_u32 of `one` at LDS byte address `addr` for the lanes of mask m (no return value, nothing to wait for)
+__device__ __forceinline__ void lds_count_masked(unsigned long long m, uint32_t addr, uint32_t one) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long saved;
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_add_u32 %2, %3\n\ts_mov_b64 exec, %0"
+                 : "=&s"(saved) : "s"(m), "v"(addr), "v"(one) : "memory");
+#else
+    (void)m; (void)addr; (void)one;
+#endif
+}
+
+// One pass over the raw candidates: counts below each bracket, bracket members to cand0 / cand1 (through the wave's two
+// staging lists at LDS byte address stage_lds, stage_entries keys each) and into the histograms of S.hist.
+struct RefineOut { uint32_t n_lt[2], n_in[2], n_valid; PickScale ps; };
+template <class WordKey2>
+__device__ __forceinline__ RefineOut wg_refine_s(const uint32_t* raw, int n_raw, const WordKey2& key2, float lo0, float hi0, float lo1, float hi1,
+                                                 float* cand0, float* cand1, uint32_t cap_list, uint32_t stage_lds, uint32_t stage_entries,
+                                                 SelScratch& S) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid < 5) S.misc[8 + tid] = 0;                                // [8] valid, [9] lt0, [10] lt1, [11] in0, [12] in1
+    for (int i = tid; i < 1024; i += blockDim.x) S.hist[i] = 0;
+    RefineOut r;
+    r.ps.lo[0] = lo0; r.ps.lo[1] = lo1;
+    r.ps.sc[0] = (hi0 > lo0 && lo0 > -INFINITY && hi0 < INFINITY) ? 512.0f * 0.999999f / (hi0 - lo0) : 0.0f;
+    r.ps.sc[1] = (hi1 > lo1 && lo1 > -INFINITY && hi1 < INFINITY) ? 512.0f * 0.999999f / (hi1 - lo1) : 0.0f;
+    __syncthreads();
+    RawSink s0{stage_lds, 0u, reinterpret_cast<uint32_t*>(cand0), &S.misc[11], nullptr, cap_list, stage_entries};
+    RawSink s1{stage_lds + 4u * stage_entries, 0u, reinterpret_cast<uint32_t*>(cand1), &S.misc[12], nullptr, cap_list, stage_entries};
+    const float vlo0 = in_vgpr(lo0), vhi0 = in_vgpr(hi0), vlo1 = in_vgpr(lo1), vhi1 = in_vgpr(hi1);
+    const float psl0 = in_vgpr(r.ps.lo[0]), psc0 = in_vgpr(r.ps.sc[0]), psl1 = in_vgpr(r.ps.lo[1]), psc1 = in_vgpr(r.ps.sc[1]);
+    const uint32_t hist_lds = lds_address(S.hist);
+    uint32_t one = 1u;
+    asm("" : "+v"(one));
+    uint32_t lt0 = 0, lt1 = 0, nv = 0;                               // wave-uniform
+    constexpr int U = 4;                                             // raw words per lane and trip
+    const int step = (int)blockDim.x * U;
+    const int last = n_raw > 0 ? n_raw - 1 : 0;
+    int i0 = (tid - lane) * U;                                       // wave-uniform trip count
+    uint32_t wn[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) wn[u] = raw[min(i0 + u * 64 + lane, last)];
+    for (; i0 < n_raw; i0 += step) {
+        uint32_t w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            w[u] = wn[u];
+            wn[u] = raw[min(i0 + step + u * 64 + lane, last)];       // next trip (clamped, never predicated)
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float k0, k1;
+            bool valid;
+            key2.of_word(w[u], k0, k1, valid);
+            const bool inb = i0 + u * 64 + lane < n_raw;
+            const unsigned long long mv = __builtin_amdgcn_ballot_w64(valid) & __builtin_amdgcn_ballot_w64(inb);
+            const unsigned long long l0 = __builtin_amdgcn_ballot_w64(k0 < vlo0) & mv, l1 = __builtin_amdgcn_ballot_w64(k1 < vlo1) & mv;
+            const unsigned long long m0 = __builtin_amdgcn_ballot_w64(k0 <= vhi0) & ~l0 & mv, m1 = __builtin_amdgcn_ballot_w64(k1 <= vhi1) & ~l1 & mv;
+            nv += (uint32_t)__popcll(mv);
+            lt0 += (uint32_t)__popcll(l0);
+            lt1 += (uint32_t)__popcll(l1);
+            lds_count_masked(m0, hist_lds + 4u * (uint32_t)pick_bin(k0, psl0, psc0), one);
+            lds_count_masked(m1, hist_lds + 2048u + 4u * (uint32_t)pick_bin(k1, psl1, psc1), one);
+            s0.put_value(m0, __float_as_uint(k0), lane);
+            s1.put_value(m1, __float_as_uint(k1), lane);
+        }
+    }
+    s0.flush(lane);
+    s1.flush(lane);
+    if (lane == 0) { if (nv) atomicAdd(&S.misc[8], nv); if (lt0) atomicAdd(&S.misc[9], lt0); if (lt1) atomicAdd(&S.misc[10], lt1); }
+    __threadfence_block();
+    __syncthreads();
+    r.n_lt[0] = S.misc[9]; r.n_lt[1] = S.misc[10]; r.n_in[0] = S.misc[11]; r.n_in[1] = S.misc[12]; r.n_valid = S.misc[8];
+    __syncthreads();
+    return r;
+}
 
 // ------------------------------------------------------------------------------------------
 // Vahadane: sparse-NMF dictionary (vahadane_stain_extractor.py:35-36, spams.trainDL K=2, lambda1,
@@ -2035,7 +2324,7 @@ static __global__ __launch_bounds__(kSweepThreads, 4) void k_select(StatsArgs a)
         const uint8_t* src = a.rgb + (size_t)tile * a.P * 3;
         int c0, c1;
         part_range((a.P + 3) >> 2, a.parts, part, c0, c1);
-        RawSink sink{lds_address(s_stage[wave]), 0u, a.raw + (size_t)tile * a.cap_raw, &st.n_raw, &st.overflow, (uint32_t)a.cap_raw};
+        RawSink sink{lds_address(s_stage[wave]), 0u, a.raw + (size_t)tile * a.cap_raw, &st.n_raw, &st.overflow, (uint32_t)a.cap_raw, (uint32_t)kStageWave};
         if ((size_t)a.P * 3 >= kStreamBytes) select_sweep<STAGE, ALIGNED, kPhaseTrip, true>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, K, sink);
         else select_sweep<STAGE, ALIGNED, kPhaseTrip, false>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, K, sink);
         sink.flush(lane);
@@ -2400,7 +2689,7 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
     auto run_select = [&](auto stage_tag, const uint8_t* src, SelConsts& K) {
         constexpr int STAGE = decltype(stage_tag)::value;
         K.lo0 = uni(sh.lo[0]); K.hi0 = uni(sh.hi[0]); K.lo1 = uni(sh.lo[1]); K.hi1 = uni(sh.hi[1]);
-        RawSink sink{lds_address(sh.stage[wave]), 0u, rawl, &sh.n_raw, &sh.overflow, (uint32_t)a.cap_raw};
+        RawSink sink{lds_address(sh.stage[wave]), 0u, rawl, &sh.n_raw, &sh.overflow, (uint32_t)a.cap_raw, (uint32_t)kStageWave};
         if (stream) select_sweep<STAGE, ALIGNED, kFusedTrip, true>(src, a.P, 0, nch, tid, NT, TB, a.ylimf, K, sink);
         else select_sweep<STAGE, ALIGNED, kFusedTrip, false>(src, a.P, 0, nch, tid, NT, TB, a.ylimf, K, sink);
         sink.flush(lane);
@@ -2532,35 +2821,38 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
                     prio_finish();
                 }
                 SL_PHASE(3);
-                // ---------------- finish 2: exact angular percentiles -> M
+                // ---------------- finish 2: exact angular percentiles -> M  (see "Finish 2 of the fused kernel" above wg_refine_s)
                 const uint32_t T = (uint32_t)sh.sum[0];
                 long long k[2];
                 double gfrac[2];
                 percentile_pos((double)T, 100.0 - a.pct, k[0], gfrac[0]);
                 percentile_pos((double)T, a.pct, k[1], gfrac[1]);
+                fin_tab_build(sh.tab);                                        // the row table's space: one-copy table + member staging
+                const FinTab FT{lds_address(&sh.tab)};
+                const uint32_t stage_lds = lds_address(&sh.tab) + kFinTabBytes + (uint32_t)wave * fin_stage_bytes(NT);
+                const uint32_t stage_entries = fin_stage_bytes(NT) / 8u;      // two lists per wave
                 AngleTileKey tkey;
-                tkey.src = src; tkey.tab = view_of_b(sh.tab); tkey.ylimf = a.ylimf;
-                RawAngleKeyT rkey;
-                rkey.raw = rawl; rkey.tab = view_of_b(sh.tab); rkey.ylimf = a.ylimf;
+                tkey.src = src; tkey.tab = FT.view(); tkey.ylimf = a.ylimf;
+                WordAngleKey rkey;
+                rkey.T = FT; rkey.ylimf = a.ylimf;
                 for (int i = 0; i < 6; ++i) { tkey.V[i] = sh.Vf[i]; rkey.V[i] = sh.Vf[i]; }
                 const bool complete = sh.n_raw <= (uint32_t)a.cap_raw && sh.overflow == 0;
                 const uint32_t n_raw = sh.n_raw < (uint32_t)a.cap_raw ? sh.n_raw : (uint32_t)a.cap_raw;
                 const float los[2] = {sh.lo[0], sh.lo[1]}, his[2] = {sh.hi[0], sh.hi[1]};
-                uint32_t n_lt[2], n_in[2], n_tis;
                 SL_SUB(2);
-                wg_refine((int)n_raw, rkey, los, his, cand0, cand1, (uint32_t)a.cap_list, n_lt, n_in, sh.S, &n_tis);
+                const RefineOut ra = wg_refine_s(rawl, (int)n_raw, rkey, los[0], his[0], los[1], his[1], cand0, cand1, (uint32_t)a.cap_list, stage_lds,
+                                                 stage_entries, sh.S);
                 SL_SUB(3);
-                // plain = tissue pixels the sweep did not collect: they sit between the two brackets (the list also holds
-                // pixels collected for their concentrations; those with an angle key count like any other candidate)
-                const long long base[2] = {0, (long long)T - (long long)n_tis};
-                for (int li = 0; li < 2; ++li) {
-                    float xa, xb;
-                    stage_order_stats(li ? cand1 : cand0, n_in[li], (uint32_t)a.cap_list, complete, los[li], his[li], base[li] + n_lt[li], a.P, tkey,
-                                      T, k[li], xa, xb, fallbacks, sh.S);
-                    if (tid == 0) { sh.res[2 * li] = xa; sh.res[2 * li + 1] = xb; }
+                {
+                    // plain = tissue pixels the sweep did not collect: they sit between the two brackets (the list also holds
+                    // pixels collected for their concentrations; those with an angle key count like any other candidate)
+                    const long long lt[2] = {(long long)ra.n_lt[0], (long long)T - (long long)ra.n_valid + (long long)ra.n_lt[1]};
+                    float res[4];
+                    stage_pick2<false>(cand0, cand1, ra.n_in, (uint32_t)a.cap_list, complete, los, his, lt, a.P, tkey, T, k, ra.ps, res, fallbacks, sh.S);
+                    if (tid == 0) { sh.res[0] = res[0]; sh.res[1] = res[1]; sh.res[2] = res[2]; sh.res[3] = res[3]; }
                     __syncthreads();
-                    SL_SUB(4 + li);
                 }
+                SL_SUB(5);
                 if (tid < 64) {
                     double M[6];
                     stain_matrix_from_angles(sh.Vd, sh.res, gfrac, M, tid);
@@ -2581,39 +2873,33 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
                     double gc;
                     percentile_pos((double)a.P, 99.0, kc, gc);
                     const long long kc2 = kc + 1 < (long long)a.P ? kc + 1 : kc;
-                    RawConcKey2 ckey2;
-                    ckey2.raw = rawl; ckey2.tab = view_of_b(sh.tab); ckey2.L = sh.L;
+                    WordConcKey ckey2;
+                    ckey2.T = FT; ckey2.L = sh.L;
                     const float cl[2] = {sh.mk.L[0], sh.mk.L[1]}, chh[2] = {sh.mk.H[0], sh.mk.H[1]};
-                    uint32_t c_lt[2], c_in[2];
-                    wg_refine((int)n_raw, ckey2, cl, chh, cand0, cand1, (uint32_t)a.cap_list, c_lt, c_in, sh.S);
+                    const RefineOut rc = wg_refine_s(rawl, (int)n_raw, ckey2, cl[0], chh[0], cl[1], chh[1], cand0, cand1, (uint32_t)a.cap_list,
+                                                     stage_lds, stage_entries, sh.S);
                     SL_SUB(14);
 #ifdef SL_DEBUG_SUBCLK
-                    if (a.phase_clock && tid == 0) {      // list sizes beside the clocks (slots 8..11 are clocks only on the resweep path)
+                    if (a.phase_clock && tid == 0) {      // list sizes beside the clocks, x 100: the tools scale by 0.01 (slots 8..11 are clocks only on the resweep path)
                         long long* q = a.phase_clock + (size_t)a.n_tiles * 8 + (size_t)tile * 16;
-                        q[8] = n_raw; q[9] = n_raw; q[10] = n_in[0] + n_in[1]; q[11] = c_in[0] + c_in[1];
+                        q[8] = 100ll * ra.n_valid; q[9] = 100ll * n_raw; q[10] = 100ll * (ra.n_in[0] + ra.n_in[1]); q[11] = 100ll * (rc.n_in[0] + rc.n_in[1]);
                     }
 #endif
                     const long long n_plain = (long long)a.P - (long long)sh.n_raw;       // proven below both brackets
+                    const long long clt[2] = {n_plain + rc.n_lt[0], n_plain + rc.n_lt[1]};
                     bool covered = true;
 #pragma unroll
-                    for (int col = 0; col < 2; ++col) {
-                        const long long lt = n_plain + c_lt[col];
-                        covered = covered & (kc >= lt) & (kc2 < lt + (long long)c_in[col]) & (c_in[col] <= (uint32_t)a.cap_list);
-                    }
+                    for (int col = 0; col < 2; ++col)
+                        covered = covered & (kc >= clt[col]) & (kc2 < clt[col] + (long long)rc.n_in[col]) & (rc.n_in[col] <= (uint32_t)a.cap_list);
                     if (covered) {
                         ConcTileKey ctk;
-                        ctk.src = src; ctk.tab = view_of_b(sh.tab); ctk.L = sh.L;
-                        for (int col = 0; col < 2; ++col) {
-                            ctk.col = col;
-                            float xa, xb;
-                            stage_order_stats(col ? cand1 : cand0, c_in[col], (uint32_t)a.cap_list, true, cl[col], chh[col], n_plain + c_lt[col], a.P,
-                                              ctk, (uint32_t)a.P, kc, xa, xb, fallbacks, sh.S);
-                            if (tid == 0) { sh.res[2 * col] = xa; sh.res[2 * col + 1] = xb; }
-                            __syncthreads();
-                        }
+                        ctk.src = src; ctk.tab = FT.view(); ctk.L = sh.L; ctk.col = 0;
+                        const long long kk[2] = {kc, kc};
+                        float res[4];
+                        stage_pick2<true>(cand0, cand1, rc.n_in, (uint32_t)a.cap_list, true, cl, chh, clt, a.P, ctk, (uint32_t)a.P, kk, rc.ps, res, fallbacks, sh.S);
                         if (tid == 0) {
-                            sh.maxC[0] = np_lerp((double)sh.res[0], (double)sh.res[1], gc);   // normalizer.py:36,47
-                            sh.maxC[1] = np_lerp((double)sh.res[2], (double)sh.res[3], gc);
+                            sh.maxC[0] = np_lerp((double)res[0], (double)res[1], gc);   // normalizer.py:36,47
+                            sh.maxC[1] = np_lerp((double)res[2], (double)res[3], gc);
                             if (!(sh.maxC[0] > 0.0) || !(sh.maxC[1] > 0.0)) sh.status = SL_TILE_ZERO_MAXC;
                         }
                     } else if (tid == 0) {
@@ -2622,6 +2908,7 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
                     __syncthreads();
                     SL_SUB(15);
                 }
+                fin_tab_expand<NT>(sh.tab);                                   // the row table back for the sweeps to come
             }
         } else {
             // ---------------- Vahadane: class-moment dictionary learning

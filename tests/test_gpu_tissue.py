@@ -135,9 +135,11 @@ def test_full_size_tile_of_mirrored_tissue_both_schedules():
     assert torch.equal(outs[0], outs[1])
     Mo = so.macenko_stain_matrix(T)
     np.testing.assert_allclose(M.cpu().numpy()[0], Mo, rtol=0, atol=M_ATOL)
-    # mirror tiling repeats every pixel four times: the statistics of the tile are those of the image
-    np.testing.assert_allclose(M.cpu().numpy()[0], g["M"], rtol=0, atol=M_ATOL)
-    np.testing.assert_allclose(mc.cpu().numpy()[0], g["maxC"].reshape(2), rtol=MAXC_RTOL)
+    # (mirror tiling repeats every pixel four times; the percentiles interpolate at other positions, so the image's own M is
+    #  only close: ~5e-6)
+    np.testing.assert_allclose(M.cpu().numpy()[0], g["M"], rtol=0, atol=5e-5)
+    C = so.get_concentrations(T, Mo)
+    np.testing.assert_allclose(mc.cpu().numpy()[0], np.percentile(C, 99, axis=0), rtol=MAXC_RTOL)
     on = so.ExtractiveStainNormalizer("macenko")
     on.stain_matrix_target, on.maxC_target = Mt[0].cpu().numpy(), mct[0].cpu().numpy().reshape(1, 2)
     u8_parity(outs[0][0].cpu().numpy(), on.transform(T), label="mirrored tissue 1024^2 (oracle)")

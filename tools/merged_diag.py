@@ -45,10 +45,16 @@ if hasattr(lib, "sl_debug_set_phase_clock"):
     sub_build = hasattr(lib, "sl_debug_bclk")
     buf = torch.zeros((n * 24,), dtype=torch.int64, device="cuda")
     lib.sl_debug_set_phase_clock.argtypes = [C.c_void_p]
+    z = (C.c_ulonglong * 16)()
+    if sub_build:
+        lib.sl_debug_bclk.argtypes = [C.c_void_p, C.c_int]
+        lib.sl_debug_bclk(z, 1)                                   # reset the bracket step timers
     lib.sl_debug_set_phase_clock(C.c_void_p(buf.data_ptr()))
     engine.macenko_transform(rgb, Mt[0], mct[0], out=out, params=p)
     torch.cuda.synchronize()
     lib.sl_debug_set_phase_clock(C.c_void_p(0))
+    if sub_build:
+        lib.sl_debug_bclk(z, 0)
     tall = buf.cpu().numpy().astype(np.float64) * 0.01
     t = tall[: n * 8].reshape(n, 8)
     if sub_build:
@@ -58,8 +64,12 @@ if hasattr(lib, "sl_debug_set_phase_clock"):
                  ("F1 conc brackets", ph[:, 2] - sub[:, 13]), ("F2 pre", sub[:, 2] - ph[:, 3]), ("F2 refine angle", sub[:, 3] - sub[:, 2]),
                  ("F2 pick angle", sub[:, 5] - sub[:, 3]), ("F2 M + verify", sub[:, 6] - sub[:, 5]), ("F2b refine conc", sub[:, 14] - sub[:, 6]),
                  ("F2b pick conc", sub[:, 15] - sub[:, 14]), ("F2b tail -> apply", ph[:, 6] - sub[:, 15])]
-        cnt = tall[n * 8:].reshape(n, 16)[:, 8:12] * 100.0       # slots 8..11: raw counts written by the kernel (not clocks)
-        print("    per tile: angle candidates %.0f, concentration candidates %.0f, angle members %.0f, concentration members %.0f" % tuple(cnt.mean(0)))
+        cnt = tall[n * 8:].reshape(n, 16)[:, 8:12]       # slots 8..11: list sizes x 100 written by the kernel (not clocks)
+        print("    per tile: raw entries with an angle key %.0f, raw entries %.0f, angle members %.0f, concentration members %.0f" % tuple(cnt.mean(0)))
+        if True:
+            bz = np.array(list(z), dtype=np.float64) * 0.01 / n
+            print("    bracket steps per tile (us, summed over the two calls): " + " ".join(f"[{i}] {x:.1f}" for i, x in enumerate(bz[:8])),
+                  " ([5]/[6] key evaluation angle/conc, [0] min-max, [1] coarse histogram, [2] locate, [3] refinement histogram, [4] locate)")
         h2 = n // 2
         for nm, v in steps:
             print(f"    {nm:20s} {v.mean():8.1f}   first half {v[:h2].mean():8.1f}  second half {v[h2:].mean():8.1f}")
