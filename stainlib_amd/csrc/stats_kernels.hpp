@@ -2669,6 +2669,178 @@ struct FusedShared {
     MergedConc mk;
 };
 
+// wave-uniform values arrive in VGPRs at an out-of-line function: back to SGPRs
+template <class T>
+__device__ __forceinline__ T* uni_ptr(T* p) {
+    const unsigned long long v = (unsigned long long)(uintptr_t)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return (T*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double uni_d(double x) {
+    const unsigned long long v = (unsigned long long)__double_as_longlong(x);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// Finish 1 of the merged schedule after the eigenvectors: brackets and thresholds into sh.lo / sh.hi / sh.mk.
+template <int NT>
+__device__ __noinline__ void fused_finish1(FusedShared<NT>* shp, uint32_t* samp_, int n_sample_, int stride_log2_, int P_, float ylimf_, double pct_, double lam_,
+                                           long long* subclk_) {
+    FusedShared<NT>& sh = *shp;
+    uint32_t* samp = uni_ptr(samp_);
+    const int n_sample = __builtin_amdgcn_readfirstlane(n_sample_), stride_log2 = __builtin_amdgcn_readfirstlane(stride_log2_), P = __builtin_amdgcn_readfirstlane(P_);
+    const float ylimf = uni(ylimf_);
+    const double pct = uni_d(pct_), lam = uni_d(lam_);
+    long long* subclk = uni_ptr(subclk_);
+    const int tid = threadIdx.x;
+#ifdef SL_DEBUG_SUBCLK
+#define SL_SUB(j) { __syncthreads(); if (subclk && tid == 0) subclk[(j)] = wall_clock64(); }
+#else
+#define SL_SUB(j)
+#endif
+    (void)subclk;
+    {
+        SampleAngleKey key;
+        key.sample = samp; key.tab = view_of_b(sh.tab); key.cps_log2 = stride_log2 - 2; key.P = P; key.ylimf = ylimf;
+        for (int i = 0; i < 6; ++i) key.V[i] = sh.Vf[i];
+        float lo[2], hi[2];
+        angle_brackets<NT>(key, n_sample, pct, lo, hi, sh.S);
+        if (tid == 0) { sh.lo[0] = lo[0]; sh.hi[0] = hi[0]; sh.lo[1] = lo[1]; sh.hi[1] = hi[1]; }
+        __syncthreads();
+    }
+    SL_SUB(12);
+    // ---------------- the box of stain matrices the sample leaves possible, concentration brackets under its centre
+    if (tid < 64) merged_box(sh.Vd, sh.lo, sh.hi, lam, tid, sh.mk);
+    __syncthreads();
+    SL_SUB(13);
+    if (sh.mk.ok) {                                               // block-uniform
+        SampleConcKey ckey;
+        ckey.sample = samp; ckey.tab = view_of_b(sh.tab); ckey.L = sh.mk.Lc; ckey.cps_log2 = stride_log2 - 2;
+        ckey.P = P; ckey.col = 0;
+        float lo[2], hi[2];
+        conc_brackets<NT>(ckey, n_sample, lo, hi, sh.S);
+        if (tid == 0) merged_thresholds(sh.mk, lo[0], lo[1], hi[0], hi[1]);
+    } else if (tid == 0) {
+        merged_thresholds(sh.mk, -INFINITY, -INFINITY, -INFINITY, -INFINITY);       // disarms the concentration test
+    }
+    __syncthreads();
+#undef SL_SUB
+}
+
+// Finish 2 of the merged schedule for the tile whose state sits in *shp: returns the number of slow exact fallbacks.
+// Leaves sh.M, sh.status, sh.conc_done (and sh.maxC, sh.L when conc_done) behind and the row table rebuilt.
+template <int NT>
+__device__ __noinline__ int fused_finish2(FusedShared<NT>* shp, const uint8_t* src_, uint32_t* rawl_, float* cand0_, float* cand1_, int P_, int cap_raw_,
+                                          int cap_list_, float ylimf_, double pct_, double lam_, long long* subclk_) {
+    FusedShared<NT>& sh = *shp;
+    const uint8_t* src = uni_ptr(src_);
+    uint32_t* rawl = uni_ptr(rawl_);
+    float* cand0 = uni_ptr(cand0_);
+    float* cand1 = uni_ptr(cand1_);
+    const int P = __builtin_amdgcn_readfirstlane(P_), cap_raw = __builtin_amdgcn_readfirstlane(cap_raw_), cap_list = __builtin_amdgcn_readfirstlane(cap_list_);
+    const float ylimf = uni(ylimf_);
+    const double pct = uni_d(pct_), lam = uni_d(lam_);
+    long long* subclk = uni_ptr(subclk_);
+    const int tid = threadIdx.x, wave = tid >> 6;
+    int fallbacks = 0;
+#ifdef SL_DEBUG_SUBCLK
+#define SL_SUB(j) { __syncthreads(); if (subclk && tid == 0) subclk[(j)] = wall_clock64(); }
+#else
+#define SL_SUB(j)
+#endif
+    (void)subclk;
+    // ---------------- finish 2: exact angular percentiles -> M  (see "Finish 2 of the fused kernel" above wg_refine_s)
+    const uint32_t T = (uint32_t)sh.sum[0];
+    long long k[2];
+    double gfrac[2];
+    percentile_pos((double)T, 100.0 - pct, k[0], gfrac[0]);
+    percentile_pos((double)T, pct, k[1], gfrac[1]);
+    fin_tab_build(sh.tab);                                        // the row table's space: one-copy table + member staging
+    const FinTab FT{lds_address(&sh.tab)};
+    const uint32_t stage_lds = lds_address(&sh.tab) + kFinTabBytes + (uint32_t)wave * fin_stage_bytes(NT);
+    const uint32_t stage_entries = fin_stage_bytes(NT) / 8u;      // two lists per wave
+    AngleTileKey tkey;
+    tkey.src = src; tkey.tab = FT.view(); tkey.ylimf = ylimf;
+    WordAngleKey rkey;
+    rkey.T = FT; rkey.ylimf = ylimf;
+    for (int i = 0; i < 6; ++i) { tkey.V[i] = sh.Vf[i]; rkey.V[i] = sh.Vf[i]; }
+    const bool complete = sh.n_raw <= (uint32_t)cap_raw && sh.overflow == 0;
+    const uint32_t n_raw = sh.n_raw < (uint32_t)cap_raw ? sh.n_raw : (uint32_t)cap_raw;
+    const float los[2] = {sh.lo[0], sh.lo[1]}, his[2] = {sh.hi[0], sh.hi[1]};
+    SL_SUB(2);
+    const RefineOut ra = wg_refine_s(rawl, (int)n_raw, rkey, los[0], his[0], los[1], his[1], cand0, cand1, (uint32_t)cap_list, stage_lds,
+                                     stage_entries, sh.S);
+    SL_SUB(3);
+    {
+        // plain = tissue pixels the sweep did not collect: they sit between the two brackets (the list also holds
+        // pixels collected for their concentrations; those with an angle key count like any other candidate)
+        const long long lt[2] = {(long long)ra.n_lt[0], (long long)T - (long long)ra.n_valid + (long long)ra.n_lt[1]};
+        float res[4];
+        stage_pick2<false>(cand0, cand1, ra.n_in, (uint32_t)cap_list, complete, los, his, lt, P, tkey, T, k, ra.ps, res, fallbacks, sh.S);
+        if (tid == 0) { sh.res[0] = res[0]; sh.res[1] = res[1]; sh.res[2] = res[2]; sh.res[3] = res[3]; }
+        __syncthreads();
+    }
+    SL_SUB(5);
+    if (tid < 64) {
+        double M[6];
+        stain_matrix_from_angles(sh.Vd, sh.res, gfrac, M, tid);
+        if (tid == 0) {
+            for (int i = 0; i < 6; ++i) sh.M[i] = M[i];
+            if (stain_matrix_singular(M)) sh.status = SL_TILE_DEGENERATE_COV;
+            // the concentration candidates of the merged sweep are usable iff the exact M lies where the sweep assumed
+            const bool use = sh.status == SL_TILE_OK && complete && merged_verify(sh.mk, M, lam);
+            sh.conc_done = use ? 1 : 0;
+            if (use) { LassoK L; lasso_consts(M, lam, L); sh.L = L; }
+        }
+    }
+    __syncthreads();
+    SL_SUB(6);
+    if (sh.conc_done) {                                           // block-uniform
+        // ---------------- finish 2b: exact 99th percentiles of the concentrations from the same raw list
+        long long kc;
+        double gc;
+        percentile_pos((double)P, 99.0, kc, gc);
+        const long long kc2 = kc + 1 < (long long)P ? kc + 1 : kc;
+        WordConcKey ckey2;
+        ckey2.T = FT; ckey2.L = sh.L;
+        const float cl[2] = {sh.mk.L[0], sh.mk.L[1]}, chh[2] = {sh.mk.H[0], sh.mk.H[1]};
+        const RefineOut rc = wg_refine_s(rawl, (int)n_raw, ckey2, cl[0], chh[0], cl[1], chh[1], cand0, cand1, (uint32_t)cap_list,
+                                         stage_lds, stage_entries, sh.S);
+        SL_SUB(14);
+#ifdef SL_DEBUG_SUBCLK
+        if (subclk && tid == 0) {             // list sizes beside the clocks, x 100: the tools scale by 0.01 (slots 8..11 are clocks only on the resweep path)
+            long long* q = subclk;
+            q[8] = 100ll * ra.n_valid; q[9] = 100ll * n_raw; q[10] = 100ll * (ra.n_in[0] + ra.n_in[1]); q[11] = 100ll * (rc.n_in[0] + rc.n_in[1]);
+        }
+#endif
+        const long long n_plain = (long long)P - (long long)sh.n_raw;       // proven below both brackets
+        const long long clt[2] = {n_plain + rc.n_lt[0], n_plain + rc.n_lt[1]};
+        bool covered = true;
+#pragma unroll
+        for (int col = 0; col < 2; ++col)
+            covered = covered & (kc >= clt[col]) & (kc2 < clt[col] + (long long)rc.n_in[col]) & (rc.n_in[col] <= (uint32_t)cap_list);
+        if (covered) {
+            ConcTileKey ctk;
+            ctk.src = src; ctk.tab = FT.view(); ctk.L = sh.L; ctk.col = 0;
+            const long long kk[2] = {kc, kc};
+            float res[4];
+            stage_pick2<true>(cand0, cand1, rc.n_in, (uint32_t)cap_list, true, cl, chh, clt, P, ctk, (uint32_t)P, kk, rc.ps, res, fallbacks, sh.S);
+            if (tid == 0) {
+                sh.maxC[0] = np_lerp((double)res[0], (double)res[1], gc);   // normalizer.py:36,47
+                sh.maxC[1] = np_lerp((double)res[2], (double)res[3], gc);
+                if (!(sh.maxC[0] > 0.0) || !(sh.maxC[1] > 0.0)) sh.status = SL_TILE_ZERO_MAXC;
+            }
+        } else if (tid == 0) {
+            sh.conc_done = 0;                                     // a bracket missed: sweep 3 settles it
+        }
+        __syncthreads();
+        SL_SUB(15);
+    }
+    fin_tab_expand<NT>(sh.tab);                                   // the row table back for the sweeps to come
+    return fallbacks;
+#undef SL_SUB
+}
+
 enum { kMethodMacenko = 0, kMethodVahadane = 1 };
 
 // NT = 512: two workgroups per CU (the throughput configuration).  NT = 1024: one workgroup per CU, used when the batch
@@ -2780,31 +2952,15 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
             __syncthreads();
             SL_SUB(1);
             if (sh.status == SL_TILE_OK) {                                    // block-uniform
-                {
-                    SampleAngleKey key;
-                    key.sample = samp; key.tab = view_of_b(sh.tab); key.cps_log2 = a.stride_log2 - 2; key.P = a.P; key.ylimf = a.ylimf;
-                    for (int i = 0; i < 6; ++i) key.V[i] = sh.Vf[i];
-                    float lo[2], hi[2];
-                    angle_brackets<NT>(key, a.n_sample, a.pct, lo, hi, sh.S);
-                    if (tid == 0) { sh.lo[0] = lo[0]; sh.hi[0] = hi[0]; sh.lo[1] = lo[1]; sh.hi[1] = hi[1]; }
-                    __syncthreads();
-                }
-                SL_SUB(12);
-                // ---------------- the box of stain matrices the sample leaves possible, concentration brackets under its centre
-                if (tid < 64) merged_box(sh.Vd, sh.lo, sh.hi, a.lam, tid, sh.mk);
-                __syncthreads();
-                SL_SUB(13);
-                if (sh.mk.ok) {                                               // block-uniform
-                    SampleConcKey ckey;
-                    ckey.sample = samp; ckey.tab = view_of_b(sh.tab); ckey.L = sh.mk.Lc; ckey.cps_log2 = a.stride_log2 - 2;
-                    ckey.P = a.P; ckey.col = 0;
-                    float lo[2], hi[2];
-                    conc_brackets<NT>(ckey, a.n_sample, lo, hi, sh.S);
-                    if (tid == 0) merged_thresholds(sh.mk, lo[0], lo[1], hi[0], hi[1]);
-                } else if (tid == 0) {
-                    merged_thresholds(sh.mk, -INFINITY, -INFINITY, -INFINITY, -INFINITY);       // disarms the concentration test
-                }
-                __syncthreads();
+                // ---------------- finish 1, the rest of it (out of line like finish 2): angle brackets, the box of stain matrices the
+                // sample leaves possible, concentration brackets under its centre
+                fused_finish1<NT>(&sh, samp, a.n_sample, a.stride_log2, a.P, a.ylimf, a.pct, a.lam,
+#ifdef SL_DEBUG_SUBCLK
+                                  a.phase_clock ? a.phase_clock + (size_t)a.n_tiles * 8 + (size_t)tile * 16 : nullptr
+#else
+                                  nullptr
+#endif
+                                  );
                 SL_PHASE(2);
                 // ---------------- sweep 2: angle select + concentration select under the box
                 {
@@ -2821,94 +2977,15 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
                     prio_finish();
                 }
                 SL_PHASE(3);
-                // ---------------- finish 2: exact angular percentiles -> M  (see "Finish 2 of the fused kernel" above wg_refine_s)
-                const uint32_t T = (uint32_t)sh.sum[0];
-                long long k[2];
-                double gfrac[2];
-                percentile_pos((double)T, 100.0 - a.pct, k[0], gfrac[0]);
-                percentile_pos((double)T, a.pct, k[1], gfrac[1]);
-                fin_tab_build(sh.tab);                                        // the row table's space: one-copy table + member staging
-                const FinTab FT{lds_address(&sh.tab)};
-                const uint32_t stage_lds = lds_address(&sh.tab) + kFinTabBytes + (uint32_t)wave * fin_stage_bytes(NT);
-                const uint32_t stage_entries = fin_stage_bytes(NT) / 8u;      // two lists per wave
-                AngleTileKey tkey;
-                tkey.src = src; tkey.tab = FT.view(); tkey.ylimf = a.ylimf;
-                WordAngleKey rkey;
-                rkey.T = FT; rkey.ylimf = a.ylimf;
-                for (int i = 0; i < 6; ++i) { tkey.V[i] = sh.Vf[i]; rkey.V[i] = sh.Vf[i]; }
-                const bool complete = sh.n_raw <= (uint32_t)a.cap_raw && sh.overflow == 0;
-                const uint32_t n_raw = sh.n_raw < (uint32_t)a.cap_raw ? sh.n_raw : (uint32_t)a.cap_raw;
-                const float los[2] = {sh.lo[0], sh.lo[1]}, his[2] = {sh.hi[0], sh.hi[1]};
-                SL_SUB(2);
-                const RefineOut ra = wg_refine_s(rawl, (int)n_raw, rkey, los[0], his[0], los[1], his[1], cand0, cand1, (uint32_t)a.cap_list, stage_lds,
-                                                 stage_entries, sh.S);
-                SL_SUB(3);
-                {
-                    // plain = tissue pixels the sweep did not collect: they sit between the two brackets (the list also holds
-                    // pixels collected for their concentrations; those with an angle key count like any other candidate)
-                    const long long lt[2] = {(long long)ra.n_lt[0], (long long)T - (long long)ra.n_valid + (long long)ra.n_lt[1]};
-                    float res[4];
-                    stage_pick2<false>(cand0, cand1, ra.n_in, (uint32_t)a.cap_list, complete, los, his, lt, a.P, tkey, T, k, ra.ps, res, fallbacks, sh.S);
-                    if (tid == 0) { sh.res[0] = res[0]; sh.res[1] = res[1]; sh.res[2] = res[2]; sh.res[3] = res[3]; }
-                    __syncthreads();
-                }
-                SL_SUB(5);
-                if (tid < 64) {
-                    double M[6];
-                    stain_matrix_from_angles(sh.Vd, sh.res, gfrac, M, tid);
-                    if (tid == 0) {
-                        for (int i = 0; i < 6; ++i) sh.M[i] = M[i];
-                        if (stain_matrix_singular(M)) sh.status = SL_TILE_DEGENERATE_COV;
-                        // the concentration candidates of the merged sweep are usable iff the exact M lies where the sweep assumed
-                        const bool use = sh.status == SL_TILE_OK && complete && merged_verify(sh.mk, M, a.lam);
-                        sh.conc_done = use ? 1 : 0;
-                        if (use) { LassoK L; lasso_consts(M, a.lam, L); sh.L = L; }
-                    }
-                }
-                __syncthreads();
-                SL_SUB(6);
-                if (sh.conc_done) {                                           // block-uniform
-                    // ---------------- finish 2b: exact 99th percentiles of the concentrations from the same raw list
-                    long long kc;
-                    double gc;
-                    percentile_pos((double)a.P, 99.0, kc, gc);
-                    const long long kc2 = kc + 1 < (long long)a.P ? kc + 1 : kc;
-                    WordConcKey ckey2;
-                    ckey2.T = FT; ckey2.L = sh.L;
-                    const float cl[2] = {sh.mk.L[0], sh.mk.L[1]}, chh[2] = {sh.mk.H[0], sh.mk.H[1]};
-                    const RefineOut rc = wg_refine_s(rawl, (int)n_raw, ckey2, cl[0], chh[0], cl[1], chh[1], cand0, cand1, (uint32_t)a.cap_list,
-                                                     stage_lds, stage_entries, sh.S);
-                    SL_SUB(14);
+                // ---------------- finish 2 (out of line: its registers are allocated apart from the sweeps'): exact angular percentiles
+                // -> M, then the concentration percentiles -> maxC from the same raw list
+                fallbacks += fused_finish2<NT>(&sh, src, rawl, cand0, cand1, a.P, a.cap_raw, a.cap_list, a.ylimf, a.pct, a.lam,
 #ifdef SL_DEBUG_SUBCLK
-                    if (a.phase_clock && tid == 0) {      // list sizes beside the clocks, x 100: the tools scale by 0.01 (slots 8..11 are clocks only on the resweep path)
-                        long long* q = a.phase_clock + (size_t)a.n_tiles * 8 + (size_t)tile * 16;
-                        q[8] = 100ll * ra.n_valid; q[9] = 100ll * n_raw; q[10] = 100ll * (ra.n_in[0] + ra.n_in[1]); q[11] = 100ll * (rc.n_in[0] + rc.n_in[1]);
-                    }
+                                               a.phase_clock ? a.phase_clock + (size_t)a.n_tiles * 8 + (size_t)tile * 16 : nullptr
+#else
+                                               nullptr
 #endif
-                    const long long n_plain = (long long)a.P - (long long)sh.n_raw;       // proven below both brackets
-                    const long long clt[2] = {n_plain + rc.n_lt[0], n_plain + rc.n_lt[1]};
-                    bool covered = true;
-#pragma unroll
-                    for (int col = 0; col < 2; ++col)
-                        covered = covered & (kc >= clt[col]) & (kc2 < clt[col] + (long long)rc.n_in[col]) & (rc.n_in[col] <= (uint32_t)a.cap_list);
-                    if (covered) {
-                        ConcTileKey ctk;
-                        ctk.src = src; ctk.tab = FT.view(); ctk.L = sh.L; ctk.col = 0;
-                        const long long kk[2] = {kc, kc};
-                        float res[4];
-                        stage_pick2<true>(cand0, cand1, rc.n_in, (uint32_t)a.cap_list, true, cl, chh, clt, a.P, ctk, (uint32_t)a.P, kk, rc.ps, res, fallbacks, sh.S);
-                        if (tid == 0) {
-                            sh.maxC[0] = np_lerp((double)res[0], (double)res[1], gc);   // normalizer.py:36,47
-                            sh.maxC[1] = np_lerp((double)res[2], (double)res[3], gc);
-                            if (!(sh.maxC[0] > 0.0) || !(sh.maxC[1] > 0.0)) sh.status = SL_TILE_ZERO_MAXC;
-                        }
-                    } else if (tid == 0) {
-                        sh.conc_done = 0;                                     // a bracket missed: sweep 3 settles it
-                    }
-                    __syncthreads();
-                    SL_SUB(15);
-                }
-                fin_tab_expand<NT>(sh.tab);                                   // the row table back for the sweeps to come
+                                               );
             }
         } else {
             // ---------------- Vahadane: class-moment dictionary learning
