@@ -990,7 +990,26 @@ struct SelConsts {          // everything VGPR-resident (in_vgpr)
     float lo0, hi0, lo1, hi1;
     // merged stage (see MergedConc): at_i = u[i][0] t0 + u[i][1] t1 + kt[i] with t = V^T od; plain <=> at_i + eps[i] (|at_1| + |at_2|) < thr[i]
     float u[2][2], kt[2], eps[2], thr[2];
+    // merged stage, XBOUND variant: every tissue pixel has t0 = V1 . od > xmin (see tissue_x_bound), so the sweep needs no gamma values
+    float xmin;
 };
+
+// A lower bound on the first projection of every TISSUE pixel, valid when the first eigenvector has only positive components:
+// tissue <=> 871 gR + 2929 gG + 296 gB < ylimf  =>  the smallest gamma is below ylimf / 4096  =>  one byte is <= b*, the largest
+// byte whose gamma is  =>  one optical density is >= od(b*), and with all three weights positive and all densities > 0
+// V1 . od >= min(V1) od(b*).  Returns -inf when no bound holds (the caller then keeps the per-pixel tissue test).
+__device__ __forceinline__ float tissue_x_bound(const float* Vf /*[6]*/, float ylimf, const TabView& tab) {
+    const float vmin = fminf(fminf(Vf[0], Vf[2]), Vf[4]);
+    if (!(vmin > 0.0f)) return -INFINITY;
+    const float gf = ylimf * (1.0f / 4096.0f);
+    if (!(tab.gam(0) < gf)) return INFINITY;                 // no byte can make a pixel tissue
+    int lo = 0, hi = 255;                                    // invariant: gam(lo) < gf; the tables are monotone
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab.gam((uint32_t)mid) < gf) lo = mid; else hi = mid - 1;
+    }
+    return vmin * tab.odf((uint32_t)lo) * (1.0f - 1e-6f);    // (the binary32 evaluation of V1 . od adds positive terms: relative error 2e-7)
+}
 
 // Sweeps 2/3.  The sweep does NOT evaluate the selection keys of every pixel.  A cheap conservative
 // test proves, for ~97 % of the pixels, on which side of both brackets their keys fall; those are
@@ -1006,8 +1025,12 @@ template <int STAGE> struct SelGather;
 template <> struct SelGather<kStageAngle> { float2 v[12]; };      // {gamma, od32} per byte
 template <> struct SelGather<kStageConc> { float v[12]; };        // od32 per byte
 template <> struct SelGather<kStageMerged> { float2 v[12]; };
+struct SelGatherOd { float v[12]; };                             // merged stage with the projection bound: od32 only
 
-template <int STAGE, bool ALIGNED, int kTrip, bool STREAM = false, class TR, class Sink>
+// XBOUND (merged stage only): angle candidates are the pixels with t0 > K.xmin outside the plain cone instead of the tissue
+// pixels outside it -- a superset (the finish evaluates the tissue test of every candidate exactly) that costs three
+// instructions less per pixel and reads 4-byte table entries.
+template <int STAGE, bool ALIGNED, int kTrip, bool STREAM = false, bool XBOUND = false, class TR, class Sink>
 __device__ __forceinline__ void select_sweep(const uint8_t* src, int P, int c0, int c1, int t, int nthreads,
                                              const TR& T, float ylimf, const SelConsts& K, Sink& sink) {
     const size_t nbytes = (size_t)P * 3;
@@ -1018,16 +1041,19 @@ __device__ __forceinline__ void select_sweep(const uint8_t* src, int P, int c0, 
     const float clo0 = conc_ok ? K.lo0 : -INFINITY, clo1 = conc_ok ? K.lo1 : -INFINITY;
     const int w0 = __builtin_amdgcn_readfirstlane(c0 + (t & ~63));
     auto fetch = [&](int cc) { return load_chunk_clamped<ALIGNED, STREAM>(src, nbytes, cc, c1); };   // dead lanes: see `live`
+    static_assert(!XBOUND || STAGE == kStageMerged, "");
+    using GatherT = std::conditional_t<XBOUND, SelGatherOd, SelGather<STAGE>>;
+    const float xmin = in_vgpr(K.xmin);
     auto gather = [&](const Chunk& ch) {
-        SelGather<STAGE> g;
+        GatherT g;
 #pragma unroll
         for (int i = 0; i < 12; ++i) {
-            if constexpr (STAGE != kStageConc) g.v[i] = T.gam_odf(T.addr(ch, i));
+            if constexpr (STAGE != kStageConc && !XBOUND) g.v[i] = T.gam_odf(T.addr(ch, i));
             else g.v[i] = T.odf(T.addr(ch, i));
         }
         return g;
     };
-    auto compute = [&](auto tail_tag, const Chunk& ch, const SelGather<STAGE>& g, int cc) {
+    auto compute = [&](auto tail_tag, const Chunk& ch, const GatherT& g, int cc) {
         constexpr bool TAIL = decltype(tail_tag)::value;
 #pragma unroll
         for (int px = 0; px < 4; ++px) {
@@ -1042,6 +1068,20 @@ __device__ __forceinline__ void select_sweep(const uint8_t* src, int P, int c0, 
                 const float t0 = fmaf(nhi0m, d, y), t1 = fmaf(nlo1m, d, y);
                 const bool pp = fminf(fminf(x, t0), -t1) > 0.0f;             // x > 0, y > hi0m d, y < lo1m d
                 m = __builtin_amdgcn_ballot_w64(tc) & ~__builtin_amdgcn_ballot_w64(pp);
+            } else if constexpr (STAGE == kStageMerged && XBOUND) {
+                const float er = g.v[3 * px], eg = g.v[3 * px + 1], eb = g.v[3 * px + 2];
+                const float x = fmaf(K.V[4], eb, fmaf(K.V[2], eg, K.V[0] * er));
+                const float y = fmaf(K.V[5], eb, fmaf(K.V[3], eg, K.V[1] * er));
+                const float d = x + fabsf(y);
+                const float t0 = fmaf(nhi0m, d, y), t1 = fmaf(nlo1m, d, y);
+                const bool cone = fminf(t0, -t1) > 0.0f;                     // y > hi0m d, y < lo1m d  (x > xmin > 0 comes with `big`)
+                const bool big = x > xmin;
+                const float a1 = fmaf(K.u[0][1], y, fmaf(K.u[0][0], x, K.kt[0]));
+                const float a2 = fmaf(K.u[1][1], y, fmaf(K.u[1][0], x, K.kt[1]));
+                const float sa = fabsf(a1) + fabsf(a2);
+                const bool g1 = fmaf(K.eps[0], sa, a1) >= K.thr[0], g2 = fmaf(K.eps[1], sa, a2) >= K.thr[1];
+                m = (__builtin_amdgcn_ballot_w64(big) & ~__builtin_amdgcn_ballot_w64(cone)) | __builtin_amdgcn_ballot_w64(g1) |
+                    __builtin_amdgcn_ballot_w64(g2);
             } else if constexpr (STAGE == kStageMerged) {
                 // the angle test of sweep 2 and, from the same two projections, a conservative test on the concentrations
                 // under a stain matrix that is only known to lie in a box around its sample estimate (MergedConc)
@@ -1082,7 +1122,7 @@ __device__ __forceinline__ void select_sweep(const uint8_t* src, int P, int c0, 
     Chunk cur[kTrip], nx[kTrip];                             // see moments_sweep
 #pragma unroll
     for (int k = 0; k < kTrip; ++k) { cur[k] = fetch(w0 + lane + k * nthreads); nx[k] = fetch(w0 + lane + (kTrip + k) * nthreads); }
-    SelGather<STAGE> g[2];
+    GatherT g[2];
     g[0] = gather(cur[0]);
     auto trip = [&](auto tail_tag, int cb) {
 #pragma unroll
@@ -1466,10 +1506,13 @@ struct RawSink {
     __device__ __forceinline__ void put_value(unsigned long long m, uint32_t value, int lane) {
         const uint32_t cnt = (uint32_t)__popcll(m);
         if (__builtin_expect(n + cnt > stage_cap, 0)) flush(lane);   // rare, out of line; a row holds <= 64 entries
-        // fill level + rank of this lane among the flagged lanes: the fill level rides in as v_mbcnt's addend
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, n));
+        // rank of this lane among the flagged lanes; the fill level joins the buffer address on the scalar unit (as v_mbcnt's
+        // addend it cost a v_mov per row: two SGPR operands do not fit one VOP3)
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 #if defined(__HIP_DEVICE_COMPILE__)
-        const uint32_t addr = buf + 4u * rank;
+        uint32_t sbase;                                      // buf + 4 n on the scalar unit (the compiler would fold it back into the vector side)
+        asm("s_lshl2_add_u32 %0, %1, %2" : "=s"(sbase) : "s"(n), "s"(buf) : "scc");
+        const uint32_t addr = sbase + 4u * rank;
         unsigned long long saved;
         asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_write_b32 %2, %3\n\ts_mov_b64 exec, %0"
                      : "=&s"(saved) : "s"(m), "v"(addr), "v"(value) : "memory");
@@ -1583,6 +1626,7 @@ __device__ __forceinline__ RefineOut wg_refine_s(const uint32_t* raw, int n_raw,
     r.ps.sc[0] = (hi0 > lo0 && lo0 > -INFINITY && hi0 < INFINITY) ? 512.0f * 0.999999f / (hi0 - lo0) : 0.0f;
     r.ps.sc[1] = (hi1 > lo1 && lo1 > -INFINITY && hi1 < INFINITY) ? 512.0f * 0.999999f / (hi1 - lo1) : 0.0f;
     __syncthreads();
+    stage_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)stage_lds);
     RawSink s0{stage_lds, 0u, reinterpret_cast<uint32_t*>(cand0), &S.misc[11], nullptr, cap_list, stage_entries};
     RawSink s1{stage_lds + 4u * stage_entries, 0u, reinterpret_cast<uint32_t*>(cand1), &S.misc[12], nullptr, cap_list, stage_entries};
     const float vlo0 = in_vgpr(lo0), vhi0 = in_vgpr(hi0), vlo1 = in_vgpr(lo1), vhi1 = in_vgpr(hi1);
@@ -2313,6 +2357,7 @@ static __global__ __launch_bounds__(kSweepThreads, 4) void k_select(StatsArgs a)
         TileState& st = a.state[tile];
         if (st.status != SL_TILE_OK) continue;                             // block-uniform
         SelConsts K;
+        K.xmin = -INFINITY;
         if (STAGE == kStageAngle) {
             for (int i = 0; i < 6; ++i) K.V[i] = in_vgpr(st.Vf[i]);
             K.L.g12 = 0.0f;
@@ -2324,7 +2369,7 @@ static __global__ __launch_bounds__(kSweepThreads, 4) void k_select(StatsArgs a)
         const uint8_t* src = a.rgb + (size_t)tile * a.P * 3;
         int c0, c1;
         part_range((a.P + 3) >> 2, a.parts, part, c0, c1);
-        RawSink sink{lds_address(s_stage[wave]), 0u, a.raw + (size_t)tile * a.cap_raw, &st.n_raw, &st.overflow, (uint32_t)a.cap_raw, (uint32_t)kStageWave};
+        RawSink sink{(uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(s_stage[wave])), 0u, a.raw + (size_t)tile * a.cap_raw, &st.n_raw, &st.overflow, (uint32_t)a.cap_raw, (uint32_t)kStageWave};
         if ((size_t)a.P * 3 >= kStreamBytes) select_sweep<STAGE, ALIGNED, kPhaseTrip, true>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, K, sink);
         else select_sweep<STAGE, ALIGNED, kPhaseTrip, false>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, K, sink);
         sink.flush(lane);
@@ -2666,6 +2711,7 @@ struct FusedShared {
     LassoK L;
     int status;
     int conc_done;           // the merged sweep's candidates settled maxC: sweep 3 is skipped
+    float xmin;              // tissue_x_bound of the tile (merged sweep)
     MergedConc mk;
 };
 
@@ -2705,7 +2751,10 @@ __device__ __noinline__ void fused_finish1(FusedShared<NT>* shp, uint32_t* samp_
         for (int i = 0; i < 6; ++i) key.V[i] = sh.Vf[i];
         float lo[2], hi[2];
         angle_brackets<NT>(key, n_sample, pct, lo, hi, sh.S);
-        if (tid == 0) { sh.lo[0] = lo[0]; sh.hi[0] = hi[0]; sh.lo[1] = lo[1]; sh.hi[1] = hi[1]; }
+        if (tid == 0) {
+            sh.lo[0] = lo[0]; sh.hi[0] = hi[0]; sh.lo[1] = lo[1]; sh.hi[1] = hi[1];
+            sh.xmin = tissue_x_bound(sh.Vf, ylimf, view_of_b(sh.tab));
+        }
         __syncthreads();
     }
     SL_SUB(12);
@@ -2861,9 +2910,15 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
     auto run_select = [&](auto stage_tag, const uint8_t* src, SelConsts& K) {
         constexpr int STAGE = decltype(stage_tag)::value;
         K.lo0 = uni(sh.lo[0]); K.hi0 = uni(sh.hi[0]); K.lo1 = uni(sh.lo[1]); K.hi1 = uni(sh.hi[1]);
-        RawSink sink{lds_address(sh.stage[wave]), 0u, rawl, &sh.n_raw, &sh.overflow, (uint32_t)a.cap_raw, (uint32_t)kStageWave};
-        if (stream) select_sweep<STAGE, ALIGNED, kFusedTrip, true>(src, a.P, 0, nch, tid, NT, TB, a.ylimf, K, sink);
-        else select_sweep<STAGE, ALIGNED, kFusedTrip, false>(src, a.P, 0, nch, tid, NT, TB, a.ylimf, K, sink);
+        RawSink sink{(uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(sh.stage[wave])), 0u, rawl, &sh.n_raw, &sh.overflow, (uint32_t)a.cap_raw,
+                     (uint32_t)kStageWave};
+        if (STAGE == kStageMerged && K.xmin > -INFINITY) {       // block-uniform: the projection bound stands in for the tissue test
+            if (stream) select_sweep<kStageMerged, ALIGNED, kFusedTrip, true, true>(src, a.P, 0, nch, tid, NT, TB, a.ylimf, K, sink);
+            else select_sweep<kStageMerged, ALIGNED, kFusedTrip, false, true>(src, a.P, 0, nch, tid, NT, TB, a.ylimf, K, sink);
+        } else {
+            if (stream) select_sweep<STAGE, ALIGNED, kFusedTrip, true>(src, a.P, 0, nch, tid, NT, TB, a.ylimf, K, sink);
+            else select_sweep<STAGE, ALIGNED, kFusedTrip, false>(src, a.P, 0, nch, tid, NT, TB, a.ylimf, K, sink);
+        }
         sink.flush(lane);
         __threadfence_block();
         __syncthreads();
@@ -2967,6 +3022,7 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
                     SelConsts K;
                     for (int i = 0; i < 6; ++i) K.V[i] = in_vgpr(sh.Vf[i]);
                     K.L.g12 = 0.0f;
+                    K.xmin = uni(sh.xmin);
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         K.u[i][0] = in_vgpr(sh.mk.u[i][0]); K.u[i][1] = in_vgpr(sh.mk.u[i][1]); K.kt[i] = in_vgpr(sh.mk.kt[i]);
@@ -3038,6 +3094,7 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
             {
                 SelConsts K;
                 K.L = sh.L;
+                K.xmin = -INFINITY;
                 vgpr(K.L);
                 prio_sweep(2);
                 run_select(std::integral_constant<int, kStageConc>{}, src, K);
