@@ -13,11 +13,13 @@ per-tile (M, maxC, status) after the timed region (and the tiny all-reduces of -
 
 Extra objects in the JSON line:
   roofline        the dominant kernel (the fused persistent transform), timed with HIP events on its own stream INSIDE
-                  the timed region; algorithmic bytes = 15 B/px sweep model; traffic from profiles/*pmc_traffic.json
+                  the timed region; algorithmic bytes = 12 B/px (three read sweeps + one write since round 3; SURVEY 8d's sweep model
+                  had four reads: 15) + 3 B/px per tile that needed the separate concentration sweep; traffic from profiles/*pmc_traffic.json
   roofline_apply  the OD + reconstruction pass alone (6 B/px), the pass the north star prices at >= 40 %
   kernels_ms_per_step / phase_kernels_ms   per-kernel-class times (untimed instrumented passes; the second one forces the
                   one-launch-per-phase schedule so that every sweep and finish step shows separately)
-  parity          the first tile against the oracle: uint8 mismatch, stain matrix error, pre-quantisation relative error
+  parity          16 tiles of the batch against the oracle (uint8 mismatch, stain matrix / maxC error, pre-quantisation error end to end),
+                  every tile's status, and the whole batch byte for byte against the other schedule
   fallbacks       order statistics that needed the slow exact whole-tile selection, summed over the batch (SlParams.fallbacks_out)
   arithmetic      what precision the path computes in (the reference is float64 throughout)
   cpu_baseline    the numpy oracle on the box's host cores (rank 0 at N=1 only): one pinned single-thread process per
@@ -316,17 +318,29 @@ def secondary_configs(dev, Mt, mct):
     out = torch.empty((512, 1024, 1024, 3), dtype=torch.uint8, device=dev)
     wss = engine.Workspace()
     structured = {}
-    for kind in ("blobs", "white_bg", "quantized"):
-        four = np.stack([so.structured_tile(kind, 1024, 1024, 20 + s) for s in range(4)])
+    def real_tissue_four():
+        """Four 1024^2 tiles made of the REAL stained-tissue fixture (scikit-image's ihc.png, tests/golden/tissue_ihc_512.npz) by
+        mirror tiling: the image itself, two rolled copies and its transpose."""
+        I = np.load(os.path.join(REPO, "tests", "golden", "tissue_ihc_512.npz"))["input"]
+        row = np.concatenate([I, I[:, ::-1]], axis=1)
+        T = np.ascontiguousarray(np.concatenate([row, row[::-1]], axis=0))
+        return np.stack([T, np.ascontiguousarray(np.roll(T, 301, axis=0)), np.ascontiguousarray(np.roll(T, 517, axis=1)),
+                         np.ascontiguousarray(T.transpose(1, 0, 2))])
+
+    for kind in ("blobs", "white_bg", "quantized", "real_tissue_ihc"):
+        four = real_tissue_four() if kind == "real_tissue_ihc" else np.stack([so.structured_tile(kind, 1024, 1024, 20 + s) for s in range(4)])
         rgb = torch.as_tensor(four, device=dev)[torch.arange(512, device=dev) % 4].contiguous()
         p = engine.make_params()
         fb = engine.attach_fallbacks(p, 512, device=dev)
+        rsw = torch.zeros((512,), dtype=torch.int32, device=dev)
+        p.resweeps_out = rsw.data_ptr()
         ms = _timed(lambda: engine.macenko_transform(rgb, Mt_d, mct_d, params=p, out=out, ws=wss), reps=5)
         o, Mg, mcg, st = engine.macenko_transform(rgb, Mt_d, mct_d, params=p, out=out, ws=wss)
         on = so.ExtractiveStainNormalizer("macenko")
         on.stain_matrix_target, on.maxC_target = Mt_np, mct_np.reshape(1, 2)
         structured[kind] = {"ms_per_batch": round(ms, 4), "tiles_per_s": round(512 / ms * 1e3, 1), "failed_tiles": int((st != 0).sum()),
-                            "exact_fallbacks": int(fb.sum()), "of": 2048, "parity_tile0": _flips(o[0].cpu().numpy(), on.transform(four[0]))}
+                            "exact_fallbacks": int(fb.sum()), "of": 2048, "resweeps": int(rsw.sum()),
+                            "parity_tile0": _flips(o[0].cpu().numpy(), on.transform(four[0]))}
         del rgb
     structured["note"] = ("oracle.structured_tile: 'blobs' = nuclei, slow eosin gradients, a lumen, little noise (neighbouring pixels strongly "
                           "correlated); 'white_bg' = 35 % saturated background; 'quantized' = JPEG-like colour ties.  A 12-colour palette "
@@ -465,6 +479,8 @@ def main():
     ev = HipEvents(2 * n_groups_max * max(a.steps, 1))
     params = _ffi.default_params()
     fallbacks = engine.attach_fallbacks(params, B, device=dev)
+    resweeps = torch.zeros((B,), dtype=torch.int32, device=dev)     # tiles whose concentration percentiles needed the separate sweep 3
+    params.resweeps_out = resweeps.data_ptr()
 
     def step(p):
         return engine.macenko_transform(rgb, Mt, mct, params=p, out=out, ws=ws)
@@ -501,6 +517,7 @@ def main():
     status = res[3]
     n_bad = int((status != 0).sum())
     n_fallbacks = int(fallbacks.sum())
+    n_resweeps = int(resweeps.sum())
 
     per_rank = [B * a.steps / t_mine]
     if world > 1:
@@ -567,11 +584,14 @@ def main():
             phase[f"{i}:{_ffi.PROF_NAMES[tag]}"] = round(ms, 4)
         params.profile = None
 
-        # dominant kernel: whole fused transform (15 B/px sweep model: 4 dependent read sweeps + 1 write,
-        # SURVEY 8d) -- or, for the per-phase schedule, its k_apply launches (6 B/px)
+        # dominant kernel: whole fused transform.  Since round 3 a tile is read THREE times (moments + sample; the merged selection
+        # sweep that collects the angular and the concentration candidates; apply) and written once: 12 B/px algorithmic, plus 3 B/px
+        # for every tile that needed the separate concentration sweep (resweeps, counted below; SURVEY 8d's sweep model had 15).
+        # For the per-phase schedule the dominant kernel is its k_apply launches (6 B/px)
         fused = [(t, ms) for tag, t, ms in timed_pairs if tag == _ffi.PROF_FUSED_TRANSFORM]
         if fused:
-            dom_name, bpp = "k_macenko_fused<transform> (mask+moments, angle select, conc select, apply: 4 sweeps + 1 write)", 15.0
+            bpp = 12.0 + 3.0 * n_resweeps / max(B, 1)
+            dom_name = "k_macenko_fused<transform> (mask+moments+sample, merged angle/concentration select, apply: 3 read sweeps + 1 write)"
             dom = fused
         else:
             dom_name, bpp = "k_apply (OD + reconstruction pass)", 6.0
@@ -590,7 +610,7 @@ def main():
         # HBM traffic from PMC counters: collected in separate rocprofv3 --pmc passes (profiles/*_pmc_traffic.json
         # documents command, units and the gfx950 FETCH_SIZE correction), scaled to this launch's pixel count
         traffic_dom = traffic_ap = traffic_src = None
-        for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
             try:
                 pmc = json.load(open(os.path.join(REPO, "profiles", name)))["kernels"]
                 if fused:
@@ -605,22 +625,50 @@ def main():
 
         parity = None
         if world == 1:
+            # ---- the bench line polices itself: 16 tiles drawn from the batch against the oracle (statistics, bytes, and the
+            # pre-quantisation error END TO END, i.e. with the GPU's own (M, maxC) in the exponent), every tile's status, and the
+            # whole batch byte for byte against the other schedule
             step(params)                                                 # (the apply timing above overwrote `out`)
             torch.cuda.synchronize()
-            I = rgb[0].cpu().numpy()
+            out_fused = out.clone()
+            M_gpu, mc_gpu = res[1].cpu().numpy(), res[2].cpu().numpy()
+            p_other = engine.make_params(schedule=1)
+            o_other, M_o, mc_o, st_o = engine.macenko_transform(rgb, Mt, mct, params=p_other, out=out, ws=ws)
+            torch.cuda.synchronize()
+            schedules_equal = bool(torch.equal(out_fused, o_other))
+            sched_M_diff = float((res[1] - M_o).abs().max().item())      # (the binary64 moment sums are added in another order)
+            checksum = int(out_fused.sum(dtype=torch.int64).item())
+            pick = sorted(np.random.RandomState(12345).choice(B, size=min(16, B), replace=False).tolist())
             nrm = so.ExtractiveStainNormalizer("macenko")
             nrm.stain_matrix_target, nrm.maxC_target = Mt.cpu().numpy(), mct.cpu().numpy().reshape(1, 2)
-            det = {}
-            want = nrm.transform(I, details=det)
-            got = out[0].cpu().numpy()
-            d = np.abs(got.astype(np.int16) - want.astype(np.int16))
-            # pre-quantisation error of the per-pixel arithmetic: the apply pass given the oracle's own (M, maxC)
-            _, pre = engine.normalize_apply(rgb[:1], det["M_src"][None], det["maxC_src"].reshape(1, 2), Mt, mct, want_prequant=True)
-            rel = np.abs(pre[0].cpu().numpy() - det["prequant"]) / np.maximum(np.abs(det["prequant"]), 1e-30)
-            parity = {"tile": 0, "u8_mismatch_rate": float((d != 0).mean()), "u8_bytes_differ": int((d != 0).sum()), "u8_max_abs_diff": int(d.max()),
-                      "M_src_max_abs_err": float(np.abs(res[1][0].cpu().numpy() - det["M_src"]).max()),
-                      "maxC_src_max_rel_err": float(np.abs(res[2][0].cpu().numpy() / det["maxC_src"].reshape(2) - 1).max()),
-                      "prequant_max_rel_err": float(rel.max()), "north_star_tolerance": 1e-4}
+            worst = {"u8_bytes_differ": 0, "u8_max_abs_diff": 0, "M_src_max_abs_err": 0.0, "maxC_src_max_rel_err": 0.0,
+                     "prequant_max_rel_err_end_to_end": 0.0, "prequant_max_rel_err_given_oracle_statistics": 0.0}
+            n_bytes = 0
+            for i in pick:
+                I = rgb[i].cpu().numpy()
+                det = {}
+                want = nrm.transform(I, details=det)
+                got = out_fused[i].cpu().numpy()
+                d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+                n_bytes = d.size
+                _, pre_e2e = engine.normalize_apply(rgb[i:i + 1], res[1][i:i + 1], res[2][i:i + 1], Mt, mct, want_prequant=True)
+                _, pre_or = engine.normalize_apply(rgb[i:i + 1], det["M_src"][None], det["maxC_src"].reshape(1, 2), Mt, mct, want_prequant=True)
+                den = np.maximum(np.abs(det["prequant"]), 1e-30)
+                worst["u8_bytes_differ"] = max(worst["u8_bytes_differ"], int((d != 0).sum()))
+                worst["u8_max_abs_diff"] = max(worst["u8_max_abs_diff"], int(d.max()))
+                worst["M_src_max_abs_err"] = max(worst["M_src_max_abs_err"], float(np.abs(M_gpu[i] - det["M_src"]).max()))
+                worst["maxC_src_max_rel_err"] = max(worst["maxC_src_max_rel_err"], float(np.abs(mc_gpu[i] / det["maxC_src"].reshape(2) - 1).max()))
+                worst["prequant_max_rel_err_end_to_end"] = max(worst["prequant_max_rel_err_end_to_end"],
+                                                               float((np.abs(pre_e2e[0].cpu().numpy() - det["prequant"]) / den).max()))
+                worst["prequant_max_rel_err_given_oracle_statistics"] = max(worst["prequant_max_rel_err_given_oracle_statistics"],
+                                                                            float((np.abs(pre_or[0].cpu().numpy() - det["prequant"]) / den).max()))
+            parity = {"tiles_checked": len(pick), "tiles": pick, "bytes_per_tile": n_bytes, "worst": worst,
+                      "worst_u8_mismatch_rate": worst["u8_bytes_differ"] / max(n_bytes, 1),
+                      "all_tile_status_ok": bool(n_bad == 0),
+                      "fused_equals_per_phase_schedule_on_the_whole_batch": schedules_equal, "schedules_M_max_abs_diff": sched_M_diff,
+                      "batch_byte_sum": checksum,
+                      "north_star_tolerance": 1e-4}
+            del out_fused
 
         line = {
             "metric": "1024x1024 H&E tiles/sec normalized (Macenko)",
@@ -656,10 +704,11 @@ def main():
                                "avg_launch_ms": round(ap_ms, 5), "launches_timed": 10},
             "end_to_end": {"per_gpu_tiles_per_s": round(per_gpu, 1),
                            "frac_hbm_compulsory_6Bpx": round(per_gpu * 6.0 * P / 1e9 / HBM_PEAK_GBS, 4),
-                           "frac_hbm_sweep_model_15Bpx": round(per_gpu * 15.0 * P / 1e9 / HBM_PEAK_GBS, 4)},
+                           "frac_hbm_sweep_model_12Bpx": round(per_gpu * 12.0 * P / 1e9 / HBM_PEAK_GBS, 4)},
             "kernels_ms_per_step": {k: round(v, 4) for k, v in sorted(per.items())},
             "phase_kernels_ms": phase,
             "fallbacks": {"order_statistics_on_the_slow_exact_path": n_fallbacks, "of": 4 * B * world,
+                          "tiles_that_needed_the_separate_concentration_sweep": n_resweeps, "of_tiles": B,
                           "note": "i.i.d. synthetic tiles never need it; heavy colour ties (palette images) do -- see tests"},
             "parity": parity,
             "distributed": {"backend": (dist.get_backend() if world > 1 else None), "world_size": (dist.get_world_size() if world > 1 else 1),
