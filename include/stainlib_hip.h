@@ -123,13 +123,21 @@ typedef struct SlParams {
                                    concentration candidates in ONE sweep under a sample estimate of the stain matrix and repeats
                                    the concentration part when the exact matrix falls outside the assumed box; diagnostics).
                                    Written by the fused schedule of sl_macenko_*; left untouched otherwise. */
+    int32_t fused_min_tiles;    /* schedule == 0 only: batches of at least this many tiles run the persistent fused kernel, smaller ones
+                                   one launch per phase.  0 (default) = the library's measured crossovers on an MI355X at its 1400 W
+                                   power state (tools/crossover.py, profiles/r03_crossover.txt): Macenko 384 tiles of >= 512 Ki pixels
+                                   (288 for smaller tiles), Vahadane 640 (192).  Results do not depend on the schedule. */
+    int32_t reserved_;          /* 0 */
 } SlParams;
 
 SL_API int sl_version(void);
 SL_API const char* sl_error_string(int code);
 SL_API void sl_default_params(SlParams* p);
 
-/* Bytes of device workspace an op needs for n tiles of h x w.  0 for ops that need none. */
+/* Bytes of device workspace an op needs for n tiles of h x w.  0 for ops that need none.
+ * The layout depends on the number of compute units of the CURRENT HIP device (persistent grids are sized to it): call this
+ * with the device current on which the operator will be launched (same partition mode); a workspace sized under another
+ * device may be refused with SL_ERR_WORKSPACE, never overrun. */
 SL_API size_t sl_workspace_bytes(int op, int n_tiles, int h, int w);
 
 /* MacenkoStainExtractor.get_stain_matrix (extraction/macenko_stain_extractor.py:7-44)
@@ -243,7 +251,8 @@ SL_API int sl_standardize_brightness(const uint8_t* rgb, uint8_t* out, int n, in
 
 /* get_mean_std (utils/stain_utils.py:174-186; cv2.meanStdDev of the lab_split planes: population std), optionally of the
  * brightness-standardised tile (standardize != 0: what ReinhardStainNormalizer.fit / transform feed it, normalizer.py:65-66,78-80).
- *   stats_out n x 8 double: p90 (NaN when !standardize), mean L, a, b, std L, a, b, 0 */
+ *   stats_out n x 8 double: p90 (NaN when !standardize), mean L, a, b, std L, a, b, and the number of tissue pixels of the
+ *   (standardised) tile at luminosity threshold 0.8 (what transform(mask_background=True) tests for emptiness) */
 SL_API int sl_reinhard_stats(const uint8_t* rgb, int n, int h, int w, int standardize, double* stats_out,
                       void* workspace, size_t workspace_bytes, void* stream);
 

@@ -43,6 +43,8 @@ class SlParams(C.Structure):
         ("profile", C.POINTER(SlProfile)),
         ("fallbacks_out", C.c_void_p),
         ("resweeps_out", C.c_void_p),
+        ("fused_min_tiles", C.c_int32),
+        ("reserved_", C.c_int32),
     ]
 
 

@@ -42,6 +42,9 @@ class ColorAugmenterBase(AugmenterBase):
     """augmenter.py:72-84."""
 
 
+_CUTOFF_BAND = 5e-6      # relative distance to a cutoff bound below which the reference's float32 mean is re-evaluated on the host
+
+
 def _checked(title, rng, lowest):
     """One interval of the constructor: None passes; otherwise a pair lo <= hi inside [lowest, 1]."""
     if rng is not None:
@@ -101,10 +104,11 @@ class HedColorAugmenter(ColorAugmenterBase):
                                                 skimage_mode=self._skimage_mode, want_sums=True)
         ok = bool(int(applied[0]))
         # The device tests the EXACT mean (integer byte sum); the reference tests np.mean of the float32 image / 255
-        # (augmenter.py:291-293), which carries ~1e-7 of rounding.  Within 1e-6 of a bound the reference's own value decides.
+        # (augmenter.py:291-293), whose pairwise binary32 sum can be off by ~2e-6 relative on a large patch.  Within _CUTOFF_BAND of
+        # a bound the reference's own value decides (one host mean, only then).
         exact = float(int(sums[0])) / patch.size / 255.0
         lo, hi = self._cutoff_range
-        if min(abs(exact - lo), abs(exact - hi)) <= 1e-6 * max(abs(lo), abs(hi), 1e-30):
+        if min(abs(exact - lo), abs(exact - hi)) <= _CUTOFF_BAND * max(abs(lo), abs(hi), 1e-30):
             ref_mean = np.mean(a=patch.astype(dtype=np.float32)) / 255.0
             ref_ok = bool(lo <= ref_mean <= hi)
             if ref_ok and not ok:                                     # transform after all: no cutoff this time
@@ -122,8 +126,28 @@ class HedColorAugmenter(ColorAugmenterBase):
         n = tiles.shape[0]
         sigmas = [self._sigmas] * n if sigmas is None else sigmas
         biases = [self._biases] * n if biases is None else biases
-        return engine.hed_augment(tiles, sigmas, biases, cutoff=self._cutoff_range,
-                                  skimage_mode=self._skimage_mode, out=out)
+        out, applied, sums = engine.hed_augment(tiles, sigmas, biases, cutoff=self._cutoff_range,
+                                                skimage_mode=self._skimage_mode, out=out, want_sums=True)
+        # The same knife-edge rule as transform(): a tile whose EXACT mean lies within _CUTOFF_BAND of a cutoff bound is decided by
+        # the reference's own expression (the float32 mean, augmenter.py:291-293) on the host, so that a tile gets the same answer
+        # alone and in a batch.  Costs one 8-byte-per-tile read-back per call; tiles near a bound are rare.
+        import torch
+        lo, hi = self._cutoff_range
+        exact = sums.to(torch.float64) / float(tiles.shape[1] * tiles.shape[2] * 3) / 255.0
+        band = _CUTOFF_BAND * max(abs(lo), abs(hi), 1e-30)
+        near = torch.nonzero(torch.minimum((exact - lo).abs(), (exact - hi).abs()) <= band).reshape(-1).tolist()
+        for i in near:
+            patch = tiles[i].cpu().numpy()
+            ref_mean = np.mean(a=patch.astype(dtype=np.float32)) / 255.0
+            ref_ok = bool(lo <= ref_mean <= hi)
+            if ref_ok and not int(applied[i]):
+                engine.hed_augment(tiles[i:i + 1], [sigmas[i]], [biases[i]], cutoff=(-np.inf, np.inf), skimage_mode=self._skimage_mode,
+                                   out=out[i:i + 1])
+                applied[i] = 1
+            elif not ref_ok and int(applied[i]):
+                out[i].copy_(tiles[i])                                    # augmenter.py:331: the patch comes back unchanged
+                applied[i] = 0
+        return out, applied
 
     def randomize_batch(self, n):
         """n successive randomize() calls (same global stream order) -> (n,3) sigmas, (n,3) biases."""

@@ -40,7 +40,7 @@ struct Layout {
 
 size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
-Layout make_layout(int n, long P, int method = kMethodMacenko, int schedule = 0) {
+Layout make_layout(int n, long P, int method = kMethodMacenko, int schedule = 0, int fused_min_tiles = 0) {
     Layout L;
     L.max_grid = max_resident_grid();
     L.parts = parts_for(P);
@@ -57,7 +57,9 @@ Layout make_layout(int n, long P, int method = kMethodMacenko, int schedule = 0)
     if (g > n) g = n;
     if (g < 1) g = 1;
     L.G = (int)g;
-    const int min_fused = method == kMethodVahadane ? (P >= (1L << 19) ? kDictFusedMinTiles : kDictFusedMinTilesSmall) : (P >= (1L << 19) ? kFusedMinTiles : kFusedMinTilesSmall);
+    const int min_fused = fused_min_tiles > 0 ? fused_min_tiles        // SlParams.fused_min_tiles; the defaults are the measured crossovers
+                        : method == kMethodVahadane ? (P >= (1L << 19) ? kDictFusedMinTiles : kDictFusedMinTilesSmall)
+                                                    : (P >= (1L << 19) ? kFusedMinTiles : kFusedMinTilesSmall);
     L.fused = (schedule == 2) || (schedule != 1 && n >= min_fused);
     L.grid = n < L.max_grid ? n : L.max_grid;
     const size_t slots = L.fused ? (size_t)L.grid : (size_t)L.G;     // candidate buffers: per workgroup / per tile of a group
@@ -268,7 +270,7 @@ extern "C" int sl_macenko_fit(const uint8_t* rgb, int n, int h, int w, const SlP
                               double* maxC_out, int32_t* status, void* workspace, size_t workspace_bytes,
                               void* stream) {
     const long P = (long)h * w;
-    const Layout L = (n > 0 && h > 0 && w > 0) ? make_layout(n, P, kMethodMacenko, params ? params->schedule : 0) : Layout{};
+    const Layout L = (n > 0 && h > 0 && w > 0) ? make_layout(n, P, kMethodMacenko, params ? params->schedule : 0, params ? params->fused_min_tiles : 0) : Layout{};
     int rc = check_common(rgb, n, h, w, workspace, workspace_bytes, L.total);
     if (rc) return rc;
     SlParams p;
@@ -294,7 +296,7 @@ extern "C" int sl_macenko_transform(const uint8_t* rgb, uint8_t* out, int n, int
                                     double* maxC_src_out, int32_t* status, void* workspace, size_t workspace_bytes,
                                     void* stream) {
     const long P = (long)h * w;
-    const Layout L = (n > 0 && h > 0 && w > 0) ? make_layout(n, P, kMethodMacenko, params ? params->schedule : 0) : Layout{};
+    const Layout L = (n > 0 && h > 0 && w > 0) ? make_layout(n, P, kMethodMacenko, params ? params->schedule : 0, params ? params->fused_min_tiles : 0) : Layout{};
     int rc = check_common(rgb, n, h, w, workspace, workspace_bytes, L.total);
     if (rc) return rc;
     if (!out || !M_tgt || !maxC_tgt) return SL_ERR_BADARG;
@@ -328,7 +330,7 @@ extern "C" int sl_vahadane_fit(const uint8_t* rgb, int n, int h, int w, const Sl
                                double* maxC_out, int32_t* status, int32_t* sweeps_out, void* workspace,
                                size_t workspace_bytes, void* stream) {
     const long P = (long)h * w;
-    const Layout L = (n > 0 && h > 0 && w > 0) ? make_layout(n, P, kMethodVahadane, params ? params->schedule : 0) : Layout{};
+    const Layout L = (n > 0 && h > 0 && w > 0) ? make_layout(n, P, kMethodVahadane, params ? params->schedule : 0, params ? params->fused_min_tiles : 0) : Layout{};
     int rc = check_common(rgb, n, h, w, workspace, workspace_bytes, L.total);
     if (rc) return rc;
     SlParams p;
@@ -354,7 +356,7 @@ extern "C" int sl_vahadane_transform(const uint8_t* rgb, uint8_t* out, int n, in
                                      double* maxC_src_out, int32_t* status, void* workspace, size_t workspace_bytes,
                                      void* stream) {
     const long P = (long)h * w;
-    const Layout L = (n > 0 && h > 0 && w > 0) ? make_layout(n, P, kMethodVahadane, params ? params->schedule : 0) : Layout{};
+    const Layout L = (n > 0 && h > 0 && w > 0) ? make_layout(n, P, kMethodVahadane, params ? params->schedule : 0, params ? params->fused_min_tiles : 0) : Layout{};
     int rc = check_common(rgb, n, h, w, workspace, workspace_bytes, L.total);
     if (rc) return rc;
     if (!out || !M_tgt || !maxC_tgt) return SL_ERR_BADARG;

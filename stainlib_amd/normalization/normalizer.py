@@ -17,7 +17,9 @@ _METHODS = ("macenko", "vahadane")
 # A single image of this many pixels or more is not handled as ONE tile (whose finish steps run on one workgroup and
 # grow with the tile) but as the vertical concatenation of its row bands: the pooled slide statistics are, by
 # definition, the reference's statistics of that concatenation, i.e. of the image itself -- computed with chip-wide
-# sweeps only (8192 x 8192: 1.9 instead of 4.9 ms; stain matrix equal to 3e-15, maxC to the bit).  The pooled path is
+# sweeps only (8192 x 8192: 1.9 instead of 4.9 ms).  The two paths agree to the rounding of the binary32 burst sums of the
+# moments (stain matrix ~1e-7, maxC ~1e-6 relative: tests/test_gpu_macenko.py::test_large_single_image_goes_through_the_pooled_statistics),
+# so results step by that much at this size; both are within 2e-6 of the reference.  The pooled path is
 # host-driven (~1.3 ms whatever the size), so it only pays from the measured crossover on (tools/big_image.py:
 # 4096^2 1.27 vs 1.58 ms, 6144^2 3.4 vs 1.9 ms).
 BIG_IMAGE_PIXELS = 5 << 22        # ~21 Mpx

@@ -96,6 +96,17 @@ def get_concentrations(I, stain_matrix, regularizer=0.01):
     return C[0].cpu().numpy().astype(np.float64)
 
 
+def get_sign(x):
+    """The sign of a scalar: +1, -1 or 0 (None for NaN, like the chain of comparisons of stain_utils.py:80-91)."""
+    if x > 0:
+        return +1
+    if x < 0:
+        return -1
+    if x == 0:
+        return 0
+    return None
+
+
 def normalize_matrix_rows(A):
     """stain_utils.py:93-99 (six numbers: host arithmetic)."""
     A = np.asarray(A, dtype=np.float64)

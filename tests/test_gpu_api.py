@@ -454,3 +454,35 @@ def test_c_abi_error_codes():
     assert transform() == 0
     torch.cuda.synchronize()
     assert torch.equal(out, good)
+
+
+def test_hed_cutoff_knife_edge_single_and_batch_agree():
+    """Tiles whose mean sits on or within a few 1e-7 of a cutoff bound (augmenter.py:291-293 tests np.mean of the float32 image):
+    transform() and transform_batch() give the same decision and the same bytes, and both follow the reference's expression."""
+    import stainlib_amd as sl
+    h = w = 64
+    n_bytes = h * w * 3
+    tiles = []
+    for extra in (-2, -1, 0, 1, 2):                      # byte sums around mean / 255 == 0.95 exactly (242.25 * n_bytes)
+        t = np.full(n_bytes, 242, np.uint8)
+        t[: n_bytes // 4 + extra] = 243
+        tiles.append(np.random.RandomState(extra + 5).permutation(t).reshape(h, w, 3))
+    for extra in (-1, 0, 1):                             # and around the lower bound 0.05 (12.75 * n_bytes)
+        t = np.full(n_bytes, 12, np.uint8)
+        t[: 3 * n_bytes // 4 + extra] = 13
+        tiles.append(np.random.RandomState(extra + 50).permutation(t).reshape(h, w, 3))
+    a = sl.HedLighterColorAugmenter()
+    np.random.seed(3)
+    a.randomize()
+    outs, applied = a.transform_batch(to_dev(tiles))
+    outs, applied = outs.cpu().numpy(), applied.cpu().numpy()
+    decisions = []
+    for i, t in enumerate(tiles):
+        ref_mean = np.mean(a=t.astype(dtype=np.float32)) / 255.0
+        ref_ok = bool(0.05 <= ref_mean <= 0.95)
+        single = a.transform(t)
+        assert (single is not t) == ref_ok, (i, ref_mean)
+        assert bool(applied[i]) == ref_ok, (i, ref_mean)
+        assert np.array_equal(outs[i], single if ref_ok else t)
+        decisions.append(ref_ok)
+    assert any(decisions) and not all(decisions)         # the set straddles the bounds

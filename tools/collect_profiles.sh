@@ -44,7 +44,7 @@ for pass in "f:FETCH_SIZE" "w:WRITE_SIZE" "s1:SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_W
 done
 # the same two traffic counters on the one-launch-per-phase schedule at 64 tiles (192 MB: fits the Infinity Cache) and 512
 for n in 64 512; do
-  rm -rf /tmp/pm_$n; timeout 300 rocprofv3 --pmc FETCH_SIZE -d /tmp/pm_$n -o p -- python tools/run_multi.py $n 1 > /dev/null 2>&1
+  rm -rf /tmp/pm_$n; timeout 300 rocprofv3 --pmc FETCH_SIZE -d /tmp/pm_$n -o p -- python tools/run_fused_once.py $n 1 > /dev/null 2>&1
   python tools/pmc_summary.py "$(ls /tmp/pm_$n/*/*.db /tmp/pm_$n/*.db 2>/dev/null | head -1)" > "$out/${tag}_pmc_phase_fetch_n$n.txt" 2>&1
 done
 python tools/make_pmc_traffic.py "$tag" "$out" > "$out/${tag}_pmc_traffic.json" 2> /dev/null
