@@ -125,8 +125,8 @@ typedef struct SlParams {
                                    Written by the fused schedule of sl_macenko_*; left untouched otherwise. */
     int32_t fused_min_tiles;    /* schedule == 0 only: batches of at least this many tiles run the persistent fused kernel, smaller ones
                                    one launch per phase.  0 (default) = the library's measured crossovers on an MI355X at its 1400 W
-                                   power state (tools/crossover.py, profiles/r03_crossover.txt): Macenko 384 tiles of >= 512 Ki pixels
-                                   (288 for smaller tiles), Vahadane 640 (192).  Results do not depend on the schedule. */
+                                   power state (tools/crossover.py, profiles/r03_crossover.txt): Macenko 320 tiles, Vahadane 640 (192 for tiles
+                                   below 512 Ki pixels).  Results do not depend on the schedule. */
     int32_t reserved_;          /* 0 */
 } SlParams;
 
@@ -306,6 +306,32 @@ SL_API int sl_slide_key_window(const uint8_t* rgb, int n, int h, int w, const Sl
  * above key_ords[t]) (key_ords: HOST pointer, 2 values). */
 SL_API int sl_slide_key_next_above(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int keyset,
                             const double* basis, const uint32_t* key_ords, uint32_t* min_out, void* stream);
+
+/* ---- the same pooled statistics, DEVICE-DRIVEN: no host read-back between the steps ----------------------------
+ * `state` is SL_POOL_STATE_DOUBLES doubles of device memory owned by the caller.  One computation is the chain
+ *     [sum of sl_tile_moments over the local tiles, pixel count appended: 11 doubles]  -> all-reduce ->  sl_pool_begin
+ *     for keyset in (SL_KEYSET_ANGLE, SL_KEYSET_CONC):
+ *         for round in 0, 1, 2:  sl_pool_histogram (sampled, 2 x 256)  -> all-reduce ->  sl_pool_pick
+ *         sl_pool_window (2 x 65536 + 2)  -> all-reduce ->  sl_pool_resolve
+ * enqueued on one stream; every decision (eigenvectors, which bin holds the rank, where the window sits, whether it caught the
+ * ranks, the stain matrix, maxC) is taken on the device from all-reduced data, so every rank reaches the same state.  Afterwards
+ * state[SL_POOL_M .. +5] is the slide's stain matrix, state[SL_POOL_MAXC .. +1] its 99th-percentile concentrations,
+ * state[SL_POOL_STATUS] a SL_TILE_* code and state[SL_POOL_MISS] != 0 says a window missed its rank (an estimate off by more than
+ * 32768 consecutive binary32 values, or an empty sample): the caller then takes the host-driven radix rounds above.  ONE read-back,
+ * at the end.  The sweeps are the kernels of sl_slide_key_histogram_sampled / sl_slide_key_window reading their basis, prefixes
+ * and windows from `state`. */
+#define SL_POOL_STATE_DOUBLES 64
+#define SL_POOL_M 0
+#define SL_POOL_MAXC 6
+#define SL_POOL_STATUS 8
+#define SL_POOL_MISS 9
+SL_API int sl_pool_begin(const double* moments11, const SlParams* params, double* state, void* stream);
+SL_API int sl_pool_histogram(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int keyset, const double* state,
+                      int round, int sample_log2, unsigned long long* hist, void* stream);
+SL_API int sl_pool_pick(double* state, int keyset, int round, const unsigned long long* hist_reduced, void* stream);
+SL_API int sl_pool_window(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int keyset, const double* state,
+                   unsigned long long* hist_below, void* stream);
+SL_API int sl_pool_resolve(double* state, int keyset, const unsigned long long* window_reduced, const SlParams* params, void* stream);
 
 #ifdef __cplusplus
 }

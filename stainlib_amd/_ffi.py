@@ -100,7 +100,14 @@ _SIGNATURES = {
                                                   C.POINTER(C.c_uint32), C.c_int, C.c_int, _P, _P]),
     "sl_slide_key_window": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(SlParams), C.c_int, C.POINTER(C.c_double),
                                        C.POINTER(C.c_uint32), _P, _P]),
+    # device-driven pooled statistics (state: SL_POOL_STATE_DOUBLES doubles on the device)
+    "sl_pool_begin": (C.c_int, [_P, C.POINTER(SlParams), _P, _P]),
+    "sl_pool_histogram": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(SlParams), C.c_int, _P, C.c_int, C.c_int, _P, _P]),
+    "sl_pool_pick": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
+    "sl_pool_window": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(SlParams), C.c_int, _P, _P, _P]),
+    "sl_pool_resolve": (C.c_int, [_P, C.c_int, _P, C.POINTER(SlParams), _P]),
 }
+POOL_STATE_DOUBLES, POOL_M, POOL_MAXC, POOL_STATUS, POOL_MISS = 64, 0, 6, 8, 9
 EXPORTS = tuple(_SIGNATURES)
 
 _lib = None

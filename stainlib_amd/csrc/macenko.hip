@@ -13,8 +13,11 @@ namespace {
 constexpr size_t kGroupBytes = (size_t)2 << 30;   // uint8 bytes of one tile group of the per-phase schedule (measured: big groups win --
                                                   // the one-workgroup-per-tile finish kernels need many tiles to fill the chip; cache reuse between sweeps does not matter)
 
-constexpr int kFusedMinTiles = 448;         // measured crossover (tools/crossover.py): below it one launch per phase wins
-constexpr int kFusedMinTilesSmall = 288;    // ... for tiles below 512 Ki pixels (256x256: 0.18 vs 0.20 ms at 256 tiles, 0.28 vs 0.25 at 384)
+// Defaults of SlParams.fused_min_tiles (documented in include/stainlib_hip.h): the measured crossovers of round 3's three-sweep fused
+// kernel on an MI355X at its 1400 W power state (tools/crossover.py, profiles/r03_crossover.txt: 1024^2 tiles 1.11 vs 1.14 ms at 256,
+// 1.64 vs 1.52 at 384; 256^2 tiles 0.22 vs 0.23 at 256, 0.32 vs 0.29 at 384).  Below them one launch per phase wins.
+constexpr int kFusedMinTiles = 320;
+constexpr int kFusedMinTilesSmall = 320;    // ... for tiles below 512 Ki pixels
 constexpr int kDictFusedMinTiles = 640;     // Vahadane: below it the dictionary sweeps run one launch per phase too (measured: 1024^2 tiles 3.70 vs
                                             // 3.85 ms at 512, 6.24 vs 5.76 at 768; in a fused launch of one tile per workgroup the few tiles
                                             // that need a third full sweep hold the whole launch, per phase they cost a short extra launch)

@@ -42,7 +42,34 @@ struct SlideArgs {
     uint32_t window_lo[2];   // window mode: histogram of key - window_lo over [window_lo, window_lo + 65536), count of keys below
     float win_flo[2], win_fhi[2];   // the same bounds as binary32 values (-inf / +inf: no cheap zone test for that target)
     uint32_t sample_mask;    // 0: every pixel; 2^s - 1: one 64-chunk row in 2^s (stratified over rows and items)
+    const double* dyn;       // NULL, or the device-resident state of a device-driven pooled computation (SL_POOL_*): the basis, prefixes
+                             // and windows are read from it by the kernel instead of coming from the host
 };
+
+// ---- layout of the device-resident pool state (doubles; include/stainlib_hip.h SL_POOL_*).  Every rank holds an identical copy:
+// each step consumes all-reduced data only.
+enum {
+    kPoolM = SL_POOL_M, kPoolMaxC = SL_POOL_MAXC, kPoolStatus = SL_POOL_STATUS, kPoolMiss = SL_POOL_MISS,
+    kPoolT = 10, kPoolNpx = 11, kPoolVd = 12, kPoolVf = 18,
+    kPoolK = 24, kPoolG = 26, kPoolTotalS = 28, kPoolKs = 30, kPoolBelow = 32, kPoolPrefix = 34, kPoolWinLo = 36, kPoolWinFlo = 38,
+    kPoolWinFhi = 40, kPoolRes = 43
+};
+static_assert(kPoolRes + 4 <= SL_POOL_STATE_DOUBLES, "");
+
+// the host-filled fields a device-driven launch takes from the pool state instead
+template <int KEYSET>
+__device__ __forceinline__ void args_from_pool_state(SlideArgs& a) {
+    const double* d = a.dyn;
+    if (!d) return;                                              // uniform
+    if (KEYSET == SL_KEYSET_ANGLE) { for (int i = 0; i < 6; ++i) a.V[i] = (float)d[kPoolVf + i]; }
+    else { for (int i = 0; i < 6; ++i) a.M[i] = d[kPoolM + i]; }
+    for (int t = 0; t < 2; ++t) {
+        a.prefix[t] = (uint32_t)d[kPoolPrefix + t];
+        a.window_lo[t] = (uint32_t)d[kPoolWinLo + t];
+        a.win_flo[t] = (float)d[kPoolWinFlo + t];
+        a.win_fhi[t] = (float)d[kPoolWinFhi + t];
+    }
+}
 
 // One target's bookkeeping of a lane: matching keys are counted in runs (neighbouring pixels mostly fall into the
 // same bin, and in the first round nearly all keys do: per-key LDS atomics on one address would serialise).
@@ -61,6 +88,7 @@ struct BinRun {
 // (a 16-bit prefix leaves ~0.2 % of the pixels: two rounds in one sweep).  (The window sweep is k_slide_window below.)
 template <int KEYSET, int MODE, bool ALIGNED>
 __global__ __launch_bounds__(kSweepThreads, 4) void k_slide_keys(SlideArgs a, unsigned long long* hist, uint32_t* min_out) {
+    args_from_pool_state<KEYSET>(a);
     constexpr bool NEXT_ABOVE = MODE == 1;
     constexpr bool LOW16 = MODE == 2;
     __shared__ RowTab s_tab;
@@ -339,6 +367,7 @@ __device__ __forceinline__ void window_sweep(const uint8_t* src, int P, int c0, 
 
 template <int KEYSET, bool ALIGNED>
 __global__ __launch_bounds__(kSweepThreads, 4) void k_slide_window(SlideArgs a, unsigned long long* hist) {
+    args_from_pool_state<KEYSET>(a);
     __shared__ RowTab s_tab;
     s_tab.fill_b();
     __syncthreads();
@@ -443,7 +472,147 @@ int fill_args(SlideArgs& a, const uint8_t* rgb, int n, int h, int w, const SlPar
     a.prefix[0] = a.prefix[1] = 0; a.prefix_bits = 0; a.above[0] = a.above[1] = 0;
     a.window_lo[0] = a.window_lo[1] = 0; a.sample_mask = 0;
     a.win_flo[0] = a.win_flo[1] = -INFINITY; a.win_fhi[0] = a.win_fhi[1] = INFINITY;
+    a.dyn = nullptr;
     return SL_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Device-driven pooled statistics (round 3): the decisions the host took between the sweeps -- eigenvectors, which histogram bin
+// holds the wanted rank, where the window goes, whether it caught the rank, the stain matrix -- are single-workgroup kernels on
+// the pool state, so that a whole pooled computation is one enqueued chain of sweeps, small all-reduces and these steps with no
+// host read-back in between (stainlib_amd/distributed.py PooledSlideStatistics; graph-capturable on one rank).
+// ------------------------------------------------------------------------------------------
+__global__ void k_pool_begin(const double* mom11, double* st, double pct) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int i = 0; i < SL_POOL_STATE_DOUBLES; ++i) st[i] = 0.0;
+    double Vd[6];
+    float Vf[6];
+    const int status = eigvecs_from_moments(mom11, Vd, Vf);
+    st[kPoolStatus] = (double)status;
+    st[kPoolT] = mom11[0];
+    st[kPoolNpx] = mom11[10];
+    for (int i = 0; i < 6; ++i) { st[kPoolVd + i] = Vd[i]; st[kPoolVf + i] = (double)Vf[i]; }
+    long long k;
+    double g;
+    percentile_pos(mom11[0], 100.0 - pct, k, g);                 // minPhi, maxPhi (macenko_stain_extractor.py:33-34)
+    st[kPoolK] = (double)k; st[kPoolG] = g;
+    percentile_pos(mom11[0], pct, k, g);
+    st[kPoolK + 1] = (double)k; st[kPoolG + 1] = g;
+    for (int t = 0; t < 2; ++t) { st[kPoolWinFlo + t] = -INFINITY; st[kPoolWinFhi + t] = INFINITY; }
+}
+
+// One radix round of the SAMPLE estimate (all-reduced 2 x 256 histogram of the next 8 bits under the current prefix); after the third
+// the 65536-key window is centred on the estimate (distributed.py window_rank_pairs does the same on the host).
+__global__ void k_pool_pick(double* st, const unsigned long long* hist, int keyset, int round) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double N = keyset == SL_KEYSET_ANGLE ? st[kPoolT] : st[kPoolNpx];
+    for (int t = 0; t < 2; ++t) {
+        const unsigned long long* h = hist + 256 * t;
+        if (round == 0) {
+            unsigned long long tot = 0;
+            for (int b = 0; b < 256; ++b) tot += h[b];
+            st[kPoolTotalS + t] = (double)tot;
+            double f = N > 1.0 ? st[kPoolK + t] / (N - 1.0) : 0.0;
+            f = f < 0.0 ? 0.0 : (f > 1.0 ? 1.0 : f);
+            double ks = tot > 0 ? floor(f * ((double)tot - 1.0)) : 0.0;
+            if (tot == 0) st[kPoolMiss] = (double)((int)st[kPoolMiss] | (keyset == SL_KEYSET_ANGLE ? 1 : 2));
+            st[kPoolKs + t] = ks; st[kPoolBelow + t] = 0.0; st[kPoolPrefix + t] = 0.0;
+        }
+        const unsigned long long want = (unsigned long long)(st[kPoolKs + t] - st[kPoolBelow + t]);
+        unsigned long long cum = 0;
+        int b = 0;
+        for (; b < 255; ++b) { if (cum + h[b] > want) break; cum += h[b]; }     // first bin with cum(b) > want
+        st[kPoolBelow + t] += (double)cum;
+        st[kPoolPrefix + t] = (double)((((unsigned long long)st[kPoolPrefix + t]) << 8) | (unsigned long long)b);
+    }
+    if (round == 2) {
+        bool usable = true;
+        float flo[2], fhi[2];
+        for (int t = 0; t < 2; ++t) {
+            const unsigned long long est = (((unsigned long long)st[kPoolPrefix + t]) << 8) | 0x80ull;
+            long long lo = (long long)est - 32768;
+            lo = lo < 0 ? 0 : (lo > (long long)(0xffffffffll - 65535ll) ? (long long)(0xffffffffll - 65535ll) : lo);
+            st[kPoolWinLo + t] = (double)lo;
+            flo[t] = ord2f((uint32_t)lo); fhi[t] = ord2f((uint32_t)lo + 65535u);
+            if (!isfinite(flo[t]) || !isfinite(fhi[t])) usable = false;
+        }
+        if (keyset == SL_KEYSET_ANGLE && !(flo[0] <= flo[1] && fhi[0] <= fhi[1])) usable = false;
+        for (int t = 0; t < 2; ++t) { st[kPoolWinFlo + t] = usable ? (double)flo[t] : -INFINITY; st[kPoolWinFhi + t] = usable ? (double)fhi[t] : INFINITY; }
+        for (int t = 0; t < 2; ++t) { st[kPoolPrefix + t] = 0.0; }
+    }
+}
+
+// The all-reduced window histogram (2 x 65536 bins + 2 counts below): the keys of ranks k and k + 1 of both targets, or a miss.
+// Angle stage: the stain matrix (macenko_stain_extractor.py:33-44) and the ranks of the concentration stage; concentration
+// stage: maxC (normalizer.py:36,47).  One workgroup of 1024 threads.
+__global__ __launch_bounds__(1024) void k_pool_resolve(double* st, const unsigned long long* win, int keyset, double lam) {
+    __shared__ unsigned long long s_seg[1024];
+    __shared__ unsigned long long s_cum[1024];
+    __shared__ float s_res[4];
+    __shared__ int s_miss;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_miss = 0;
+    if (tid < 4) s_res[tid] = 0.0f;
+    const double N = keyset == SL_KEYSET_ANGLE ? st[kPoolT] : st[kPoolNpx];
+    for (int t = 0; t < 2; ++t) {
+        const unsigned long long* h = win + 65536 * t;
+        unsigned long long seg = 0;
+        for (int j = 0; j < 64; ++j) seg += h[tid * 64 + j];
+        __syncthreads();
+        s_seg[tid] = seg;
+        __syncthreads();
+        if (tid == 0) { unsigned long long c = 0; for (int i = 0; i < 1024; ++i) { s_cum[i] = c; c += s_seg[i]; } }   // exclusive
+        __syncthreads();
+        const unsigned long long inside = s_cum[1023] + s_seg[1023];
+        const unsigned long long below = win[2 * 65536 + t];
+        const double kd = st[kPoolK + t];
+        const unsigned long long k = (unsigned long long)(kd < 0 ? 0 : (kd > N - 1.0 ? N - 1.0 : kd));
+        const unsigned long long k1 = (double)(k + 1) <= N - 1.0 ? k + 1 : k;
+        const bool covered = N >= 1.0 && below <= k && k1 < below + inside;
+        if (!covered) { if (tid == 0) s_miss = 1; continue; }                  // uniform
+        const uint32_t lo = (uint32_t)st[kPoolWinLo + t];
+        for (int which = 0; which < 2; ++which) {
+            const unsigned long long want = (which ? k1 : k) - below;           // rank inside the window
+            if (want >= s_cum[tid] && want < s_cum[tid] + s_seg[tid]) {         // exactly one thread
+                unsigned long long c = s_cum[tid];
+                for (int j = 0; j < 64; ++j) {
+                    const unsigned long long v = h[tid * 64 + j];
+                    if (want < c + v) { s_res[2 * t + which] = ord2f(lo + (uint32_t)(tid * 64 + j)); break; }
+                    c += v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (s_miss) {
+        if (tid == 0) st[kPoolMiss] = (double)((int)st[kPoolMiss] | (keyset == SL_KEYSET_ANGLE ? 1 : 2));
+        return;
+    }
+    if (tid < 4) st[kPoolRes + tid] = (double)s_res[tid];
+    if (keyset == SL_KEYSET_ANGLE) {
+        __shared__ double s_Vd[6], s_g[2];
+        if (tid < 6) s_Vd[tid] = st[kPoolVd + tid];
+        if (tid < 2) s_g[tid] = st[kPoolG + tid];
+        __syncthreads();
+        if (tid < 64) {
+            double M[6];
+            stain_matrix_from_angles(s_Vd, s_res, s_g, M, tid);
+            if (tid == 0) {
+                for (int i = 0; i < 6; ++i) st[kPoolM + i] = M[i];
+                if (stain_matrix_singular(M)) st[kPoolStatus] = (double)SL_TILE_DEGENERATE_COV;
+                long long k;
+                double g;
+                percentile_pos(st[kPoolNpx], 99.0, k, g);                       // normalizer.py:36,47
+                st[kPoolK] = st[kPoolK + 1] = (double)k;
+                st[kPoolG] = st[kPoolG + 1] = g;
+                for (int t = 0; t < 2; ++t) { st[kPoolWinFlo + t] = -INFINITY; st[kPoolWinFhi + t] = INFINITY; st[kPoolWinLo + t] = 0.0; }
+            }
+        }
+    } else if (tid == 0) {
+        for (int t = 0; t < 2; ++t) st[kPoolMaxC + t] = np_lerp((double)s_res[2 * t], (double)s_res[2 * t + 1], st[kPoolG + t]);
+        (void)lam;
+    }
 }
 
 template <int NEXT>
@@ -571,5 +740,67 @@ extern "C" int sl_slide_key_next_above(const uint8_t* rgb, int n, int h, int w, 
     if (!min_out || !key_ords) return SL_ERR_BADARG;
     a.above[0] = key_ords[0]; a.above[1] = key_ords[1];
     launch_keys<1>(a, aligned4(rgb, (long)h * w), nullptr, min_out, (hipStream_t)stream);
+    return launch_status();
+}
+
+
+// ---- device-driven pooled statistics: see k_pool_* above and include/stainlib_hip.h ----
+extern "C" int sl_pool_begin(const double* moments11, const SlParams* params, double* state, void* stream) {
+    if (!moments11 || !state) return SL_ERR_BADARG;
+    SlParams p;
+    sl_default_params(&p);
+    if (params) p = *params;
+    hipLaunchKernelGGL(k_pool_begin, dim3(1), dim3(64), 0, (hipStream_t)stream, moments11, state, p.angular_percentile);
+    return launch_status();
+}
+
+extern "C" int sl_pool_histogram(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int keyset, const double* state,
+                                 int round, int sample_log2, unsigned long long* hist, void* stream) {
+    static const double dummy_basis[6] = {1, 0, 0, 0, 1, 0};
+    SlideArgs a;
+    const int rc = fill_args(a, rgb, n, h, w, params, keyset, dummy_basis);
+    if (rc) return rc;
+    if (!hist || !state || round < 0 || round > 3 || sample_log2 < 0 || sample_log2 > 12) return SL_ERR_BADARG;
+    a.dyn = state;
+    a.prefix_bits = 8 * round;
+    a.sample_mask = (1u << sample_log2) - 1u;
+    launch_keys<0>(a, aligned4(rgb, (long)h * w), hist, nullptr, (hipStream_t)stream);
+    return launch_status();
+}
+
+extern "C" int sl_pool_pick(double* state, int keyset, int round, const unsigned long long* hist_reduced, void* stream) {
+    if (!state || !hist_reduced || round < 0 || round > 2 || (keyset != SL_KEYSET_ANGLE && keyset != SL_KEYSET_CONC)) return SL_ERR_BADARG;
+    hipLaunchKernelGGL(k_pool_pick, dim3(1), dim3(64), 0, (hipStream_t)stream, state, hist_reduced, keyset, round);
+    return launch_status();
+}
+
+extern "C" int sl_pool_window(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int keyset, const double* state,
+                              unsigned long long* hist_below, void* stream) {
+    static const double dummy_basis[6] = {1, 0, 0, 0, 1, 0};
+    SlideArgs a;
+    const int rc = fill_args(a, rgb, n, h, w, params, keyset, dummy_basis);
+    if (rc) return rc;
+    if (!hist_below || !state) return SL_ERR_BADARG;
+    a.dyn = state;
+    const bool al = aligned4(rgb, (long)h * w);
+    const int mg = max_resident_grid();
+    const dim3 g((unsigned)(a.n_items < mg ? a.n_items : mg)), b(kSweepThreads);
+    hipStream_t s = (hipStream_t)stream;
+    if (keyset == SL_KEYSET_ANGLE) {
+        if (al) hipLaunchKernelGGL((k_slide_window<SL_KEYSET_ANGLE, true>), g, b, 0, s, a, hist_below);
+        else    hipLaunchKernelGGL((k_slide_window<SL_KEYSET_ANGLE, false>), g, b, 0, s, a, hist_below);
+    } else {
+        if (al) hipLaunchKernelGGL((k_slide_window<SL_KEYSET_CONC, true>), g, b, 0, s, a, hist_below);
+        else    hipLaunchKernelGGL((k_slide_window<SL_KEYSET_CONC, false>), g, b, 0, s, a, hist_below);
+    }
+    return launch_status();
+}
+
+extern "C" int sl_pool_resolve(double* state, int keyset, const unsigned long long* window_reduced, const SlParams* params, void* stream) {
+    if (!state || !window_reduced || (keyset != SL_KEYSET_ANGLE && keyset != SL_KEYSET_CONC)) return SL_ERR_BADARG;
+    SlParams p;
+    sl_default_params(&p);
+    if (params) p = *params;
+    hipLaunchKernelGGL(k_pool_resolve, dim3(1), dim3(1024), 0, (hipStream_t)stream, state, window_reduced, keyset, p.lasso_lambda);
     return launch_status();
 }

@@ -201,7 +201,65 @@ class PooledSlideStatistics:
         self.thr, self.pct, self.lam = luminosity_threshold, angular_percentile, lasso_lambda
         self.last_path = []          # per stage of the last call: "window" (one sweep) or "radix" (the fallback rounds)
 
-    def __call__(self, tiles_local: torch.Tensor):
+    def enqueue(self, tiles_local: torch.Tensor, ws=None) -> torch.Tensor:
+        """DEVICE-DRIVEN: enqueue the whole computation (4 full sweeps, 6 sampled passes, the all-reduces between them and the
+        single-workgroup decision steps) on the current stream and return the pool state tensor (device float64,
+        _ffi.POOL_STATE_DOUBLES) WITHOUT reading anything back: state[POOL_M:POOL_M+6] / state[POOL_MAXC:+2] are the slide's stain
+        matrix and maxC once state[POOL_STATUS] == 0 and state[POOL_MISS] == 0 (``finish`` checks them with one read-back).  Every
+        rank reaches the same state: each step consumes all-reduced data only.  On one rank the chain is graph-capturable."""
+        import math
+        from . import engine, _ffi
+        params = engine.make_params(luminosity_threshold=self.thr, angular_percentile=self.pct, lasso_lambda=self.lam)
+        _, world = _world(self.group)
+        n_local, h, w, _ = tiles_local.shape
+        dev = tiles_local.device
+        mom = torch.empty((11,), dtype=torch.float64, device=dev)
+        mom[:10] = engine.tile_moments(tiles_local, params=params, ws=ws).sum(dim=0)
+        mom[10] = float(n_local * h * w)
+        if world > 1:
+            dist.all_reduce(mom, group=self.group)
+        state = engine.pool_begin(mom, params=params)
+        # the sample: ~4 M pixels of the slide or more (shards differ by at most one tile: every rank derives the same density)
+        n_pixels = world * n_local * h * w
+        slog = min(6, max(0, int(math.floor(math.log2(max(n_pixels, 1) / 4.0e6))))) if n_pixels > 4.0e6 else 0
+        hists = torch.zeros((2, 3, 2, 256), dtype=torch.int64, device=dev)
+        wins = torch.zeros((2, 2 * 65536 + 2), dtype=torch.int64, device=dev)
+        for si, keyset in enumerate((_ffi.KEYSET_ANGLE, _ffi.KEYSET_CONC)):
+            for rnd in range(3):
+                hb = engine.pool_histogram(tiles_local, keyset, state, rnd, slog, hists[si, rnd], params=params)
+                if world > 1:
+                    dist.all_reduce(hb, group=self.group)
+                engine.pool_pick(state, keyset, rnd, hb)
+            wb = engine.pool_window(tiles_local, keyset, state, wins[si], params=params)
+            if world > 1:
+                dist.all_reduce(wb, group=self.group)
+            engine.pool_resolve(state, keyset, wb, params=params)
+        return state
+
+    def finish(self, state: torch.Tensor):
+        """The one read-back of the device-driven path: (M, maxC) as numpy, or None when a window missed (the caller then runs the
+        host-driven rounds).  Raises like the reference on an empty tissue mask."""
+        import numpy as np
+        from . import _ffi
+        from .utils.excepts import TissueMaskException
+        s = state.cpu().numpy()
+        status, miss = int(s[_ffi.POOL_STATUS]), int(s[_ffi.POOL_MISS])
+        if status == _ffi.TILE_EMPTY_MASK:
+            raise TissueMaskException("Empty tissue mask computed")
+        if status != 0 or miss != 0:
+            return None
+        self.last_path = ["window", "window"]
+        return s[_ffi.POOL_M:_ffi.POOL_M + 6].reshape(2, 3).copy(), s[_ffi.POOL_MAXC:_ffi.POOL_MAXC + 2].copy()
+
+    def __call__(self, tiles_local: torch.Tensor, device_driven: bool = True):
+        if device_driven:
+            got = self.finish(self.enqueue(tiles_local))
+            if got is not None:
+                return got
+        return self.host_driven(tiles_local)
+
+    def host_driven(self, tiles_local: torch.Tensor):
+        """The same statistics with the decisions on the host (a read-back per step): the radix fallback lives here."""
         import math
         import numpy as np
         from . import engine, _ffi
@@ -280,15 +338,26 @@ class SlideNormalizer:
         """tiles_local: this rank's (n_local,H,W,3) uint8 device tensor.  Returns (out, M_slide, maxC_slide, status_local)."""
         from . import engine
         if self.mode == "pooled":
+            from . import _ffi
             stats = PooledSlideStatistics(self.group)
-            M_np, maxC_np = stats(tiles_local)
-            self.last_path = stats.last_path             # per stage: "window" (one sweep) or "radix" (fallback rounds)
             dev = tiles_local.device
             n = tiles_local.shape[0]
-            M_s = torch.as_tensor(M_np, dtype=torch.float64, device=dev)
-            maxC_s = torch.as_tensor(maxC_np, dtype=torch.float64, device=dev)
-            out = engine.normalize_apply(tiles_local, M_s.expand(n, 2, 3).contiguous(), maxC_s.expand(n, 2).contiguous(),
-                                         self.normalizer.stain_matrix_target, self.normalizer.maxC_target.reshape(2), out=out)
+            # device-driven: the statistics AND the apply pass are enqueued before anything is read back; the one read-back
+            # afterwards only confirms that both windows caught their ranks (else: the host-driven rounds, and the pass again)
+            state = stats.enqueue(tiles_local)
+            M_s = state[_ffi.POOL_M:_ffi.POOL_M + 6].reshape(2, 3)
+            maxC_s = state[_ffi.POOL_MAXC:_ffi.POOL_MAXC + 2]
+            Mt, mct = self.normalizer.stain_matrix_target, self.normalizer.maxC_target.reshape(2)
+            out = engine.normalize_apply(tiles_local, M_s.expand(n, 2, 3).contiguous(), maxC_s.expand(n, 2).contiguous(), Mt, mct, out=out)
+            got = stats.finish(state)
+            if got is None:
+                M_np, maxC_np = stats.host_driven(tiles_local)
+                M_s = torch.as_tensor(M_np, dtype=torch.float64, device=dev)
+                maxC_s = torch.as_tensor(maxC_np, dtype=torch.float64, device=dev)
+                out = engine.normalize_apply(tiles_local, M_s.expand(n, 2, 3).contiguous(), maxC_s.expand(n, 2).contiguous(), Mt, mct, out=out)
+            else:
+                M_s, maxC_s = M_s.clone(), maxC_s.clone()
+            self.last_path = stats.last_path             # per stage: "window" (one sweep) or "radix" (fallback rounds)
             return out, M_s, maxC_s, torch.zeros((n,), dtype=torch.int32, device=dev)
         M, maxC, status = self.normalizer.fit_batch_targets(tiles_local)
         M_all, maxC_all, st_all = gather_tile_stats(M, maxC, status, self.group)

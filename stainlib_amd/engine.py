@@ -442,6 +442,42 @@ def slide_key_window(rgb, keyset, basis, window_lo, params=None):
     return buf
 
 
+# ---- device-driven pooled statistics (sl_pool_*): every step is enqueued, nothing is read back -------------------------------
+def pool_begin(moments11, state=None, params=None):
+    """moments11: device float64 (11,) = the tile moments summed over all tiles and ranks + the pixel count.  Returns the state tensor."""
+    p = params if params is not None else _ffi.default_params()
+    if state is None:
+        state = torch.empty((_ffi.POOL_STATE_DOUBLES,), dtype=torch.float64, device=moments11.device)
+    _ffi.check(_ffi.lib().sl_pool_begin(_ptr(moments11), C.byref(p), _ptr(state), _stream()), "sl_pool_begin")
+    return state
+
+
+def pool_histogram(rgb, keyset, state, rnd, sample_log2, hist, params=None):
+    """This process's sampled (2, 256) histogram of radix round `rnd` under the prefixes in `state`, accumulated into hist (zeroed by the caller)."""
+    n, h, w = _check_tiles(rgb)
+    p = params if params is not None else _ffi.default_params()
+    _ffi.check(_ffi.lib().sl_pool_histogram(_ptr(rgb), n, h, w, C.byref(p), int(keyset), _ptr(state), int(rnd), int(sample_log2), _ptr(hist),
+                                            _stream()), "sl_pool_histogram")
+    return hist
+
+
+def pool_pick(state, keyset, rnd, hist_reduced):
+    _ffi.check(_ffi.lib().sl_pool_pick(_ptr(state), int(keyset), int(rnd), _ptr(hist_reduced), _stream()), "sl_pool_pick")
+
+
+def pool_window(rgb, keyset, state, buf, params=None):
+    """This process's window histogram + counts below ((2 * 65536 + 2,) int64, zeroed by the caller) around the windows in `state`."""
+    n, h, w = _check_tiles(rgb)
+    p = params if params is not None else _ffi.default_params()
+    _ffi.check(_ffi.lib().sl_pool_window(_ptr(rgb), n, h, w, C.byref(p), int(keyset), _ptr(state), _ptr(buf), _stream()), "sl_pool_window")
+    return buf
+
+
+def pool_resolve(state, keyset, window_reduced, params=None):
+    p = params if params is not None else _ffi.default_params()
+    _ffi.check(_ffi.lib().sl_pool_resolve(_ptr(state), int(keyset), _ptr(window_reduced), C.byref(p), _stream()), "sl_pool_resolve")
+
+
 def slide_key_next_above(rgb, keyset, basis, key_ords, params=None):
     """Per target: smallest key (ordered uint32, Python ints) above key_ords[t] among this process's pixels; 0xffffffff if none."""
     n, h, w = _check_tiles(rgb)

@@ -342,6 +342,109 @@ def _install_numpy_engine(force_radix=False):
             res.append(so.truncate_u8(255 * np.exp(-C @ np.asarray(M_tgt))).reshape(t.shape))
         return torch.from_numpy(np.stack(res))
 
+    # ---- the device-driven steps (sl_pool_*): numpy restatements of the single-workgroup decision kernels of csrc/slide.hip on a
+    # CPU float64 "state" tensor with the layout of include/stainlib_hip.h (SL_POOL_*) -- the orchestration in
+    # PooledSlideStatistics.enqueue / finish is the product code
+    K_T, K_NPX, K_VD, K_VF, K_K, K_G, K_TOT, K_KS, K_BELOW, K_PREFIX, K_WLO, K_RES = 10, 11, 12, 18, 24, 26, 28, 30, 32, 34, 36, 43
+
+    def ord2f(o):
+        o = int(o)
+        bits = (o & 0x7fffffff) if (o & 0x80000000) else (~o & 0xffffffff)
+        return float(np.array([bits], np.uint32).view(np.float32)[0])
+
+    def pool_begin(mom11, state=None, params=None):
+        m = mom11.numpy()
+        st = torch.zeros((_ffi.POOL_STATE_DOUBLES,), dtype=torch.float64)
+        T = m[0]
+        st[K_T], st[K_NPX] = T, m[10]
+        if T < 1:
+            st[_ffi.POOL_STATUS] = _ffi.TILE_EMPTY_MASK
+            return st
+        mean = m[1:4] / T
+        S2 = np.array([[m[4], m[5], m[6]], [m[5], m[7], m[8]], [m[6], m[8], m[9]]])
+        _, V = np.linalg.eigh((S2 - T * np.outer(mean, mean)) / (T - 1.0))
+        V = V[:, [2, 1]].copy()
+        for i in range(2):
+            if V[0, i] < 0:
+                V[:, i] *= -1.0
+        st[K_VD:K_VD + 6] = torch.from_numpy(V.reshape(6))
+        st[K_VF:K_VF + 6] = torch.from_numpy(V.astype(np.float32).astype(np.float64).reshape(6))
+        for t, pct in enumerate((1.0, 99.0)):
+            k, g = sd.percentile_position(int(T), pct)
+            st[K_K + t], st[K_G + t] = k, g
+        return st
+
+    def basis_of(state, keyset):
+        return state[K_VF:K_VF + 6].numpy() if keyset == _ffi.KEYSET_ANGLE else state[_ffi.POOL_M:_ffi.POOL_M + 6].numpy()
+
+    def pool_histogram(tiles, keyset, state, rnd, slog, hist_out, params=None):
+        pre = [int(state[K_PREFIX + t]) for t in range(2)]
+        hist_out += hist(tiles, keyset, basis_of(state, keyset), pre, 8 * rnd, every=1 << slog)
+        return hist_out
+
+    def pool_pick(state, keyset, rnd, h):
+        N = float(state[K_T] if keyset == _ffi.KEYSET_ANGLE else state[K_NPX])
+        hc = h.numpy()
+        for t in range(2):
+            if rnd == 0:
+                tot = int(hc[t].sum())
+                f = min(max(float(state[K_K + t]) / (N - 1.0) if N > 1 else 0.0, 0.0), 1.0)
+                state[K_TOT + t], state[K_KS + t], state[K_BELOW + t], state[K_PREFIX + t] = tot, (np.floor(f * (tot - 1.0)) if tot else 0.0), 0.0, 0.0
+                if tot == 0:
+                    state[_ffi.POOL_MISS] = float(int(state[_ffi.POOL_MISS]) | (1 if keyset == _ffi.KEYSET_ANGLE else 2))
+            want = int(state[K_KS + t] - state[K_BELOW + t])
+            cum, b = 0, 0
+            while b < 255 and not (cum + int(hc[t][b]) > want):
+                cum += int(hc[t][b]); b += 1
+            state[K_BELOW + t] += cum
+            state[K_PREFIX + t] = float((int(state[K_PREFIX + t]) << 8) | b)
+        if rnd == 2:
+            for t in range(2):
+                est = (int(state[K_PREFIX + t]) << 8) | 0x80
+                state[K_WLO + t] = float(min(max(est - 32768, 0), 0xffffffff - 65535))
+                state[K_PREFIX + t] = 0.0
+
+    def pool_window(tiles, keyset, state, buf, params=None):
+        buf += window(tiles, keyset, basis_of(state, keyset), [int(state[K_WLO]), int(state[K_WLO + 1])])
+        return buf
+
+    def pool_resolve(state, keyset, win, params=None):
+        N = int(state[K_T] if keyset == _ffi.KEYSET_ANGLE else state[K_NPX])
+        b = win.numpy()
+        res = []
+        for t in range(2):
+            histo, below = b[t * 65536:(t + 1) * 65536], int(b[2 * 65536 + t])
+            k = min(max(int(state[K_K + t]), 0), N - 1)
+            k1 = min(k + 1, N - 1)
+            if not (N >= 1 and below <= k and k1 < below + int(histo.sum())):
+                state[_ffi.POOL_MISS] = float(int(state[_ffi.POOL_MISS]) | (1 if keyset == _ffi.KEYSET_ANGLE else 2))
+                return
+            cum = np.cumsum(histo)
+            lo = int(state[K_WLO + t])
+            res += [ord2f(lo + int(np.searchsorted(cum, k - below, side="right"))), ord2f(lo + int(np.searchsorted(cum, k1 - below, side="right")))]
+        state[K_RES:K_RES + 4] = torch.tensor(res, dtype=torch.float64)
+        if keyset == _ffi.KEYSET_ANGLE:
+            import math
+
+            def ang(p):
+                if abs(p) <= 1.0:
+                    return math.atan2(p, 1.0 - abs(p))
+                pp = 2.0 - p if p > 0 else -2.0 - p
+                return math.atan2(pp, -(1.0 - abs(pp)))
+            V = state[K_VD:K_VD + 6].numpy().reshape(3, 2)
+            phis = [sd.np_lerp(ang(res[0]), ang(res[1]), float(state[K_G])), sd.np_lerp(ang(res[2]), ang(res[3]), float(state[K_G + 1]))]
+            v1, v2 = V @ np.array([math.cos(phis[0]), math.sin(phis[0])]), V @ np.array([math.cos(phis[1]), math.sin(phis[1])])
+            M = np.array([v1, v2]) if v1[0] > v2[0] else np.array([v2, v1])
+            M = M / np.linalg.norm(M, axis=1, keepdims=True)
+            state[_ffi.POOL_M:_ffi.POOL_M + 6] = torch.from_numpy(M.reshape(6))
+            k, g = sd.percentile_position(int(state[K_NPX]), 99.0)
+            state[K_K], state[K_K + 1], state[K_G], state[K_G + 1] = k, k, g, g
+        else:
+            for t in range(2):
+                state[_ffi.POOL_MAXC + t] = sd.np_lerp(res[2 * t], res[2 * t + 1], float(state[K_G + t]))
+
+    engine.pool_begin, engine.pool_histogram, engine.pool_pick = pool_begin, pool_histogram, pool_pick
+    engine.pool_window, engine.pool_resolve = pool_window, pool_resolve
     engine.make_params = lambda **kw: None
     engine.tile_moments = tile_moments
     engine.slide_key_histogram = hist
@@ -352,8 +455,10 @@ def _install_numpy_engine(force_radix=False):
     engine.normalize_apply = normalize_apply
 
 
-def _slide_tiles():
+def _slide_tiles(big=False):
     from oracle import stain_oracle as so
+    if big:      # ~100 k pixels: neighbouring order statistics lie well inside one 65536-key window, both stages take the one-sweep path
+        return [so.synth_tile(128, 128, 300 + s) for s in range(5)] + [so.structured_tile("white_bg", 128, 128, 7)]
     return [so.synth_tile(48, 64, 300 + s) for s in range(5)] + [so.structured_tile("white_bg", 64, 48, 7).transpose(1, 0, 2).copy()]
 
 
@@ -365,13 +470,13 @@ class _FittedTarget:                       # what SlideNormalizer needs of a fit
         self.stain_matrix_target, self.maxC_target = n.stain_matrix_target, n.maxC_target
 
 
-def _pooled_worker(rank, world, port, force_radix, q):
+def _pooled_worker(rank, world, port, force_radix, q, big=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     _install_numpy_engine(force_radix)
-    tiles = _slide_tiles()
+    tiles = _slide_tiles(big)
     lo, hi = sd.shard_range(len(tiles), rank, world)              # 6 tiles -> 3 + 3; rank 1 holds the white-background tile
     mine = torch.from_numpy(np.stack(tiles[lo:hi]))
     stats = sd.PooledSlideStatistics()
@@ -418,3 +523,36 @@ def test_pooled_slide_statistics_real_call_on_two_gloo_ranks(force_radix):
     both = np.concatenate([res[0][4], res[1][4]])                                  # the two shards' outputs = the single-rank output
     d = both.astype(np.int16) - one[4].astype(np.int16)
     assert np.abs(d).max() <= 1 and (d != 0).sum() <= 2                            # (1e-16 in M can flip a byte on a knife edge)
+
+
+def test_device_driven_pooled_statistics_on_two_gloo_ranks():
+    """The device-driven chain (PooledSlideStatistics.enqueue / finish: per step one all-reduce, decisions in the pool state, one
+    read-back at the end) on two gloo ranks with a slide large enough for both windows to catch their ranks: the ranks agree to
+    the bit, match the single-rank run and the reference's statistics of the concatenated slide, and no host-driven round ran."""
+    from oracle import stain_oracle as so
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pooled_worker, args=(r, 2, port, False, q, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    q1 = ctx.Queue()
+    p1 = ctx.Process(target=_pooled_worker, args=(0, 1, port, False, q1, True))
+    p1.start()
+    one = q1.get(timeout=600)
+    p1.join(timeout=60)
+    tall = np.concatenate(_slide_tiles(True), axis=0)
+    M_ref = so.macenko_stain_matrix(tall)
+    c_ref = np.percentile(so.get_concentrations(tall, M_ref), 99, axis=0)
+    for rank, M, maxC, path, out, M_s, mc_s in res:
+        assert path == ["window", "window"] and path == one[3]                     # the device-driven path settled both stages
+        assert np.array_equal(M, res[0][1]) and np.array_equal(maxC, res[0][2])    # the ranks agree to the bit
+        np.testing.assert_allclose(M, one[1], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(maxC, one[2], rtol=1e-12)
+        np.testing.assert_allclose(M, M_ref, rtol=0, atol=2e-6)
+        np.testing.assert_allclose(maxC, c_ref, rtol=2e-6)
+        assert np.array_equal(M_s, M) and np.array_equal(mc_s, maxC)

@@ -486,3 +486,43 @@ def test_hed_cutoff_knife_edge_single_and_batch_agree():
         assert np.array_equal(outs[i], single if ref_ok else t)
         decisions.append(ref_ok)
     assert any(decisions) and not all(decisions)         # the set straddles the bounds
+
+
+def test_device_driven_pooled_statistics_match_the_host_driven_rounds_and_capture_into_a_graph():
+    """sl_pool_*: the pooled slide statistics with every decision on the device (no read-back between the steps) against the
+    host-driven path (same sweeps, decisions in Python) and the reference's statistics of the concatenated slide; the whole chain
+    replays from a HIP graph (single rank: no collective inside)."""
+    import torch
+    from stainlib_amd import _ffi
+    from stainlib_amd.distributed import PooledSlideStatistics
+    tiles = [so.synth_tile(256, 256, 40 + s) for s in range(6)] + [so.structured_tile("white_bg", 256, 256, 9), so.structured_tile("blobs", 256, 256, 5)]
+    dev = to_dev(tiles)
+    stats = PooledSlideStatistics(group=False)
+    state = stats.enqueue(dev)
+    got = stats.finish(state)
+    assert got is not None and stats.last_path == ["window", "window"]
+    M_d, mc_d = got
+    M_h, mc_h = stats.host_driven(dev)
+    assert stats.last_path == ["window", "window"]
+    np.testing.assert_allclose(M_d, M_h, rtol=0, atol=1e-13)               # same sweeps; the trigonometry runs on the device instead of libm
+    np.testing.assert_allclose(mc_d, mc_h, rtol=1e-13)
+    tall = np.concatenate(tiles, axis=0)
+    M_ref = so.macenko_stain_matrix(tall)
+    np.testing.assert_allclose(M_d, M_ref, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(mc_d, np.percentile(so.get_concentrations(tall, M_ref), 99, axis=0), rtol=2e-6)
+    # captured once, replayed on new contents of the same tensor
+    from stainlib_amd import engine
+    ws = engine.Workspace()
+    g = engine.Graphed(lambda: stats.enqueue(dev, ws=ws))
+    dev.copy_(to_dev([so.synth_tile(256, 256, 90 + s) for s in range(8)]))
+    st2 = g.replay()
+    torch.cuda.synchronize()
+    M2, mc2 = stats.finish(st2)
+    M2h, mc2h = stats.host_driven(dev)
+    np.testing.assert_allclose(M2, M2h, rtol=0, atol=1e-13)
+    np.testing.assert_allclose(mc2, mc2h, rtol=1e-13)
+    assert np.abs(M2 - M_d).max() > 1e-4                                   # (the replay really saw the new slide)
+    # an all-background slide is reported like the reference does
+    import stainlib_amd as sl
+    with pytest.raises(sl.TissueMaskException):
+        stats(to_dev([np.full((64, 64, 3), 255, np.uint8)] * 2))
