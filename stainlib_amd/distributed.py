@@ -213,9 +213,9 @@ class PooledSlideStatistics:
         _, world = _world(self.group)
         n_local, h, w, _ = tiles_local.shape
         dev = tiles_local.device
-        mom = torch.empty((11,), dtype=torch.float64, device=dev)
-        mom[:10] = engine.tile_moments(tiles_local, params=params, ws=ws).sum(dim=0)
-        mom[10] = float(n_local * h * w)
+        # 10 moment sums + this rank's pixel count (torch.full: a fill kernel -- a scalar copied from the host could not be captured)
+        mom = torch.cat([engine.tile_moments(tiles_local, params=params, ws=ws).sum(dim=0),
+                         torch.full((1,), float(n_local * h * w), dtype=torch.float64, device=dev)])
         if world > 1:
             dist.all_reduce(mom, group=self.group)
         state = engine.pool_begin(mom, params=params)
