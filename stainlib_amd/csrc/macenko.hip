@@ -16,8 +16,8 @@ constexpr size_t kGroupBytes = (size_t)2 << 30;   // uint8 bytes of one tile gro
 // Defaults of SlParams.fused_min_tiles (documented in include/stainlib_hip.h): the measured crossovers of round 3's three-sweep fused
 // kernel on an MI355X at its 1400 W power state (tools/crossover.py, profiles/r03_crossover.txt: 1024^2 tiles 1.11 vs 1.14 ms at 256,
 // 1.64 vs 1.52 at 384; 256^2 tiles 0.22 vs 0.23 at 256, 0.32 vs 0.29 at 384).  Below them one launch per phase wins.
-constexpr int kFusedMinTiles = 320;
-constexpr int kFusedMinTilesSmall = 320;    // ... for tiles below 512 Ki pixels
+constexpr int kFusedMinTiles = 416;
+constexpr int kFusedMinTilesSmall = 416;    // ... for tiles below 512 Ki pixels
 constexpr int kDictFusedMinTiles = 640;     // Vahadane: below it the dictionary sweeps run one launch per phase too (measured: 1024^2 tiles 3.70 vs
                                             // 3.85 ms at 512, 6.24 vs 5.76 at 768; in a fused launch of one tile per workgroup the few tiles
                                             // that need a third full sweep hold the whole launch, per phase they cost a short extra launch)
@@ -38,7 +38,7 @@ struct Layout {
     bool fused;
     int grid;                               // fused: workgroups launched
     int max_grid;                           // resident sweep workgroups of the device
-    size_t off_M, off_maxC, off_status, off_partials, off_sample, off_cand, off_list, off_state, off_dstate, off_diag, total;
+    size_t off_M, off_maxC, off_status, off_partials, off_sample, off_cand, off_list, off_state, off_dstate, off_mstate, off_diag, total;
 };
 
 size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -81,6 +81,7 @@ Layout make_layout(int n, long P, int method = kMethodMacenko, int schedule = 0,
     L.off_list = o;     o = align_up(o + sizeof(float) * 2 * (size_t)L.cap_list * slots);
     L.off_state = o;    o = align_up(o + sizeof(TileState) * (size_t)L.G);
     L.off_dstate = o;   o = align_up(o + sizeof(DictState) * (size_t)L.G);
+    L.off_mstate = o;   o = align_up(o + sizeof(TileMerged) * (size_t)L.G);
     L.total = o;
     return L;
 }
@@ -109,6 +110,7 @@ StatsArgs stats_args(const uint8_t* rgb, int g0, int m, long P, const SlParams& 
     a.tile0 = g0;
     a.dstate = (DictState*)(ws + L.off_dstate);
     a.sweeps_out = nullptr;
+    a.mstate = nullptr;                      // set by the merged Macenko schedule only (the Vahadane groups reuse k_select<conc> / k_finish_conc)
     return a;
 }
 
@@ -120,19 +122,24 @@ int run_stats_group(const uint8_t* rgb, int g0, int m, long P, const SlParams& p
     const long items = (long)m * L.parts;
     const dim3 gs((unsigned)(items < L.max_grid ? items : L.max_grid)), bs(kSweepThreads), gf((unsigned)m), bf(kFinishThreads);
     SlProfile* prof = p.profile;
+    a.mstate = (TileMerged*)(ws + L.off_mstate);
+    const dim3 bm(kMFinishThreads);
     {
         ProfScope ps(prof, SL_PROF_MOMENTS, m, s);
         if (al) hipLaunchKernelGGL((k_moments<true>), gs, bs, SL_DYN_LDS, s, a);
         else    hipLaunchKernelGGL((k_moments<false>), gs, bs, SL_DYN_LDS, s, a);
     }
-    { ProfScope ps(prof, SL_PROF_FINISH, m, s); hipLaunchKernelGGL(k_finish_moments, gf, bf, 0, s, a); }
-    {
+    { ProfScope ps(prof, SL_PROF_FINISH, m, s); hipLaunchKernelGGL(k_finish1m, gf, bm, 0, s, a); }
+    {   // ONE selection sweep for the angular and the concentration candidates (as sweep 2 of the fused kernel)
         ProfScope ps(prof, SL_PROF_SELECT_ANGLE, m, s);
-        if (al) hipLaunchKernelGGL((k_select<kStageAngle, true>), gs, bs, SL_DYN_LDS, s, a);
-        else    hipLaunchKernelGGL((k_select<kStageAngle, false>), gs, bs, SL_DYN_LDS, s, a);
+        if (al) hipLaunchKernelGGL((k_select<kStageMerged, true>), gs, bs, SL_DYN_LDS, s, a);
+        else    hipLaunchKernelGGL((k_select<kStageMerged, false>), gs, bs, SL_DYN_LDS, s, a);
     }
-    { ProfScope ps(prof, SL_PROF_FINISH, m, s); hipLaunchKernelGGL(k_finish_angle, gf, bf, 0, s, a); }
     {
+        ProfScope ps(prof, SL_PROF_FINISH, m, s);
+        hipLaunchKernelGGL(k_finish2m, gf, bm, 0, s, a, M_all, maxC_all, status_all, p.fallbacks_out, g0);
+    }
+    {   // only the tiles whose exact stain matrix left the box the merged sweep assumed still have work here (none, normally)
         ProfScope ps(prof, SL_PROF_SELECT_CONC, m, s);
         if (al) hipLaunchKernelGGL((k_select<kStageConc, true>), gs, bs, SL_DYN_LDS, s, a);
         else    hipLaunchKernelGGL((k_select<kStageConc, false>), gs, bs, SL_DYN_LDS, s, a);

@@ -100,6 +100,7 @@ struct StatsArgs {
     int tile0;               // first tile of the group within the batch (sweeps_out index)
     struct DictState* dstate;   // [tile]
     int32_t* sweeps_out;     // [n_tiles of the batch] (may be NULL)
+    struct TileMerged* mstate;  // [tile] merged selection stage of the per-phase Macenko schedule
 };
 
 
@@ -775,6 +776,13 @@ struct MergedConc {
     LassoK Lc;                 // the box centre's lasso constants (sample keys)
 };
 
+// per-tile state of the merged selection stage in the one-launch-per-phase schedule (the fused kernel keeps it in LDS)
+struct TileMerged {
+    MergedConc mk;
+    float xmin;
+    int conc_done;
+};
+
 // Called by one whole wave after the angular brackets are known: lanes 0..8 evaluate the 3 x 3 grid of the box.
 __device__ __forceinline__ void merged_box(const double* Vd, const float* lo, const float* hi, double lam, int lane, MergedConc& mk) {
     const bool finite = (lo[0] > -INFINITY) & (hi[0] < INFINITY) & (lo[1] > -INFINITY) & (hi[1] < INFINITY);
@@ -982,7 +990,7 @@ __device__ __forceinline__ void moments_sweep_b(const uint8_t* src, int P, int c
     if (cb < c1) trip(std::true_type{}, cb);                    // at most one ragged trip per wave
 }
 
-enum { kStageAngle = 0, kStageConc = 1, kStageMerged = 2 };
+enum { kStageConc = 1, kStageMerged = 2 };       // (the angle-only stage of rounds 1-2 went with the merged sweep)
 
 struct SelConsts {          // everything VGPR-resident (in_vgpr)
     float V[6];
@@ -1011,18 +1019,18 @@ __device__ __forceinline__ float tissue_x_bound(const float* Vf /*[6]*/, float y
     return vmin * tab.odf((uint32_t)lo) * (1.0f - 1e-6f);    // (the binary32 evaluation of V1 . od adds positive terms: relative error 2e-7)
 }
 
-// Sweeps 2/3.  The sweep does NOT evaluate the selection keys of every pixel.  A cheap conservative
-// test proves, for ~97 % of the pixels, on which side of both brackets their keys fall; those are
-// only counted ("plain").  The remaining pixels -- inside or near a bracket, or beyond the outer
-// ends -- are appended as raw RGB to a per-tile list and resolved exactly by the finish step.
-//   angle stage (one key p for both brackets, tissue only): plain <=> hi0 < p < lo1, tested without the
-//     division as  y > (hi0+eps) d  and  y < (lo1-eps) d  with d = x + |y|, x > 0
+// The selection sweeps.  A sweep does NOT evaluate the selection keys of every pixel.  A cheap conservative
+// test proves, for ~94 % of the pixels, on which side of both brackets their keys fall ("plain").  The remaining
+// pixels -- inside or near a bracket, or beyond the outer ends -- are appended as raw RGB to a per-tile list and
+// resolved exactly by the finish step.
+//   merged stage: the angle test (one key p for both brackets, tissue only: plain <=> hi0 < p < lo1, tested without the
+//     division as  y > (hi0+eps) d  and  y < (lo1-eps) d  with d = x + |y|, x > 0) and, from the same two projections,
+//     a conservative test on the concentrations under the box of stain matrices (MergedConc)
 //   concentration stage (g12 >= 0): c_i <= max(0, a_i) exactly, so  a1 < lo0 and a2 < lo1  =>  both
 //     keys lie below their brackets (needs lo > 0; otherwise nothing is plain)
 // The plain pixels are not even counted: their number is (valid pixels of the stage) - (raw candidates).
 // c0 must be a multiple of 64.  The LDS gathers of a chunk are issued one chunk ahead of its arithmetic.
 template <int STAGE> struct SelGather;
-template <> struct SelGather<kStageAngle> { float2 v[12]; };      // {gamma, od32} per byte
 template <> struct SelGather<kStageConc> { float v[12]; };        // od32 per byte
 template <> struct SelGather<kStageMerged> { float2 v[12]; };
 struct SelGatherOd { float v[12]; };                             // merged stage with the projection bound: od32 only
@@ -1059,16 +1067,7 @@ __device__ __forceinline__ void select_sweep(const uint8_t* src, int P, int c0, 
         for (int px = 0; px < 4; ++px) {
             // flagged = valid and not provably plain.  The lane mask is assembled from ballots of BARE compares.
             unsigned long long m;
-            if constexpr (STAGE == kStageAngle) {
-                const float2 er = g.v[3 * px], eg = g.v[3 * px + 1], eb = g.v[3 * px + 2];
-                const bool tc = is_tissue_f(er.x, eg.x, eb.x, ylimf);
-                const float x = fmaf(K.V[4], eb.y, fmaf(K.V[2], eg.y, K.V[0] * er.y));
-                const float y = fmaf(K.V[5], eb.y, fmaf(K.V[3], eg.y, K.V[1] * er.y));
-                const float d = x + fabsf(y);
-                const float t0 = fmaf(nhi0m, d, y), t1 = fmaf(nlo1m, d, y);
-                const bool pp = fminf(fminf(x, t0), -t1) > 0.0f;             // x > 0, y > hi0m d, y < lo1m d
-                m = __builtin_amdgcn_ballot_w64(tc) & ~__builtin_amdgcn_ballot_w64(pp);
-            } else if constexpr (STAGE == kStageMerged && XBOUND) {
+            if constexpr (STAGE == kStageMerged && XBOUND) {
                 const float er = g.v[3 * px], eg = g.v[3 * px + 1], eb = g.v[3 * px + 2];
                 const float x = fmaf(K.V[4], eb, fmaf(K.V[2], eg, K.V[0] * er));
                 const float y = fmaf(K.V[5], eb, fmaf(K.V[3], eg, K.V[1] * er));
@@ -1198,25 +1197,6 @@ struct ConcTileKey {
     }
 };
 // exact keys (for bracket 0 and bracket 1) of raw candidate i
-struct RawAngleKey2 {                 // one pseudo-angle serves both brackets; every raw candidate is tissue
-    const uint32_t* raw; TabView tab; float V[6];
-    __device__ __forceinline__ void operator()(int i, float& k0, float& k1) const {
-        const uint32_t s = raw[i];
-        k0 = k1 = angle_key(V, tab.odf(s & 255u), tab.odf((s >> 8) & 255u), tab.odf((s >> 16) & 255u));
-    }
-};
-// the same when the raw list also holds pixels the merged sweep collected for their concentrations: those may be background
-// (NaN: no angle key)
-struct RawAngleKeyT {
-    const uint32_t* raw; TabView tab; float V[6]; float ylimf;
-    __device__ __forceinline__ void operator()(int i, float& k0, float& k1) const {
-        const uint32_t s = raw[i];
-        const uint32_t r = s & 255u, g = (s >> 8) & 255u, b = (s >> 16) & 255u;
-        const bool tissue = is_tissue_f(tab.gam(r), tab.gam(g), tab.gam(b), ylimf);
-        const float k = angle_key(V, tab.odf(r), tab.odf(g), tab.odf(b));
-        k0 = k1 = tissue ? k : nan_f();
-    }
-};
 struct RawConcKey2 {
     const uint32_t* raw; TabView tab; LassoK L;
     __device__ __forceinline__ void operator()(int i, float& k0, float& k1) const {
@@ -1583,7 +1563,7 @@ __device__ __forceinline__ void fin_tab_expand(RowTab& tab) {
     __syncthreads();
 }
 
-// keys of a raw word (same arithmetic as RawAngleKeyT / RawConcKey2: the per-phase schedule must select the same values)
+// keys of a raw word (angle_key / lasso2 as in the tile-key functors: every path must select the same values)
 struct WordAngleKey {           // one pseudo-angle serves both brackets; valid = tissue
     FinTab T; float V[6]; float ylimf;
     __device__ __forceinline__ void of_word(uint32_t s, float& k0, float& k1, bool& valid) const {
@@ -2311,42 +2291,6 @@ __device__ __forceinline__ void conc_brackets(const SampleConcKey& key, int n_sa
     wg_brackets_regs<2, KPT, 2>(ord, set_of, p2, lo, hi, S);
 }
 
-static __global__ SL_FINISH_BOUNDS void k_finish_moments(StatsArgs a) {
-    __shared__ SmallTab s_tab;
-    __shared__ SelScratch S;
-    __shared__ double s_sum[10];
-    __shared__ float s_V[6];
-    const int tile = blockIdx.x, tid = threadIdx.x;
-    TileState& st = a.state[tile];
-    s_tab.fill();
-    if (tid < 10) {                                   // fixed order => run-to-run identical sums
-        double t = 0;
-        for (int p = 0; p < a.parts; ++p) t += a.partials[((size_t)tile * a.parts + p) * 10 + tid];
-        s_sum[tid] = t;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        double Vd[6];
-        float Vf[6];
-        st.status = eigvecs_from_moments(s_sum, Vd, Vf);
-        for (int i = 0; i < 6; ++i) { st.Vd[i] = Vd[i]; st.Vf[i] = Vf[i]; s_V[i] = Vf[i]; }
-        st.n_tissue = s_sum[0];
-        st.fallbacks = 0;
-        st.n_raw = 0; st.overflow = 0;
-    }
-    __syncthreads();
-    SampleAngleKey key;
-    key.sample = a.sample + (size_t)tile * a.n_sample;
-    key.tab = view_of(s_tab);
-    for (int i = 0; i < 6; ++i) key.V[i] = s_V[i];
-    key.cps_log2 = a.stride_log2 - 2;
-    key.P = a.P;
-    key.ylimf = a.ylimf;
-    float lo[2], hi[2];
-    angle_brackets<kFinishThreads>(key, a.n_sample, a.pct, lo, hi, S);
-    if (tid == 0) { st.lo[0] = lo[0]; st.hi[0] = hi[0]; st.lo[1] = lo[1]; st.hi[1] = hi[1]; }
-}
-
 template <int STAGE, bool ALIGNED>
 static __global__ __launch_bounds__(kSweepThreads, 4) void k_select(StatsArgs a) {
     __shared__ RowTab s_tab;
@@ -2359,11 +2303,19 @@ static __global__ __launch_bounds__(kSweepThreads, 4) void k_select(StatsArgs a)
         const int tile = item / a.parts, part = item % a.parts;
         TileState& st = a.state[tile];
         if (st.status != SL_TILE_OK) continue;                             // block-uniform
+        if (STAGE == kStageConc && a.mstate && a.mstate[tile].conc_done) continue;      // (merged schedule: the tile's maxC is settled)
         SelConsts K;
         K.xmin = -INFINITY;
-        if (STAGE == kStageAngle) {
+        if (STAGE == kStageMerged) {
+            const TileMerged& tm = a.mstate[tile];
             for (int i = 0; i < 6; ++i) K.V[i] = in_vgpr(st.Vf[i]);
             K.L.g12 = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                K.u[i][0] = in_vgpr(tm.mk.u[i][0]); K.u[i][1] = in_vgpr(tm.mk.u[i][1]); K.kt[i] = in_vgpr(tm.mk.kt[i]);
+                K.eps[i] = in_vgpr(tm.mk.eps[i]); K.thr[i] = in_vgpr(tm.mk.thr[i]);
+            }
+            K.xmin = uni(tm.xmin);
         } else {
             lasso_consts(st.M, a.lam, K.L);
             vgpr(K.L);
@@ -2373,79 +2325,16 @@ static __global__ __launch_bounds__(kSweepThreads, 4) void k_select(StatsArgs a)
         int c0, c1;
         part_range((a.P + 3) >> 2, a.parts, part, c0, c1);
         RawSink sink{(uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(s_stage[wave])), 0u, a.raw + (size_t)tile * a.cap_raw, &st.n_raw, &st.overflow, (uint32_t)a.cap_raw, (uint32_t)kStageWave};
-        if ((size_t)a.P * 3 >= kStreamBytes) select_sweep<STAGE, ALIGNED, kPhaseTrip, true>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, K, sink);
-        else select_sweep<STAGE, ALIGNED, kPhaseTrip, false>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, K, sink);
+        const bool stream = (size_t)a.P * 3 >= kStreamBytes;
+        if (STAGE == kStageMerged && K.xmin > -INFINITY) {                   // block-uniform: the projection bound stands in for the tissue test
+            if (stream) select_sweep<kStageMerged, ALIGNED, kPhaseTrip, true, true>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, K, sink);
+            else select_sweep<kStageMerged, ALIGNED, kPhaseTrip, false, true>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, K, sink);
+        } else {
+            if (stream) select_sweep<STAGE, ALIGNED, kPhaseTrip, true>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, K, sink);
+            else select_sweep<STAGE, ALIGNED, kPhaseTrip, false>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, K, sink);
+        }
         sink.flush(lane);
     }
-}
-
-static __global__ SL_FINISH_BOUNDS void k_finish_angle(StatsArgs a) {
-    __shared__ SmallTab s_tab;
-    __shared__ SelScratch S;
-    __shared__ float s_res[4];
-    __shared__ LassoK s_L;
-    const int tile = blockIdx.x, tid = threadIdx.x;
-    TileState& st = a.state[tile];
-    if (st.status != SL_TILE_OK) {
-        if (tid < 6) st.M[tid] = nan_d();
-        return;
-    }
-    s_tab.fill();
-    __syncthreads();
-    const uint8_t* src = a.rgb + (size_t)tile * a.P * 3;
-    AngleTileKey tkey;
-    tkey.src = src; tkey.tab = view_of(s_tab); tkey.ylimf = a.ylimf;
-    RawAngleKey2 rkey;
-    rkey.raw = a.raw + (size_t)tile * a.cap_raw; rkey.tab = view_of(s_tab);
-    for (int i = 0; i < 6; ++i) { tkey.V[i] = st.Vf[i]; rkey.V[i] = st.Vf[i]; }
-    const uint32_t T = (uint32_t)st.n_tissue;
-    long long k[2];
-    double gfrac[2];
-    percentile_pos((double)T, 100.0 - a.pct, k[0], gfrac[0]);
-    percentile_pos((double)T, a.pct, k[1], gfrac[1]);
-    const bool complete = st.n_raw <= (uint32_t)a.cap_raw && st.overflow == 0;
-    const uint32_t n_raw = st.n_raw < (uint32_t)a.cap_raw ? st.n_raw : (uint32_t)a.cap_raw;
-    float* cand0 = a.cand + ((size_t)tile * 2 + 0) * a.cap_list;
-    float* cand1 = a.cand + ((size_t)tile * 2 + 1) * a.cap_list;
-    const float los[2] = {st.lo[0], st.lo[1]}, his[2] = {st.hi[0], st.hi[1]};
-    uint32_t n_lt[2], n_in[2];
-    wg_refine((int)n_raw, rkey, los, his, cand0, cand1, (uint32_t)a.cap_list, n_lt, n_in, S);
-    // plain pixels (tissue pixels that were not collected) sit between the two brackets
-    const long long base[2] = {0, (long long)T - (long long)st.n_raw};
-    int fallbacks = 0;
-    for (int li = 0; li < 2; ++li) {
-        float xa, xb;
-        stage_order_stats(li ? cand1 : cand0, n_in[li], (uint32_t)a.cap_list, complete, los[li], his[li], base[li] + n_lt[li], a.P, tkey, T,
-                          k[li], xa, xb, fallbacks, S);
-        if (tid == 0) { s_res[2 * li] = xa; s_res[2 * li + 1] = xb; }
-        __syncthreads();
-    }
-    double M[6];
-    if (tid < 64) stain_matrix_from_angles(st.Vd, s_res, gfrac, M, tid);     // (st.Vd: global memory, read-only here)
-    __syncthreads();                                     // every lane has read s_res before lane 0 reuses s_res[0]
-    if (tid == 0) {
-        const bool singular = stain_matrix_singular(M);
-        if (singular) st.status = SL_TILE_DEGENERATE_COV;
-        for (int i = 0; i < 6; ++i) st.M[i] = singular ? nan_d() : M[i];
-        st.fallbacks += fallbacks;
-        LassoK L;
-        lasso_consts(M, a.lam, L);
-        s_L = L;
-        s_res[0] = singular ? 1.0f : 0.0f;
-        st.n_raw = 0; st.overflow = 0;
-    }
-    __syncthreads();
-    if (s_res[0] != 0.0f) return;                        // block-uniform: the concentration stage skips this tile
-    SampleConcKey ckey;
-    ckey.sample = a.sample + (size_t)tile * a.n_sample;
-    ckey.tab = view_of(s_tab);
-    ckey.L = s_L;
-    ckey.cps_log2 = a.stride_log2 - 2;
-    ckey.P = a.P;
-    ckey.col = 0;
-    float lo[2], hi[2];
-    conc_brackets<kFinishThreads>(ckey, a.n_sample, lo, hi, S);
-    if (tid == 0) { st.lo[0] = lo[0]; st.hi[0] = hi[0]; st.lo[1] = lo[1]; st.hi[1] = hi[1]; }
 }
 
 static __global__ SL_FINISH_BOUNDS void k_finish_conc(StatsArgs a, double* M_out, double* maxC_out,
@@ -2456,6 +2345,7 @@ static __global__ SL_FINISH_BOUNDS void k_finish_conc(StatsArgs a, double* M_out
     __shared__ LassoK s_L;
     const int tile = blockIdx.x, tid = threadIdx.x;
     TileState& st = a.state[tile];
+    if (a.mstate && a.mstate[tile].conc_done) return;             // block-uniform: settled (and written out) by k_finish2m
     const bool bad = st.status != SL_TILE_OK;
     if (!bad) {
         s_tab.fill();
@@ -2891,6 +2781,109 @@ __device__ __noinline__ int fused_finish2(FusedShared<NT>* shp, const uint8_t* s
     fin_tab_expand<NT>(sh.tab);                                   // the row table back for the sweeps to come
     return fallbacks;
 #undef SL_SUB
+}
+
+// ---- the merged schedule, one launch per phase: k_moments -> k_finish1m -> k_select<merged> -> k_finish2m [-> k_select<conc>,
+// k_finish_conc for the rare tile whose exact stain matrix left the assumed box] -> k_apply.  The finish kernels ARE the fused
+// kernel's finish steps (fused_finish1 / fused_finish2) on a FusedShared block of their own, with the tile's state carried in
+// TileState / TileMerged between the launches: both schedules select the same values by construction.
+constexpr int kMFinishThreads = 1024;
+static __global__ __launch_bounds__(kMFinishThreads) void k_finish1m(StatsArgs a) {
+    __shared__ FusedShared<kMFinishThreads> sh;
+    const int tile = blockIdx.x, tid = threadIdx.x;
+    TileState& st = a.state[tile];
+    sh.tab.fill_b();
+    if (tid < 10) {                                   // fixed order => run-to-run identical sums
+        double t = 0;
+        for (int p = 0; p < a.parts; ++p) t += a.partials[((size_t)tile * a.parts + p) * 10 + tid];
+        sh.sum[tid] = t;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double Vd[6];
+        float Vf[6];
+        sh.status = eigvecs_from_moments(sh.sum, Vd, Vf);
+        for (int i = 0; i < 6; ++i) { sh.Vd[i] = Vd[i]; sh.Vf[i] = Vf[i]; }
+        sh.mk.ok = 0;
+        sh.xmin = -INFINITY;
+    }
+    __syncthreads();
+    if (sh.status == SL_TILE_OK)                                               // block-uniform
+        fused_finish1<kMFinishThreads>(&sh, a.sample + (size_t)tile * a.n_sample, a.n_sample, a.stride_log2, a.P, a.ylimf, a.pct, a.lam, nullptr);
+    __syncthreads();
+    if (tid == 0) {
+        st.status = sh.status;
+        st.n_tissue = sh.sum[0];
+        for (int i = 0; i < 6; ++i) { st.Vd[i] = sh.Vd[i]; st.Vf[i] = sh.Vf[i]; }
+        st.lo[0] = sh.lo[0]; st.hi[0] = sh.hi[0]; st.lo[1] = sh.lo[1]; st.hi[1] = sh.hi[1];
+        st.fallbacks = 0;
+        st.n_raw = 0; st.overflow = 0;
+        TileMerged& tm = a.mstate[tile];
+        tm.mk = sh.mk;
+        tm.xmin = sh.xmin;
+        tm.conc_done = 0;
+    }
+}
+
+static __global__ __launch_bounds__(kMFinishThreads) void k_finish2m(StatsArgs a, double* M_out, double* maxC_out, int32_t* status_out,
+                                                                    int32_t* fallbacks_out, int tile0) {
+    __shared__ FusedShared<kMFinishThreads> sh;
+    const int tile = blockIdx.x, tid = threadIdx.x;
+    TileState& st = a.state[tile];
+    TileMerged& tm = a.mstate[tile];
+    const bool bad = st.status != SL_TILE_OK;                                  // block-uniform
+    int fallbacks = 0;
+    if (!bad) {
+        sh.tab.fill_b();
+        if (tid == 0) {
+            sh.status = SL_TILE_OK;
+            sh.sum[0] = st.n_tissue;
+            for (int i = 0; i < 6; ++i) { sh.Vd[i] = st.Vd[i]; sh.Vf[i] = st.Vf[i]; }
+            sh.lo[0] = st.lo[0]; sh.hi[0] = st.hi[0]; sh.lo[1] = st.lo[1]; sh.hi[1] = st.hi[1];
+            sh.n_raw = st.n_raw; sh.overflow = st.overflow;
+            sh.mk = tm.mk;
+            sh.conc_done = 0;
+            sh.maxC[0] = sh.maxC[1] = nan_d();
+        }
+        __syncthreads();
+        fallbacks = fused_finish2<kMFinishThreads>(&sh, a.rgb + (size_t)tile * a.P * 3, a.raw + (size_t)tile * a.cap_raw,
+                                                   a.cand + ((size_t)tile * 2 + 0) * a.cap_list, a.cand + ((size_t)tile * 2 + 1) * a.cap_list, a.P,
+                                                   a.cap_raw, a.cap_list, a.ylimf, a.pct, a.lam, nullptr);
+        __syncthreads();
+        const bool singular = sh.status == SL_TILE_DEGENERATE_COV;             // block-uniform
+        const bool settled = sh.conc_done != 0 || singular;                    // nothing left for the concentration stage to do
+        if (tid == 0) {
+            st.status = sh.status;
+            for (int i = 0; i < 6; ++i) st.M[i] = singular ? nan_d() : sh.M[i];
+            st.maxC[0] = (singular || !sh.conc_done) ? nan_d() : sh.maxC[0];
+            st.maxC[1] = (singular || !sh.conc_done) ? nan_d() : sh.maxC[1];
+            st.fallbacks += fallbacks;
+            st.n_raw = 0; st.overflow = 0;
+            tm.conc_done = settled ? 1 : 0;
+        }
+        if (!settled) {
+            // the exact matrix left the box the sweep assumed (or a bracket missed): brackets for the separate concentration sweep,
+            // as k_finish_angle leaves them
+            if (tid == 0) { LassoK L; lasso_consts(sh.M, a.lam, L); sh.L = L; }
+            __syncthreads();
+            SampleConcKey ckey;
+            ckey.sample = a.sample + (size_t)tile * a.n_sample; ckey.tab = view_of_b(sh.tab); ckey.L = sh.L; ckey.cps_log2 = a.stride_log2 - 2;
+            ckey.P = a.P; ckey.col = 0;
+            float lo[2], hi[2];
+            conc_brackets<kMFinishThreads>(ckey, a.n_sample, lo, hi, sh.S);
+            if (tid == 0) { st.lo[0] = lo[0]; st.hi[0] = hi[0]; st.lo[1] = lo[1]; st.hi[1] = hi[1]; }
+            return;                                                            // k_select<conc> / k_finish_conc take it from here
+        }
+    } else if (tid == 0) {
+        for (int i = 0; i < 6; ++i) st.M[i] = nan_d();
+        st.maxC[0] = st.maxC[1] = nan_d();
+        tm.conc_done = 1;
+    }
+    __syncthreads();
+    if (tid < 6 && M_out) M_out[(size_t)(tile0 + tile) * 6 + tid] = st.M[tid];
+    if (tid < 2 && maxC_out) maxC_out[(size_t)(tile0 + tile) * 2 + tid] = st.maxC[tid];
+    if (tid == 0 && status_out) status_out[tile0 + tile] = st.status;
+    if (tid == 0 && fallbacks_out) fallbacks_out[tile0 + tile] = bad ? 0 : st.fallbacks;
 }
 
 enum { kMethodMacenko = 0, kMethodVahadane = 1 };
