@@ -2296,6 +2296,14 @@ static __global__ __launch_bounds__(kSweepThreads, 4) void k_select(StatsArgs a)
     __shared__ RowTab s_tab;
     __shared__ uint32_t s_stage[kSweepThreads / 64][kStageWave];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (STAGE == kStageConc && a.mstate) {   // merged Macenko schedule: normally every tile is settled already -- leave before the table is built
+        bool any = false;
+        for (int item = blockIdx.x; item < a.n_items; item += gridDim.x) {
+            const int tile = item / a.parts;
+            any = any | (a.state[tile].status == SL_TILE_OK && !a.mstate[tile].conc_done);
+        }
+        if (!any) return;                    // block-uniform
+    }
     s_tab.fill_b();
     __syncthreads();
     const TabReaderB T = TabReaderB::make(s_tab);
