@@ -27,7 +27,7 @@ class SlProfile(C.Structure):
 
 PROF_MOMENTS, PROF_SELECT_ANGLE, PROF_SELECT_CONC, PROF_FINISH, PROF_APPLY, PROF_DICT = 1, 2, 4, 8, 16, 32
 PROF_FUSED_FIT, PROF_FUSED_TRANSFORM = 64, 128
-PROF_NAMES = {1: "k_moments", 2: "k_select<angle>", 4: "k_select<conc>", 8: "k_finish_*", 16: "k_apply", 32: "k_dict",
+PROF_NAMES = {1: "k_moments", 2: "k_select<merged>", 4: "k_select<conc>", 8: "k_finish_*", 16: "k_apply", 32: "k_dict",
               64: "k_macenko_fused<fit>", 128: "k_macenko_fused<transform>"}
 
 

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Collects every measurement the docs cite into gpurun_out/ (run on the GPU box from the repo root):
-#   make -C tools && /usr/local/graft/bin/gpurun --timeout 1800 -- 'bash tools/collect_profiles.sh r02'
-# then copy gpurun_out/r02_* to profiles/ (tracked); bench.py reads <tag>_pmc_traffic.json from there.
-tag=${1:-r02}
+#   make -C tools && /usr/local/graft/bin/gpurun --timeout 1800 -- 'bash tools/collect_profiles.sh r03'
+# then copy gpurun_out/r03_* to profiles/ (tracked); bench.py reads <tag>_pmc_traffic.json from there.
+tag=${1:-r03}
 cd "$GRAFT_REPO_ROOT" || exit 1
 out=$PWD/gpurun_out
 mkdir -p "$out"
@@ -11,7 +11,7 @@ dev=$PWD/stainlib_amd/csrc/libstainlib_hip_dev.so
 python bench.py --steps 20 --warmup 3 2>/dev/null | tail -1 > "$out/${tag}_bench_n1.json"
 python tools/crossover.py 2>/dev/null | grep "size" > "$out/${tag}_crossover.txt"
 python tools/phase_classes.py 1024 2>/dev/null | grep "^size" > "$out/${tag}_phase_classes.txt"
-[ -f "$dev" ] && STAINLIB_HIP_LIB=$dev python tools/phase_times.py 512 1024 2>/dev/null | grep -A12 "per-tile" > "$out/${tag}_phase_times.txt"
+[ -f "$dev" ] && STAINLIB_HIP_LIB=$dev python tools/merged_diag.py 512 1024 2>/dev/null | grep -v amdgpu > "$out/${tag}_phase_times.txt"
 python tools/bench_pipeline.py 2>/dev/null | tail -3 > "$out/${tag}_pipeline.txt"
 # rocprofv3 kernel trace of the same bench command (no CPU baseline / secondary: the trace is about the headline kernels)
 rm -rf /tmp/kt; timeout 600 rocprofv3 --kernel-trace -d /tmp/kt -o p -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary > /dev/null 2>&1

@@ -34,7 +34,7 @@ def pick(table, needle, counter):
 f, w = dump(f"{d}/{tag}_pmc_f.txt"), dump(f"{d}/{tag}_pmc_w.txt")
 tiles, px = 512, 1048576
 kernels = {}
-for name, needle, alg_bpp in (("k_fused<macenko,transform>", "k_fused<0, true, true", 15), ("k_apply", "k_apply<", 6)):
+for name, needle, alg_bpp in (("k_fused<macenko,transform>", "k_fused<0, true, true", 12), ("k_apply", "k_apply<", 6)):
     fr, wr = pick(f, needle, "FETCH_SIZE"), pick(w, needle, "WRITE_SIZE")
     if fr is None or wr is None:
         continue
@@ -50,7 +50,7 @@ for n in (64, 512):
     except OSError:
         continue
     phase[f"n{n}"] = {k: pick(t, needle, "FETCH_SIZE") for k, needle in
-                      (("k_moments", "k_moments<"), ("k_select<angle>", "k_select<0"), ("k_select<conc>", "k_select<1"), ("k_apply", "k_apply<"))}
+                      (("k_moments", "k_moments<"), ("k_select<merged>", "k_select<2"), ("k_select<conc>", "k_select<1"), ("k_apply", "k_apply<"))}
 doc = {
     "how": "rocprofv3 --pmc FETCH_SIZE and (separate pass) --pmc WRITE_SIZE on `python tools/run_fused_once.py 512` (512 tiles of "
            "1024x1024x3 uint8 per launch), MI355X, ROCm 7.2 (tools/collect_profiles.sh, tools/make_pmc_traffic.py). Counters are in KiB "

@@ -1,5 +1,7 @@
-"""How often the merged selection sweep of the fused Macenko kernel settles the concentration percentiles (development aid):
-resweeps (tiles that needed sweep 3), slow exact fallbacks, and the phase times when the development build is loaded."""
+"""The fused Macenko kernel from the inside (development aid): how often the merged selection sweep settles the concentration
+percentiles (resweeps = tiles that needed sweep 3), slow exact fallbacks, and -- with the development build
+(make -C stainlib_amd/csrc dev; STAINLIB_HIP_LIB=.../libstainlib_hip_dev.so) -- per-tile phase times, the sub-steps of both finish
+steps, list sizes and the bracket step timers.    python tools/merged_diag.py [tiles] [size]"""
 import ctypes as C
 import sys
 
@@ -73,6 +75,10 @@ if hasattr(lib, "sl_debug_set_phase_clock"):
         h2 = n // 2
         for nm, v in steps:
             print(f"    {nm:20s} {v.mean():8.1f}   first half {v[:h2].mean():8.1f}  second half {v[h2:].mean():8.1f}")
+    t = t.copy()
+    no_resweep = t[:, 4] == 0                           # markers 4 and 5 are only written on the resweep path
+    t[no_resweep, 4] = t[no_resweep, 6]
+    t[no_resweep, 5] = t[no_resweep, 6]
     d = np.diff(t, axis=1)
     names = ["sweep1 moments", "finish1 eig+brackets+box", "sweep2 merged", "finish2 M (+maxC)", "sweep3 conc (resweep)", "finish3 maxC", "sweep4 apply"]
     for i, nm in enumerate(names):
