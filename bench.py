@@ -339,7 +339,7 @@ def secondary_configs(dev, Mt, mct):
         on = so.ExtractiveStainNormalizer("macenko")
         on.stain_matrix_target, on.maxC_target = Mt_np, mct_np.reshape(1, 2)
         structured[kind] = {"ms_per_batch": round(ms, 4), "tiles_per_s": round(512 / ms * 1e3, 1), "failed_tiles": int((st != 0).sum()),
-                            "exact_fallbacks": int(fb.sum()), "of": 2048, "resweeps": int(rsw.sum()),
+                            "exact_fallbacks": int(fb.sum()), "of": 2048, "resweeps": int((rsw != 0).sum()), "resweep_reasons": {str(k): int((rsw == k).sum()) for k in (1, 2, 3, 4) if int((rsw == k).sum())},
                             "parity_tile0": _flips(o[0].cpu().numpy(), on.transform(four[0]))}
         del rgb
     structured["note"] = ("oracle.structured_tile: 'blobs' = nuclei, slow eosin gradients, a lumen, little noise (neighbouring pixels strongly "
@@ -517,7 +517,7 @@ def main():
     status = res[3]
     n_bad = int((status != 0).sum())
     n_fallbacks = int(fallbacks.sum())
-    n_resweeps = int(resweeps.sum())
+    n_resweeps = int((resweeps != 0).sum())
 
     per_rank = [B * a.steps / t_mine]
     if world > 1:

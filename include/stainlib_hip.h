@@ -103,6 +103,10 @@ typedef struct SlProfile {
 /* Extractor constants.  The reference never forwards these from fit/transform, so the
  * defaults are effectively constants (macenko_stain_extractor.py:7,
  * vahadane_stain_extractor.py:19, stain_utils.py:69). */
+#define SL_RESWEEP_NO_BOX 1         /* the sample's brackets left no usable box of stain matrices (open, or too wide) */
+#define SL_RESWEEP_OUTSIDE_BOX 2    /* the exact stain matrix fell outside the box the sweep assumed */
+#define SL_RESWEEP_BRACKET_MISSED 3 /* a concentration bracket did not hold the wanted rank */
+#define SL_RESWEEP_LIST_FULL 4      /* the candidate list overflowed */
 typedef struct SlParams {
     double luminosity_threshold; /* 0.8  (binary64 like the Python float the reference compares with) */
     double angular_percentile;   /* 99   */
@@ -118,7 +122,7 @@ typedef struct SlParams {
                                    (two angular, two concentration percentiles) needed the slow exact selection over the whole
                                    tile because the sampled bracket missed or its candidate list overflowed (diagnostics;
                                    results never depend on it).  Written by sl_macenko_* / sl_vahadane_*. */
-    int32_t* resweeps_out;      /* NULL (default) or DEVICE pointer to n ints: 1 for a tile whose concentration percentiles needed a
+    int32_t* resweeps_out;      /* NULL (default) or DEVICE pointer to n ints: nonzero (an SL_RESWEEP_* reason, below) for a tile whose concentration percentiles needed a
                                    selection sweep of their own (the persistent Macenko kernel collects the angular and the
                                    concentration candidates in ONE sweep under a sample estimate of the stain matrix and repeats
                                    the concentration part when the exact matrix falls outside the assumed box; diagnostics).

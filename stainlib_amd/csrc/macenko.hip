@@ -76,7 +76,9 @@ Layout make_layout(int n, long P, int method = kMethodMacenko, int schedule = 0,
     // list capacities scale with the tile: ~7 % of the pixels are raw candidates of the merged selection sweep (angle ~2.5 %,
     // concentrations ~4.5 %), ~1 % end up in a bracket
     L.cap_raw = (int)(P / 8 > kMinCapRaw ? P / 8 : kMinCapRaw);
-    L.cap_list = (int)(P / 40 > kMinCapList ? P / 40 : kMinCapList);
+    // (bracket members: P/40 held them on i.i.d. tiles; spatially smooth and real tissue tiles put 30-60 k pixels into the concentration
+    //  brackets the merged sweep widens by the box of stain matrices, and a full list costs the tile its separate sweep)
+    L.cap_list = (int)(P / 12 > kMinCapList ? P / 12 : kMinCapList);
     L.off_cand = o;     o = align_up(o + sizeof(uint32_t) * (size_t)L.cap_raw * slots);
     L.off_list = o;     o = align_up(o + sizeof(float) * 2 * (size_t)L.cap_list * slots);
     L.off_state = o;    o = align_up(o + sizeof(TileState) * (size_t)L.G);

@@ -40,7 +40,7 @@ namespace sl {
 
 constexpr int kMaxSample = 16384;   // samples per tile (<= P/64)
 constexpr int kMinCapRaw = 65536;   // raw-pixel candidate capacity per tile and stage: max(this, P/12), set by the host
-constexpr int kMinCapList = 16384;  // exact-key bracket members per list after the refine pass: max(this, P/40)
+constexpr int kMinCapList = 16384;  // exact-key bracket members per list after the refine pass: max(this, P/12)
 #ifdef SL_EXP_FIN512
 constexpr int kFinishThreads = 512;
 #else
@@ -2613,6 +2613,7 @@ struct FusedShared {
     int status;
     int conc_done;           // the merged sweep's candidates settled maxC: sweep 3 is skipped
     float xmin;              // tissue_x_bound of the tile (merged sweep)
+    int why;                 // why the merged sweep's concentration candidates were not used (SL_RESWEEP_*; 0 = they were)
     MergedConc mk;
 };
 
@@ -2740,6 +2741,7 @@ __device__ __noinline__ int fused_finish2(FusedShared<NT>* shp, const uint8_t* s
             // the concentration candidates of the merged sweep are usable iff the exact M lies where the sweep assumed
             const bool use = sh.status == SL_TILE_OK && complete && merged_verify(sh.mk, M, lam);
             sh.conc_done = use ? 1 : 0;
+            sh.why = use ? 0 : (!sh.mk.ok ? SL_RESWEEP_NO_BOX : (!complete ? SL_RESWEEP_LIST_FULL : SL_RESWEEP_OUTSIDE_BOX));
             if (use) { LassoK L; lasso_consts(M, lam, L); sh.L = L; }
         }
     }
@@ -2781,7 +2783,8 @@ __device__ __noinline__ int fused_finish2(FusedShared<NT>* shp, const uint8_t* s
                 if (!(sh.maxC[0] > 0.0) || !(sh.maxC[1] > 0.0)) sh.status = SL_TILE_ZERO_MAXC;
             }
         } else if (tid == 0) {
-            sh.conc_done = 0;                                     // a bracket missed: sweep 3 settles it
+            sh.conc_done = 0;                                     // a bracket missed (or holds more members than a list): sweep 3 settles it
+            sh.why = (rc.n_in[0] > (uint32_t)cap_list || rc.n_in[1] > (uint32_t)cap_list) ? SL_RESWEEP_LIST_FULL : SL_RESWEEP_BRACKET_MISSED;
         }
         __syncthreads();
         SL_SUB(15);
@@ -3143,7 +3146,7 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
             sh.maxC[0] = sh.maxC[1] = nan_d();
         }
         __syncthreads();
-        if (tid == 0 && a.resweep_out) a.resweep_out[tile] = (METHOD == kMethodMacenko && resweep) ? 1 : 0;
+        if (tid == 0 && a.resweep_out) a.resweep_out[tile] = (METHOD == kMethodMacenko && resweep) ? (sh.why ? sh.why : SL_RESWEEP_NO_BOX) : 0;
         if (tid < 6 && a.M_out) a.M_out[(size_t)tile * 6 + tid] = sh.M[tid];
         if (tid < 2 && a.maxC_out) a.maxC_out[(size_t)tile * 2 + tid] = sh.maxC[tid];
         if (tid == 0 && a.status_out) a.status_out[tile] = sh.status;

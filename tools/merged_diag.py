@@ -24,7 +24,7 @@ p.resweeps_out = rs.data_ptr()
 out = torch.empty_like(rgb)
 o, M, mc, status = engine.macenko_transform(rgb, Mt[0], mct[0], out=out, params=p)
 torch.cuda.synchronize()
-print(f"tiles {n} x {size}^2: resweeps {int((rs == 1).sum())}  untouched {int((rs == -1).sum())}  exact fallbacks {int(fb.sum())}  bad status {int((status != 0).sum())}")
+print(f"tiles {n} x {size}^2: resweeps {int((rs > 0).sum())} (reasons 1 no box / 2 outside box / 3 bracket missed / 4 list full: {[int((rs == k).sum()) for k in (1, 2, 3, 4)]})  untouched {int((rs == -1).sum())}  exact fallbacks {int(fb.sum())}  bad status {int((status != 0).sum())}")
 def med(fn, reps=15):
     for _ in range(5):
         fn()

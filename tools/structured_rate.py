@@ -29,14 +29,24 @@ ws = engine.Workspace()
 iid = synth_tiles(n, 1024, 1024, seed=7)
 out = torch.empty_like(iid)
 print(f"i.i.d.      {med(lambda: engine.macenko_transform(iid, Mt[0], mct[0], out=out, ws=ws)):.3f} ms per {n} tiles")
-for kind in ("blobs", "white_bg", "quantized", "palette12"):
-    base = torch.as_tensor(np.stack([so.structured_tile(kind, 1024, 1024, 20 + s) for s in range(4)]), device="cuda")
+def ihc_four():
+    import os
+    I = np.load(os.path.join("tests", "golden", "tissue_ihc_512.npz"))["input"]
+    row = np.concatenate([I, I[:, ::-1]], axis=1)
+    T = np.ascontiguousarray(np.concatenate([row, row[::-1]], axis=0))
+    return np.stack([T, np.ascontiguousarray(np.roll(T, 301, axis=0)), np.ascontiguousarray(np.roll(T, 517, axis=1)), np.ascontiguousarray(T.transpose(1, 0, 2))])
+
+
+for kind in ("blobs", "white_bg", "quantized", "palette12", "real_tissue_ihc"):
+    base = torch.as_tensor(ihc_four() if kind == "real_tissue_ihc" else np.stack([so.structured_tile(kind, 1024, 1024, 20 + s) for s in range(4)]), device="cuda")
     rgb = base[torch.arange(n, device="cuda") % 4].contiguous()
     p = engine.make_params()
     fb = engine.attach_fallbacks(p, n)
+    rs = torch.zeros((n,), dtype=torch.int32, device="cuda")
+    p.resweeps_out = rs.data_ptr()
     t = med(lambda: engine.macenko_transform(rgb, Mt[0], mct[0], params=p, out=out, ws=ws))
     o, M, mc, st = engine.macenko_transform(rgb, Mt[0], mct[0], params=p, out=out, ws=ws)
     torch.cuda.synchronize()
     Mo = so.macenko_stain_matrix(base[0].cpu().numpy())
-    print(f"{kind:10s}  {t:.3f} ms per {n} tiles = {n / t:.1f} k tiles/s   failed tiles {int((st != 0).sum())}   exact fallbacks {int(fb.sum())} of {4 * n}"
+    print(f"{kind:10s}  {t:.3f} ms per {n} tiles = {n / t:.1f} k tiles/s   failed tiles {int((st != 0).sum())}   exact fallbacks {int(fb.sum())} of {4 * n}   resweeps {int((rs != 0).sum())} (reasons 1..4: {[int((rs == k).sum()) for k in (1, 2, 3, 4)]})"
           f"   |M - oracle| tile 0 {np.abs(M[0].cpu().numpy() - Mo).max():.1e}", flush=True)
