@@ -374,3 +374,37 @@ def test_transform_with_a_negative_target_entry_wraps_like_the_reference_in_both
             print(f"wrap case schedule {sched} tile {i}: {int((d != 0).sum())} of {d.size} bytes differ, max value {pre.max():.0f}")
             assert (d != 0).sum() <= int(3e-4 * d.size), (sched, i, int((d != 0).sum()))
     assert torch.equal(outs[0], outs[1])
+
+
+def test_first_eigenvector_with_a_negative_component_takes_the_per_pixel_tissue_test():
+    """The merged selection sweep normally replaces the per-pixel tissue test by a bound on the first projection, valid when the first
+    eigenvector is positive (tissue_x_bound).  A tile whose dominant variation trades one channel against another has a first
+    eigenvector of mixed signs: the sweep then keeps the tissue test -- same results against the oracle, in both schedules, also
+    with a lower luminosity threshold (where part of the tile is background)."""
+    from stainlib_amd import engine
+    rng = np.random.RandomState(5)
+    h = w = 160
+    t = rng.uniform(0, 1, (h, w))
+    I = np.stack([(40 + 150 * t + rng.normal(0, 4, (h, w))).clip(1, 255), (200 - 150 * t + rng.normal(0, 4, (h, w))).clip(1, 255),
+                  (120 + rng.normal(0, 10, (h, w))).clip(1, 255)], -1).astype(np.uint8)
+    tgt = so.synth_tile(96, 96, 1001, so.M_TRUE_TGT)
+    Mt, mct, _ = engine.macenko_fit(to_dev([tgt]))
+    for thr in (0.8, 0.55):
+        d = {}
+        Mo = so.macenko_stain_matrix(I, thr, details=d)
+        assert (d["V"][:, 0] < 0).any()                                  # the case this test is about
+        mco = np.percentile(so.get_concentrations(I, Mo), 99, axis=0)
+        outs = []
+        for sched in (1, 2):
+            p = engine.make_params(schedule=sched, luminosity_threshold=thr)
+            fb = engine.attach_fallbacks(p, 3)
+            out, M, mc, st = engine.macenko_transform(to_dev([I, I[::-1].copy(), I]), Mt[0], mct[0], params=p)
+            assert (st.cpu().numpy() == 0).all() and int(fb.sum()) == 0
+            # (the blue channel of this tile is almost constant: the second and third eigenvalues lie close, which amplifies the
+            #  ~1e-7 of the binary32 burst sums in the moments to ~3e-6 in the third column of M)
+            np.testing.assert_allclose(M.cpu().numpy()[0], Mo, rtol=0, atol=1e-5)
+            np.testing.assert_allclose(mc.cpu().numpy()[0], mco, rtol=1e-5)
+            outs.append(out)
+        assert torch.equal(outs[0], outs[1])
+        want = so.truncate_u8(255 * np.exp(-(so.get_concentrations(I, Mo) * (mct[0].cpu().numpy() / mco)) @ Mt[0].cpu().numpy())).reshape(I.shape)
+        u8_parity(outs[0][0].cpu().numpy(), want, label=f"mixed-sign eigenvector, threshold {thr}")
