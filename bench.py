@@ -371,7 +371,7 @@ def secondary_configs(dev, Mt, mct):
     sec["pooled_slide_512x1024"] = {
         "ms_per_slide": round(ms, 4), "tiles_per_s": round(512 / ms * 1e3, 1), "selection_paths": list(sn.last_path),
         "parity_8_tile_slide": {"M_max_abs_err": float(np.abs(Mp - Mo).max()), "maxC_max_rel_err": float(np.abs(cp / co - 1).max())},
-        "note": "host-driven: 4 full sweeps + 6 over a pixel sample with a host read-back between stages (wall clock, not event time)"}
+        "note": "device-driven since round 3 (sl_pool_*): 4 full sweeps + 6 over a pixel sample + 9 single-workgroup decision steps enqueued as one chain, the apply pass enqueued behind it, ONE read-back at the end (wall clock, not event time)"}
     del rgb, out
 
     # ---- configs[4] at the size of ONE GPU's shard: 100 k tiles / 8 GPUs = 12 500 tiles (39 GB in, 39 GB out, resident in HBM);

@@ -76,20 +76,15 @@ static __global__ __launch_bounds__(kWG) void k_hed(const uint8_t* __restrict__ 
     const int span = (nch + parts - 1) / parts;
     const int c0 = part * span, c1 = min(nch, c0 + span);
     uint32_t bsum = 0;
-    // software pipeline as in k_apply: the next trip's chunks are requested before this trip's arithmetic
-    constexpr int kUH = kUApply;
-    Chunk nxt[kUH];
+    for (int c = c0 + tid; c < c1; c += kWG * kU) {
+        Chunk in[kU];
 #pragma unroll
-    for (int u = 0; u < kUH; ++u) nxt[u] = load_chunk_clamped<ALIGNED, true>(src, nbytes, c0 + tid + u * kWG, c1);
-    for (int c = c0 + tid; c < c1; c += kWG * kUH) {
-        Chunk in[kUH];
-#pragma unroll
-        for (int u = 0; u < kUH; ++u) {
-            in[u] = nxt[u];
-            nxt[u] = load_chunk_clamped<ALIGNED, true>(src, nbytes, c + (kUH + u) * kWG, c1);   // single pass: non-temporal; never predicated (see load_chunk_clamped); dead lanes masked below
+        for (int u = 0; u < kU; ++u) {
+            const int cc = c + u * kWG;
+            in[u] = load_chunk_clamped<ALIGNED, true>(src, nbytes, cc, c1);   // single pass: non-temporal; no predicated load (see load_chunk_clamped); dead lanes masked below
         }
 #pragma unroll
-        for (int u = 0; u < kUH; ++u) {
+        for (int u = 0; u < kU; ++u) {
             const int cc = c + u * kWG;
             const uint32_t one = cc < c1 ? 0x01010101u : 0u;                 // lanes past the end add nothing to the byte sum
             bsum = __builtin_amdgcn_udot4(in[u].w0, one, bsum, false);
