@@ -408,3 +408,22 @@ def test_first_eigenvector_with_a_negative_component_takes_the_per_pixel_tissue_
         assert torch.equal(outs[0], outs[1])
         want = so.truncate_u8(255 * np.exp(-(so.get_concentrations(I, Mo) * (mct[0].cpu().numpy() / mco)) @ Mt[0].cpu().numpy())).reshape(I.shape)
         u8_parity(outs[0][0].cpu().numpy(), want, label=f"mixed-sign eigenvector, threshold {thr}")
+
+
+def test_resweep_reasons_are_reported_by_the_fused_schedule():
+    """SlParams.resweeps_out: 0 for a tile whose concentration percentiles came out of the merged selection sweep, an SL_RESWEEP_*
+    reason otherwise (a 12-colour palette tile overflows its candidate list: SL_RESWEEP_LIST_FULL = 4).  Diagnostics only -- the
+    results are the oracle's either way; the one-launch-per-phase schedule leaves the buffer untouched."""
+    from stainlib_amd import engine
+    tiles = [so.synth_tile(256, 256, 11), so.structured_tile("palette12", 256, 256, 4), so.structured_tile("blobs", 256, 256, 5)]
+    tgt = so.synth_tile(96, 96, 1001, so.M_TRUE_TGT)
+    Mt, mct, _ = engine.macenko_fit(to_dev([tgt]))
+    for sched, want in ((2, [0, 4, 0]), (1, [-1, -1, -1])):
+        p = engine.make_params(schedule=sched)
+        rs = torch.full((3,), -1, dtype=torch.int32, device="cuda")
+        p.resweeps_out = rs.data_ptr()
+        out, M, mc, st = engine.macenko_transform(to_dev(tiles), Mt[0], mct[0], params=p)
+        assert (st.cpu().numpy() == 0).all()
+        assert rs.cpu().tolist() == want
+        for i, I in enumerate(tiles):
+            np.testing.assert_allclose(M.cpu().numpy()[i], so.macenko_stain_matrix(I), rtol=0, atol=M_ATOL)
