@@ -93,8 +93,9 @@ __device__ __forceinline__ void store_chunk(uint8_t* tile, size_t nbytes, int c,
 __device__ __forceinline__ uint32_t trunc_u8(float t) { return ((uint32_t)t) & 0xffu; }
 
 // ---- the normalisation step shared by k_apply and sweep 4 of the fused kernel (bit-identical by construction) ----
-// Issue count per pixel (the sweep is vector-issue bound): the lasso's max(min(a, s), 0) is ONE v_min_f32 with
-// the clamp modifier -- VOP3 clamp is [0, 1], so the concentrations are carried scaled by 2^-k, k chosen per tile from a
+// Issue count per pixel (the sweep is vector-issue bound): the lasso's max(min(a, s), 0) is a v_min_f32 and ONE v_fma_f32
+// with the clamp modifier (fma_clamp01; round 2: three FMAs for s and a clamped v_min_f32) -- VOP3 clamp is [0, 1], so the
+// concentrations are carried scaled by 2^-k, k chosen per tile from a
 // bound on |a|, |s| over every optical density a byte can produce (exact: a power of two), and compensated in q.
 // (Folding the factor 255 into the exponent -- 2^(e + log2 255), three multiplies fewer -- was measured and dropped: a
 // pixel with zero concentrations must give EXACTLY 255 like the reference, and 2^(log2 255) comes out as 254.99998, which
@@ -128,14 +129,15 @@ __device__ __forceinline__ void scale_lasso(LassoK& k, float sc) {
     k.ka1 *= sc; k.ka2 *= sc; k.ks1 *= sc; k.ks2 *= sc;     // (g12, g22 only enter sign tests that are homogeneous in s1, s2)
 }
 
-// max(min(a, s), 0) for operands in [-1, 1]: v_min_f32 with the VOP3 clamp modifier
-__device__ __forceinline__ float min_clamp01(float a, float s) {
+// max(a + r m, 0) for results in [-1, 1]: v_fma_f32 with the VOP3 clamp modifier.  With m = min(a_other, 0) this is the lasso's
+// max(0, min(a, s)) (sl_device.hpp: s = a + r a_other), one instruction where a separate s cost three FMAs and a clamped min.
+__device__ __forceinline__ float fma_clamp01(float r, float m, float a) {
 #ifdef SL_EXP_NOCLAMP
-    return fmaxf(fminf(a, s), 0.0f);
+    return fmaxf(fmaf(r, m, a), 0.0f);
 #else
-    float r;
-    asm("v_min_f32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(s));
-    return r;
+    float o;
+    asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(o) : "v"(r), "v"(m), "v"(a));
+    return o;
 #endif
 }
 
@@ -166,10 +168,8 @@ __device__ __forceinline__ void apply_px(const ApplyK& K, float x, float y, floa
     if (FAST) {                                    // g12 >= 0: branch-free lasso (see lasso2)
         float a1, a2;
         lasso_interior(K.L, x, y, z, a1, a2);
-        const float s1 = fmaf(K.L.ws1[2], z, fmaf(K.L.ws1[1], y, fmaf(K.L.ws1[0], x, K.L.ks1)));
-        const float s2 = fmaf(K.L.ws2[2], z, fmaf(K.L.ws2[1], y, fmaf(K.L.ws2[0], x, K.L.ks2)));
-        c1 = min_clamp01(a1, s1);
-        c2 = min_clamp01(a2, s2);
+        c1 = fma_clamp01(K.L.r1, fminf(a2, 0.0f), a1);
+        c2 = fma_clamp01(K.L.r2, fminf(a1, 0.0f), a2);
     } else {
         lasso2(K.L, x, y, z, c1, c2);
     }
@@ -374,10 +374,8 @@ __device__ __forceinline__ void augment_sweep(const uint8_t* src, uint8_t* dst, 
             if (FAST) {                                    // g12 >= 0: branch-free lasso (see lasso2, apply_px)
                 float i1, i2;
                 lasso_interior(K.L, er.y, eg.y, eb.y, i1, i2);
-                const float s1 = fmaf(K.L.ws1[2], eb.y, fmaf(K.L.ws1[1], eg.y, fmaf(K.L.ws1[0], er.y, K.L.ks1)));
-                const float s2 = fmaf(K.L.ws2[2], eb.y, fmaf(K.L.ws2[1], eg.y, fmaf(K.L.ws2[0], er.y, K.L.ks2)));
-                a1 = min_clamp01(i1, s1);
-                a2 = min_clamp01(i2, s2);
+                a1 = fma_clamp01(K.L.r1, fminf(i2, 0.0f), i1);
+                a2 = fma_clamp01(K.L.r2, fminf(i1, 0.0f), i2);
             } else {
                 lasso2(K.L, er.y, eg.y, eb.y, a1, a2);
             }
