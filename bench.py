@@ -327,8 +327,20 @@ def secondary_configs(dev, Mt, mct):
         return np.stack([T, np.ascontiguousarray(np.roll(T, 301, axis=0)), np.ascontiguousarray(np.roll(T, 517, axis=1)),
                          np.ascontiguousarray(T.transpose(1, 0, 2))])
 
-    for kind in ("blobs", "white_bg", "quantized", "real_tissue_ihc"):
-        four = real_tissue_four() if kind == "real_tissue_ihc" else np.stack([so.structured_tile(kind, 1024, 1024, 20 + s) for s in range(4)])
+    def grey_background_four():
+        """i.i.d. tissue on a UNIFORM (245, 245, 245) background covering 60 % of the tile: not tissue, yet past the projection bound of
+        the merged sweep and outside the stains' cone -- the case the sample-based guard of finish 1 exists for."""
+        rng = np.random.RandomState(8)
+        four = []
+        for s in range(4):
+            I = so.synth_tile(1024, 1024, 40 + s).copy()
+            I[rng.rand(1024, 1024) < 0.6] = 245
+            four.append(I)
+        return np.stack(four)
+
+    for kind in ("blobs", "white_bg", "quantized", "grey_bg", "real_tissue_ihc"):
+        four = (real_tissue_four() if kind == "real_tissue_ihc" else grey_background_four() if kind == "grey_bg"
+                else np.stack([so.structured_tile(kind, 1024, 1024, 20 + s) for s in range(4)]))
         rgb = torch.as_tensor(four, device=dev)[torch.arange(512, device=dev) % 4].contiguous()
         p = engine.make_params()
         fb = engine.attach_fallbacks(p, 512, device=dev)

@@ -363,7 +363,7 @@ __device__ unsigned long long g_bclk[16];      // development aid: wall-clock ti
 #endif
 template <int NSETS, int KPT, int NBR>
 __device__ __forceinline__ void wg_brackets_regs(const uint32_t (&ord)[NSETS][KPT], const int (&set_of)[NBR],
-                                                 const double (&pct)[NBR], float* lo, float* hi, SelScratch& S) {
+                                                 const double (&pct)[NBR], float* lo, float* hi, SelScratch& S, float z = kBracketZ) {
     static_assert(2 * NBR <= 4, "four 256-bin refinement windows");
     uint32_t omin[NSETS], omax[NSETS], nv[NSETS];
 #ifdef SL_DEBUG_SUBCLK
@@ -401,8 +401,8 @@ __device__ __forceinline__ void wg_brackets_regs(const uint32_t (&ord)[NSETS][KP
             const double q = pct[b] / 100.0;
             const double r = q * ((double)n - 1.0);
             const double sd = sqrt(fmax(q * (1.0 - q) * (double)n, 0.0));
-            const long long rlo = (long long)floor(r - kBracketZ * sd) - 1;
-            const long long rhi = (long long)ceil(r + kBracketZ * sd) + 1;
+            const long long rlo = (long long)floor(r - z * sd) - 1;
+            const long long rhi = (long long)ceil(r + z * sd) + 1;
             open[2 * b] = rlo < 0;
             open[2 * b + 1] = rhi > (long long)n - 1;
             rank[2 * b] = open[2 * b] ? 0u : (uint32_t)rlo;
@@ -693,7 +693,8 @@ __device__ __forceinline__ void stain_matrix_from_angles(const double* Vd, const
 // whose exact keys the finish step evaluates, so the concentration test can run before M is known, against every M the
 // sample leaves possible:
 //   * the sample's angular brackets [lo, hi] bound the two percentile angles; a box of kBoxFrac of their width around
-//     the mid-points (about +-3.6 sigma of the sample rank) is where the exact angles will fall in all but ~1e-3 of the tiles;
+//     the mid-points (about +-3.6 sigma of the sample rank) is where the exact angles will fall in all but ~1e-3 of the tiles
+//     (when a 6-sigma bracket is open -- a small tissue sample -- the box is a second pair of brackets at kBoxZ sigma);
 //   * for M in that box the interior solution of a pixel is a(M; x) = T a(M~; x) + r with M~ the box centre (the rows of
 //     G^-1 M always span the plane of V, so T is 2x2).  |T - I| <= eps and |r| <= rho over the box (nine grid points,
 //     inflated) give  a_i(M; x) <= a~_i + eps_i (|a~_1| + |a~_2|) + rho_i  for every pixel;
@@ -784,11 +785,12 @@ struct TileMerged {
 };
 
 // Called by one whole wave after the angular brackets are known: lanes 0..8 evaluate the 3 x 3 grid of the box.
-__device__ __forceinline__ void merged_box(const double* Vd, const float* lo, const float* hi, double lam, int lane, MergedConc& mk) {
-    const bool finite = (lo[0] > -INFINITY) & (hi[0] < INFINITY) & (lo[1] > -INFINITY) & (hi[1] < INFINITY);
+// box = {lo0, hi0, lo1, hi1}: the intervals of pseudo-angle the two percentile angles are assumed to fall in (angle_brackets)
+__device__ __forceinline__ void merged_box(const double* Vd, const float* box, double lam, int lane, MergedConc& mk) {
+    const bool finite = (box[0] > -INFINITY) & (box[1] < INFINITY) & (box[2] > -INFINITY) & (box[3] < INFINITY);
     const int i0 = lane % 3, i1 = (lane / 3) % 3;
-    const double m0 = 0.5 * ((double)lo[0] + (double)hi[0]), r0 = kBoxFrac * 0.5 * ((double)hi[0] - (double)lo[0]);
-    const double m1 = 0.5 * ((double)lo[1] + (double)hi[1]), r1 = kBoxFrac * 0.5 * ((double)hi[1] - (double)lo[1]);
+    const double m0 = 0.5 * ((double)box[0] + (double)box[1]), r0 = 0.5 * ((double)box[1] - (double)box[0]);
+    const double m1 = 0.5 * ((double)box[2] + (double)box[3]), r1 = 0.5 * ((double)box[3] - (double)box[2]);
     const double p0 = finite ? m0 + (double)(i0 - 1) * r0 : -0.25;
     const double p1 = finite ? m1 + (double)(i1 - 1) * r1 : 0.25;
     double M[6];
@@ -2227,9 +2229,13 @@ static __global__ __launch_bounds__(kSweepThreads, 4) void k_moments(StatsArgs a
 }
 
 // brackets of both angular quantiles from the sample (THREADS = blockDim.x)
+// box (optional, float[4] = {lo0, hi0, lo1, hi1}): where the merged sweep may assume the two percentile angles to fall.  When
+// both 6-sigma brackets are closed it is their central kBoxFrac; when one is open (a small tissue sample: the rank minus 6 sigma
+// leaves it) a second pair at kBoxZ sigma is located in the same register-resident keys -- costs a histogram pass only then.
+constexpr float kBoxZ = 3.6f;
 template <int THREADS>
 __device__ __forceinline__ void angle_brackets(const SampleAngleKey& key, int n_sample, double pct, float* lo, float* hi,
-                                               SelScratch& S) {
+                                               SelScratch& S, float* box = nullptr) {
     constexpr int KPT = kMaxSample / THREADS;
     uint32_t ord[1][KPT];
 #ifdef SL_DEBUG_SUBCLK
@@ -2257,6 +2263,24 @@ __device__ __forceinline__ void angle_brackets(const SampleAngleKey& key, int n_
     const int set_of[2] = {0, 0};
     const double p2[2] = {100.0 - pct, pct};          // minPhi, maxPhi (macenko_stain_extractor.py:33-34)
     wg_brackets_regs<1, KPT, 2>(ord, set_of, p2, lo, hi, S);
+    if (box) {
+        const bool closed = (lo[0] > -INFINITY) & (hi[0] < INFINITY) & (lo[1] > -INFINITY) & (hi[1] < INFINITY);     // block-uniform
+        if (closed) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const float m = 0.5f * (lo[b] + hi[b]), r = (float)kBoxFrac * 0.5f * (hi[b] - lo[b]);
+                box[2 * b] = m - r; box[2 * b + 1] = m + r;
+            }
+        } else {
+            // worth a second pass only if the kBoxZ-sigma ranks stay inside the sample (S.misc[6]: its valid keys, left by the first pass)
+            const double n = (double)S.misc[6], q = p2[0] / 100.0;
+            const bool inside = n > 0.0 && floor(q * (n - 1.0) - (double)kBoxZ * sqrt(fmax(q * (1.0 - q) * n, 0.0))) - 1.0 >= 0.0;   // block-uniform
+            float blo[2] = {-INFINITY, -INFINITY}, bhi[2] = {INFINITY, INFINITY};
+            __syncthreads();
+            if (inside) wg_brackets_regs<1, KPT, 2>(ord, set_of, p2, blo, bhi, S, kBoxZ);
+            box[0] = blo[0]; box[1] = bhi[0]; box[2] = blo[1]; box[3] = bhi[1];
+        }
+    }
 }
 // brackets of the 99th percentile of both concentration columns from the sample (normalizer.py:36,47)
 template <int THREADS>
@@ -2608,6 +2632,7 @@ struct FusedShared {
     double maxC[2];
     float Vf[6];
     float lo[2], hi[2];
+    float box[4];            // where the merged sweep assumes the two percentile angles (angle_brackets)
     float res[4];
     LassoK L;
     int status;
@@ -2652,16 +2677,44 @@ __device__ __noinline__ void fused_finish1(FusedShared<NT>* shp, uint32_t* samp_
         key.sample = samp; key.tab = view_of_b(sh.tab); key.cps_log2 = stride_log2 - 2; key.P = P; key.ylimf = ylimf;
         for (int i = 0; i < 6; ++i) key.V[i] = sh.Vf[i];
         float lo[2], hi[2];
-        angle_brackets<NT>(key, n_sample, pct, lo, hi, sh.S);
+        float box[4];
+        angle_brackets<NT>(key, n_sample, pct, lo, hi, sh.S, box);
         if (tid == 0) {
             sh.lo[0] = lo[0]; sh.hi[0] = hi[0]; sh.lo[1] = lo[1]; sh.hi[1] = hi[1];
+            for (int i = 0; i < 4; ++i) sh.box[i] = box[i];
             sh.xmin = tissue_x_bound(sh.Vf, ylimf, view_of_b(sh.tab));
+            sh.S.misc[32] = 0;
         }
         __syncthreads();
+        // The projection bound makes the sweep collect NON-tissue pixels too when they pass it and lie outside the cone.  On most
+        // tiles those are few; a uniform bright-but-not-white background (say 245, 245, 245: not tissue, first projection above the
+        // bound, direction outside the stains' cone) would put most of the tile on the candidate list and cost it the exact
+        // fallback (measured: 21 ms per 512 such tiles).  The sample says beforehand: if the pixels the bound would add exceed
+        // P/40, this tile's sweep keeps the per-pixel tissue test.
+        const float xm = sh.xmin;
+        if (xm > -INFINITY && xm < INFINITY) {                    // block-uniform
+            const float hi0 = sh.hi[0], lo1 = sh.lo[1];
+            uint32_t extra = 0;
+            for (int b = tid; b < n_sample; b += NT) {
+                if (!key.present(b, n_sample)) continue;
+                const uint32_t w = samp[b];
+                const uint32_t r = w & 255u, g = (w >> 8) & 255u, bl = (w >> 16) & 255u;
+                const bool tissue = is_tissue_f(key.tab.gam(r), key.tab.gam(g), key.tab.gam(bl), ylimf);
+                const float ox = key.tab.odf(r), oy = key.tab.odf(g), oz = key.tab.odf(bl);
+                const float x = fmaf(key.V[4], oz, fmaf(key.V[2], oy, key.V[0] * ox));
+                const float p = angle_key(key.V, ox, oy, oz);
+                extra += (!tissue && x > xm && !(p > hi0 && p < lo1)) ? 1u : 0u;
+            }
+            for (int o = 32; o > 0; o >>= 1) extra += __shfl_xor((int)extra, o, 64);
+            if ((tid & 63) == 0 && extra) atomicAdd(&sh.S.misc[32], extra);
+            __syncthreads();
+            if (tid == 0 && ((unsigned long long)sh.S.misc[32] << stride_log2) > (unsigned long long)P / 40ull) sh.xmin = -INFINITY;
+            __syncthreads();
+        }
     }
     SL_SUB(12);
     // ---------------- the box of stain matrices the sample leaves possible, concentration brackets under its centre
-    if (tid < 64) merged_box(sh.Vd, sh.lo, sh.hi, lam, tid, sh.mk);
+    if (tid < 64) merged_box(sh.Vd, sh.box, lam, tid, sh.mk);
     __syncthreads();
     SL_SUB(13);
     if (sh.mk.ok) {                                               // block-uniform

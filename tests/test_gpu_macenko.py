@@ -431,3 +431,35 @@ def test_resweep_reasons_are_reported_by_the_fused_schedule():
         if sched == 2:
             for i, I in enumerate(tiles):
                 np.testing.assert_allclose(M.cpu().numpy()[i], so.macenko_stain_matrix(I), rtol=0, atol=M_ATOL)
+
+
+def test_uniform_grey_background_does_not_flood_the_candidate_list():
+    """A uniform bright-but-not-white background (245, 245, 245: not tissue, but its first projection passes the bound that stands
+    in for the tissue test in the merged sweep, and its direction lies outside the stains' cone) would put most of the tile on the
+    candidate list; the sample predicts that and such a tile keeps the per-pixel tissue test: no exact fallback, the oracle's results,
+    both schedules, at 60 % and 85 % background (where the tissue sample is small enough for the 3.6-sigma box to be needed)."""
+    from stainlib_amd import engine
+    tgt = so.synth_tile(96, 96, 1001, so.M_TRUE_TGT)
+    Mt, mct, _ = engine.macenko_fit(to_dev([tgt]))
+    rng = np.random.RandomState(8)
+    tiles = []
+    for frac in (0.6, 0.85):
+        I = so.synth_tile(1024, 1024, 31).copy()
+        I[rng.rand(1024, 1024) < frac] = 245
+        tiles.append(I)
+    outs = []
+    for sched in (1, 2):
+        p = engine.make_params(schedule=sched)
+        fb = engine.attach_fallbacks(p, 2)
+        rs = torch.full((2,), -1, dtype=torch.int32, device="cuda")
+        p.resweeps_out = rs.data_ptr()
+        out, M, mc, st = engine.macenko_transform(to_dev(tiles), Mt[0], mct[0], params=p)
+        assert (st.cpu().numpy() == 0).all() and int(fb.sum()) == 0
+        if sched == 2:
+            assert rs.cpu().tolist() == [0, 0]                       # the merged sweep settled both tiles
+        outs.append(out)
+        for i, I in enumerate(tiles):
+            Mo = so.macenko_stain_matrix(I)
+            np.testing.assert_allclose(M.cpu().numpy()[i], Mo, rtol=0, atol=M_ATOL)
+            np.testing.assert_allclose(mc.cpu().numpy()[i], np.percentile(so.get_concentrations(I, Mo), 99, axis=0), rtol=MAXC_RTOL)
+    assert torch.equal(outs[0], outs[1])
