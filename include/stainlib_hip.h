@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SL_VERSION 200 /* 0.2.0 */
+#define SL_VERSION 300 /* 0.3.0: SlParams grew (fused_min_tiles), sl_pool_* added, resweeps_out carries reasons */
 
 /* The library is built with -fvisibility=hidden: exactly the functions declared here are exported. */
 #if defined(__GNUC__)
