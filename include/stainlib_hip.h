@@ -130,7 +130,9 @@ typedef struct SlParams {
     int32_t fused_min_tiles;    /* schedule == 0 only: batches of at least this many tiles run the persistent fused kernel, smaller ones
                                    one launch per phase.  0 (default) = the library's measured crossovers on an MI355X at its 1400 W
                                    power state (tools/crossover.py, profiles/r03_crossover.txt): Macenko 320 tiles, Vahadane 640 (192 for tiles
-                                   below 512 Ki pixels).  Results do not depend on the schedule. */
+                                   below 512 Ki pixels).  A batch larger than the fused kernel's resident grid (2 x compute units) is split:
+                                   whole fused rounds, and a remainder below this number of tiles one launch per phase.  Results do not
+                                   depend on the schedule. */
     int32_t reserved_;          /* 0 */
 } SlParams;
 

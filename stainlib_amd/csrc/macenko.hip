@@ -250,6 +250,69 @@ int check_common(const void* rgb, int n, int h, int w, const void* ws, size_t ws
     return SL_OK;
 }
 
+// What a Macenko call does with its n tiles.  Automatic schedule only: a batch larger than the resident grid of the fused kernel
+// whose last round would be mostly empty (n mod grid below the crossover) gives that remainder to the one-launch-per-phase
+// schedule instead -- 640 tiles: one full fused round + 128 tiles per phase, 2.3 ms, where two fused rounds take 2.75 ms.  Results
+// do not depend on the split (both schedules select the same values).
+struct MacenkoPlan {
+    Layout L;            // the whole batch (result arrays) and the fused part
+    bool mixed;
+    int n_fused;         // tiles [0, n_fused) fused, [n_fused, n) per phase (mixed only)
+    Layout Lp;           // the per-phase remainder, placed behind L in the workspace
+    size_t total;
+};
+MacenkoPlan plan_macenko(int n, long P, int schedule, int fused_min_tiles) {
+    MacenkoPlan pl;
+    pl.L = make_layout(n, P, kMethodMacenko, schedule, fused_min_tiles);
+    pl.mixed = false;
+    pl.n_fused = 0;
+    pl.Lp = Layout{};
+    pl.total = pl.L.total;
+    if (schedule == 0 && pl.L.fused && n > pl.L.max_grid) {
+        const int rest = n % pl.L.max_grid;
+        const int min_fused = fused_min_tiles > 0 ? fused_min_tiles : (P >= (1L << 19) ? kFusedMinTiles : kFusedMinTilesSmall);
+        if (rest > 0 && rest < min_fused) {
+            pl.mixed = true;
+            pl.n_fused = n - rest;
+            pl.Lp = make_layout(rest, P, kMethodMacenko, 1, 0);
+            pl.total = pl.L.total + pl.Lp.total;
+        }
+    }
+    return pl;
+}
+
+// fit (out == nullptr) or transform of a batch according to its plan
+int run_macenko(const MacenkoPlan& pl, const uint8_t* rgb, uint8_t* out, int n, int h, int w, const SlParams& p, const double* M_tgt,
+                const double* maxC_tgt, double* M_all, double* maxC_all, int32_t* st_all, char* ws, void* stream) {
+    const long P = (long)h * w;
+    const Layout& L = pl.L;
+    int rc;
+    if (L.fused && !pl.mixed)
+        return run_fused(kMethodMacenko, rgb, out, n, P, p, L, ws, M_tgt, maxC_tgt, M_all, maxC_all, st_all, nullptr, (hipStream_t)stream);
+    int first = 0;
+    const Layout* Lg = &L;
+    char* wsg = ws;
+    if (pl.mixed) {
+        rc = run_fused(kMethodMacenko, rgb, out, pl.n_fused, P, p, L, ws, M_tgt, maxC_tgt, M_all, maxC_all, st_all, nullptr, (hipStream_t)stream);
+        if (rc) return rc;
+        first = pl.n_fused;
+        Lg = &pl.Lp;
+        wsg = ws + L.total;
+    }
+    for (int g0 = first; g0 < n; g0 += Lg->G) {
+        const int m = (n - g0) < Lg->G ? (n - g0) : Lg->G;
+        rc = run_stats_group(rgb, g0, m, P, p, *Lg, wsg, M_all, maxC_all, st_all, (hipStream_t)stream);
+        if (rc) return rc;
+        if (out) {
+            ProfScope ps(p.profile, SL_PROF_APPLY, m, (hipStream_t)stream);
+            rc = sl_normalize_apply(rgb + (size_t)g0 * 3 * P, out + (size_t)g0 * 3 * P, m, h, w, M_all + 6 * (size_t)g0, maxC_all + 2 * (size_t)g0,
+                                    M_tgt, maxC_tgt, p.lasso_lambda, nullptr, stream);
+            if (rc) return rc;
+        }
+    }
+    return SL_OK;
+}
+
 }  // namespace
 
 extern "C" size_t sl_workspace_bytes(int op, int n_tiles, int h, int w) {
@@ -257,9 +320,18 @@ extern "C" size_t sl_workspace_bytes(int op, int n_tiles, int h, int w) {
     switch (op) {
         case SL_OP_MACENKO_FIT:
         case SL_OP_MACENKO_TRANSFORM:
-        {   // SlParams.schedule may force either schedule: size for the larger of the two
-            const size_t a = make_layout(n_tiles, (long)h * w, kMethodMacenko, 1).total, b = make_layout(n_tiles, (long)h * w, kMethodMacenko, 2).total;
-            return a > b ? a : b;
+        {   // SlParams.schedule may force either schedule, and the automatic one may split the batch: size for the largest of the three
+            // (a caller-set SlParams.fused_min_tiles can only move tiles between plans that are all covered: the split's remainder is
+            //  sized as a per-phase batch of at most one resident grid)
+            const long P = (long)h * w;
+            const size_t a = make_layout(n_tiles, P, kMethodMacenko, 1).total, b = make_layout(n_tiles, P, kMethodMacenko, 2).total;
+            size_t c = plan_macenko(n_tiles, P, 0, 0).total;
+            const int mg = max_resident_grid();
+            if (n_tiles > mg && n_tiles % mg) {                   // the largest remainder plan any fused_min_tiles could choose
+                const size_t d = b + make_layout(n_tiles % mg, P, kMethodMacenko, 1).total;
+                c = c > d ? c : d;
+            }
+            return (a > b ? a : b) > c ? (a > b ? a : b) : c;
         }
         case SL_OP_VAHADANE_FIT:
         case SL_OP_VAHADANE_TRANSFORM:
@@ -282,25 +354,17 @@ extern "C" int sl_macenko_fit(const uint8_t* rgb, int n, int h, int w, const SlP
                               double* maxC_out, int32_t* status, void* workspace, size_t workspace_bytes,
                               void* stream) {
     const long P = (long)h * w;
-    const Layout L = (n > 0 && h > 0 && w > 0) ? make_layout(n, P, kMethodMacenko, params ? params->schedule : 0, params ? params->fused_min_tiles : 0) : Layout{};
-    int rc = check_common(rgb, n, h, w, workspace, workspace_bytes, L.total);
+    const MacenkoPlan pl = (n > 0 && h > 0 && w > 0) ? plan_macenko(n, P, params ? params->schedule : 0, params ? params->fused_min_tiles : 0) : MacenkoPlan{};
+    int rc = check_common(rgb, n, h, w, workspace, workspace_bytes, pl.total);
     if (rc) return rc;
     SlParams p;
     sl_default_params(&p);
     if (params) p = *params;
     char* ws = (char*)workspace;
-    double* M_all = M_out ? M_out : (double*)(ws + L.off_M);
-    double* maxC_all = maxC_out ? maxC_out : (double*)(ws + L.off_maxC);
-    int32_t* st_all = status ? status : (int32_t*)(ws + L.off_status);
-    if (L.fused)
-        return run_fused(kMethodMacenko, rgb, nullptr, n, P, p, L, ws, nullptr, nullptr, M_all, maxC_all, st_all, nullptr,
-                         (hipStream_t)stream);
-    for (int g0 = 0; g0 < n; g0 += L.G) {
-        const int m = (n - g0) < L.G ? (n - g0) : L.G;
-        rc = run_stats_group(rgb, g0, m, P, p, L, ws, M_all, maxC_all, st_all, (hipStream_t)stream);
-        if (rc) return rc;
-    }
-    return SL_OK;
+    double* M_all = M_out ? M_out : (double*)(ws + pl.L.off_M);
+    double* maxC_all = maxC_out ? maxC_out : (double*)(ws + pl.L.off_maxC);
+    int32_t* st_all = status ? status : (int32_t*)(ws + pl.L.off_status);
+    return run_macenko(pl, rgb, nullptr, n, h, w, p, nullptr, nullptr, M_all, maxC_all, st_all, ws, stream);
 }
 
 extern "C" int sl_macenko_transform(const uint8_t* rgb, uint8_t* out, int n, int h, int w, const SlParams* params,
@@ -308,33 +372,18 @@ extern "C" int sl_macenko_transform(const uint8_t* rgb, uint8_t* out, int n, int
                                     double* maxC_src_out, int32_t* status, void* workspace, size_t workspace_bytes,
                                     void* stream) {
     const long P = (long)h * w;
-    const Layout L = (n > 0 && h > 0 && w > 0) ? make_layout(n, P, kMethodMacenko, params ? params->schedule : 0, params ? params->fused_min_tiles : 0) : Layout{};
-    int rc = check_common(rgb, n, h, w, workspace, workspace_bytes, L.total);
+    const MacenkoPlan pl = (n > 0 && h > 0 && w > 0) ? plan_macenko(n, P, params ? params->schedule : 0, params ? params->fused_min_tiles : 0) : MacenkoPlan{};
+    int rc = check_common(rgb, n, h, w, workspace, workspace_bytes, pl.total);
     if (rc) return rc;
     if (!out || !M_tgt || !maxC_tgt) return SL_ERR_BADARG;
     SlParams p;
     sl_default_params(&p);
     if (params) p = *params;
     char* ws = (char*)workspace;
-    double* M_all = M_src_out ? M_src_out : (double*)(ws + L.off_M);
-    double* maxC_all = maxC_src_out ? maxC_src_out : (double*)(ws + L.off_maxC);
-    int32_t* st_all = status ? status : (int32_t*)(ws + L.off_status);
-    if (L.fused)
-        return run_fused(kMethodMacenko, rgb, out, n, P, p, L, ws, M_tgt, maxC_tgt, M_all, maxC_all, st_all, nullptr,
-                         (hipStream_t)stream);
-    for (int g0 = 0; g0 < n; g0 += L.G) {
-        const int m = (n - g0) < L.G ? (n - g0) : L.G;
-        rc = run_stats_group(rgb, g0, m, P, p, L, ws, M_all, maxC_all, st_all, (hipStream_t)stream);
-        if (rc) return rc;
-        {
-            ProfScope ps(p.profile, SL_PROF_APPLY, m, (hipStream_t)stream);
-            rc = sl_normalize_apply(rgb + (size_t)g0 * 3 * P, out + (size_t)g0 * 3 * P, m, h, w,
-                                    M_all + 6 * (size_t)g0, maxC_all + 2 * (size_t)g0, M_tgt, maxC_tgt,
-                                    p.lasso_lambda, nullptr, stream);
-        }
-        if (rc) return rc;
-    }
-    return SL_OK;
+    double* M_all = M_src_out ? M_src_out : (double*)(ws + pl.L.off_M);
+    double* maxC_all = maxC_src_out ? maxC_src_out : (double*)(ws + pl.L.off_maxC);
+    int32_t* st_all = status ? status : (int32_t*)(ws + pl.L.off_status);
+    return run_macenko(pl, rgb, out, n, h, w, p, M_tgt, maxC_tgt, M_all, maxC_all, st_all, ws, stream);
 }
 
 // Vahadane: the persistent kernel for large batches, one launch per phase below kDictFusedMinTiles tiles.

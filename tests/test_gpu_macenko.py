@@ -463,3 +463,31 @@ def test_uniform_grey_background_does_not_flood_the_candidate_list():
             np.testing.assert_allclose(M.cpu().numpy()[i], Mo, rtol=0, atol=M_ATOL)
             np.testing.assert_allclose(mc.cpu().numpy()[i], np.percentile(so.get_concentrations(I, Mo), 99, axis=0), rtol=MAXC_RTOL)
     assert torch.equal(outs[0], outs[1])
+
+
+def test_a_batch_beyond_the_resident_grid_is_split_between_the_schedules():
+    """Automatic schedule: 700 tiles = one full round of the fused kernel (512 workgroups on this part) + 188 tiles one launch per
+    phase (a second fused round would be mostly empty).  Same bytes and statistics as either schedule forced on the whole batch;
+    diagnostics cover every tile; the workspace the library asks for is enough for the split."""
+    from stainlib_amd import engine
+    base = [so.synth_tile(64, 64, 200 + s) for s in range(7)] + [np.full((64, 64, 3), 255, np.uint8)]
+    tiles = to_dev(base)[torch.arange(700, device="cuda") % 8].contiguous()
+    tgt = so.synth_tile(96, 96, 1001, so.M_TRUE_TGT)
+    Mt, mct, _ = engine.macenko_fit(to_dev([tgt]))
+    res = {}
+    for sched in (0, 1, 2):
+        p = engine.make_params(schedule=sched)
+        fb = engine.attach_fallbacks(p, 700)
+        fb.fill_(-7)
+        out, M, mc, st = engine.macenko_transform(tiles, Mt[0], mct[0], params=p)
+        Mf, mcf, stf = engine.macenko_fit(tiles, params=p)
+        torch.cuda.synchronize()
+        assert int((fb == -7).sum()) == 0                      # every tile's diagnostics were written, whichever part it was in
+        assert torch.equal(st, stf) and torch.equal(M[st == 0], Mf[stf == 0])
+        res[sched] = (out.clone(), M.clone(), mc.clone(), st.clone())
+    assert (res[0][3].cpu().numpy()[7::8] == 1).all() and (res[0][3].cpu().numpy()[:7] == 0).all()     # the white tile: empty mask
+    for sched in (1, 2):
+        assert torch.equal(res[0][0], res[sched][0]) and torch.equal(res[0][3], res[sched][3])
+        good = res[0][3] == 0
+        assert float((res[0][1][good] - res[sched][1][good]).abs().max()) < 1e-12
+        assert float((res[0][2][good] / res[sched][2][good] - 1).abs().max()) < 1e-12
