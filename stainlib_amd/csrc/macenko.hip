@@ -14,10 +14,21 @@ constexpr size_t kGroupBytes = (size_t)2 << 30;   // uint8 bytes of one tile gro
                                                   // the one-workgroup-per-tile finish kernels need many tiles to fill the chip; cache reuse between sweeps does not matter)
 
 // Defaults of SlParams.fused_min_tiles (documented in include/stainlib_hip.h): the measured crossovers of round 3's three-sweep fused
-// kernel on an MI355X at its 1400 W power state (tools/crossover.py, profiles/r03_crossover.txt: 1024^2 tiles 1.11 vs 1.14 ms at 256,
-// 1.64 vs 1.52 at 384; 256^2 tiles 0.22 vs 0.23 at 256, 0.32 vs 0.29 at 384).  Below them one launch per phase wins.
-constexpr int kFusedMinTiles = 416;
-constexpr int kFusedMinTilesSmall = 416;    // ... for tiles below 512 Ki pixels
+// kernel on an MI355X at its 1400 W power state (tools/crossover.py, profiles/r03_crossover.txt and r03_crossover_small.txt).  Below them one
+// launch per phase wins.  1024^2 tiles: 1.11 vs 1.14 ms at 256, 1.64 vs 1.52 at 384.  Smaller tiles cross earlier (the per-phase launches
+// of more than 256 tiles split into two groups' worth of finish launches): 512^2 0.42 vs 0.47 ms at 256 tiles, 0.58 vs 0.56 at 320, 0.64 vs
+// 0.57 at 384; 256^2 0.235 vs 0.232 at 256, 0.35 vs 0.28 at 320; 700^2 0.78 vs 0.83 at 320, 0.87 vs 0.83 at 384.
+constexpr int kFusedMinTiles = 416;         // tiles of 512 Ki pixels and more
+constexpr int kFusedMinTilesMid = 352;      // 256 Ki < pixels < 512 Ki
+constexpr int kFusedMinTilesSmall = 288;    // up to 256 Ki pixels
+// The automatic split of a batch beyond the resident grid (plan_macenko): the remainder goes per phase when it is below these.  For small
+// tiles a second, partly empty fused round overlaps the first one's tail and the split pays only for short remainders (512^2, 640 tiles:
+// 0.91 split vs 0.97 fused, 768 tiles: 1.03 vs 0.98; 256^2: never).
+constexpr int kSplitMaxRest = 416, kSplitMaxRestMid = 224, kSplitMaxRestSmall = 192, kSplitMaxRestTiny = 0;   // tiny: up to 64 Ki pixels
+inline int fused_min_default(long P) { return P >= (1L << 19) ? kFusedMinTiles : P > (1L << 18) ? kFusedMinTilesMid : kFusedMinTilesSmall; }
+inline int split_max_rest(long P) {
+    return P >= (1L << 19) ? kSplitMaxRest : P > (1L << 18) ? kSplitMaxRestMid : P > (1L << 16) ? kSplitMaxRestSmall : kSplitMaxRestTiny;
+}
 constexpr int kDictFusedMinTiles = 640;     // Vahadane: below it the dictionary sweeps run one launch per phase too (measured: 1024^2 tiles 3.70 vs
                                             // 3.85 ms at 512, 6.24 vs 5.76 at 768; in a fused launch of one tile per workgroup the few tiles
                                             // that need a third full sweep hold the whole launch, per phase they cost a short extra launch)
@@ -62,7 +73,7 @@ Layout make_layout(int n, long P, int method = kMethodMacenko, int schedule = 0,
     L.G = (int)g;
     const int min_fused = fused_min_tiles > 0 ? fused_min_tiles        // SlParams.fused_min_tiles; the defaults are the measured crossovers
                         : method == kMethodVahadane ? (P >= (1L << 19) ? kDictFusedMinTiles : kDictFusedMinTilesSmall)
-                                                    : (P >= (1L << 19) ? kFusedMinTiles : kFusedMinTilesSmall);
+                                                    : fused_min_default(P);
     L.fused = (schedule == 2) || (schedule != 1 && n >= min_fused);
     L.grid = n < L.max_grid ? n : L.max_grid;
     const size_t slots = L.fused ? (size_t)L.grid : (size_t)L.G;     // candidate buffers: per workgroup / per tile of a group
@@ -270,8 +281,8 @@ MacenkoPlan plan_macenko(int n, long P, int schedule, int fused_min_tiles) {
     pl.total = pl.L.total;
     if (schedule == 0 && pl.L.fused && n > pl.L.max_grid) {
         const int rest = n % pl.L.max_grid;
-        const int min_fused = fused_min_tiles > 0 ? fused_min_tiles : (P >= (1L << 19) ? kFusedMinTiles : kFusedMinTilesSmall);
-        if (rest > 0 && rest < min_fused) {
+        const int max_rest = fused_min_tiles > 0 ? fused_min_tiles : split_max_rest(P);
+        if (rest > 0 && rest < max_rest) {
             pl.mixed = true;
             pl.n_fused = n - rest;
             pl.Lp = make_layout(rest, P, kMethodMacenko, 1, 0);

@@ -467,10 +467,11 @@ def test_uniform_grey_background_does_not_flood_the_candidate_list():
 
 def test_a_batch_beyond_the_resident_grid_is_split_between_the_schedules():
     """Automatic schedule: 700 tiles = one full round of the fused kernel (512 workgroups on this part) + 188 tiles one launch per
-    phase (a second fused round would be mostly empty).  Same bytes and statistics as either schedule forced on the whole batch;
-    diagnostics cover every tile; the workspace the library asks for is enough for the split."""
+    phase (a second fused round would be mostly empty; tiles of more than 64 Ki pixels: smaller ones are never split by default).
+    Same bytes and statistics as either schedule forced on the whole batch; diagnostics cover every tile; the workspace the library
+    asks for is enough for the split."""
     from stainlib_amd import engine
-    base = [so.synth_tile(64, 64, 200 + s) for s in range(7)] + [np.full((64, 64, 3), 255, np.uint8)]
+    base = [so.synth_tile(288, 288, 200 + s) for s in range(7)] + [np.full((288, 288, 3), 255, np.uint8)]
     tiles = to_dev(base)[torch.arange(700, device="cuda") % 8].contiguous()
     tgt = so.synth_tile(96, 96, 1001, so.M_TRUE_TGT)
     Mt, mct, _ = engine.macenko_fit(to_dev([tgt]))

@@ -10,6 +10,7 @@ export TMPDIR=/tmp
 dev=$PWD/stainlib_amd/csrc/libstainlib_hip_dev.so
 python bench.py --steps 20 --warmup 3 2>/dev/null | tail -1 > "$out/${tag}_bench_n1.json"
 python tools/crossover.py 2>/dev/null | grep "size" > "$out/${tag}_crossover.txt"
+python tools/crossover.py macenko 700,512,384 2>/dev/null | grep "size" > "$out/${tag}_crossover_small.txt"
 python tools/phase_classes.py 1024 2>/dev/null | grep "^size" > "$out/${tag}_phase_classes.txt"
 [ -f "$dev" ] && STAINLIB_HIP_LIB=$dev python tools/merged_diag.py 512 1024 2>/dev/null | grep -v amdgpu > "$out/${tag}_phase_times.txt"
 python tools/bench_pipeline.py 2>/dev/null | tail -3 > "$out/${tag}_pipeline.txt"

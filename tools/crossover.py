@@ -1,4 +1,5 @@
-"""Fused vs one-launch-per-phase schedule by batch size, Macenko and Vahadane (where the automatic switch should sit)."""
+"""Fused vs one-launch-per-phase schedule by batch and tile size, Macenko and Vahadane, with the automatic schedule beside them (where the
+switch and the split of a batch beyond the resident grid should sit).  python tools/crossover.py [methods] [sizes]"""
 import sys, time, torch
 sys.path.insert(0, ".")
 from stainlib_amd import engine
@@ -6,16 +7,15 @@ from tools.synth import synth_tiles
 tgt = synth_tiles(1, 1024, 1024, seed=1, M_true=[[0.55, 0.75, 0.35], [0.10, 0.95, 0.20]])
 Mt, mct, st = engine.macenko_fit(tgt)
 methods = sys.argv[1].split(",") if len(sys.argv) > 1 else ["macenko", "vahadane"]
+sizes = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1024, 256]
 for method in methods:
     fn = engine.macenko_transform if method == "macenko" else engine.vahadane_transform
-    for size in (1024, 256):
-        for n in (16, 32, 64, 128, 256, 384, 448, 512, 768, 1024):
-            if size == 1024 and n > 1024:
-                continue
+    for size in sizes:
+        for n in (16, 32, 64, 128, 256, 320, 384, 448, 512, 640, 768, 1024):
             rgb = synth_tiles(n, size, size, seed=3)
             out = torch.empty_like(rgb)
             r = []
-            for sched in (1, 2):
+            for sched in (1, 2, 0):
                 p = engine.make_params(schedule=sched, dl_tol=1e-6, dl_max_sweeps=100)
                 for _ in range(3):
                     fn(rgb, Mt[0], mct[0], params=p, out=out)
@@ -23,5 +23,5 @@ for method in methods:
                 for _ in range(10):
                     fn(rgb, Mt[0], mct[0], params=p, out=out)
                 torch.cuda.synchronize(); r.append((time.perf_counter() - t0) / 10 * 1e3)
-            print(f"{method} size {size} n {n:4d}: per-phase {r[0]:.3f} ms  fused {r[1]:.3f} ms  -> {n / min(r):.1f} k tiles/s")
+            print(f"{method} size {size} n {n:4d}: per-phase {r[0]:.3f} ms  fused {r[1]:.3f} ms  automatic {r[2]:.3f} ms -> {n / r[2]:.1f} k tiles/s")
             del rgb, out
