@@ -75,6 +75,10 @@ Layout make_layout(int n, long P, int method = kMethodMacenko, int schedule = 0,
                         : method == kMethodVahadane ? (P >= (1L << 19) ? kDictFusedMinTiles : kDictFusedMinTilesSmall)
                                                     : fused_min_default(P);
     L.fused = (schedule == 2) || (schedule != 1 && n >= min_fused);
+    // Vahadane just beyond one resident grid: the second, mostly empty round of the persistent kernel costs more than one launch per phase
+    // for the whole batch (1024^2: 640 tiles 5.65 vs 4.71 ms, 768 tiles 5.71 vs 6.20; 512^2: 576 tiles 1.93 vs 1.63, 768 tiles 1.98 vs 2.09)
+    if (schedule == 0 && fused_min_tiles <= 0 && method == kMethodVahadane && P >= (1L << 18) && n > L.max_grid && 8L * n < 11L * L.max_grid)
+        L.fused = false;
     L.grid = n < L.max_grid ? n : L.max_grid;
     const size_t slots = L.fused ? (size_t)L.grid : (size_t)L.G;     // candidate buffers: per workgroup / per tile of a group
     size_t o = 0;
