@@ -437,6 +437,9 @@ def main():
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     if a.gpus != world and world > 1:
         a.gpus = world
+    # SL_BENCH_FORCE_DIST=1: take the N > 1 path (RCCL process group bound to the device, device barriers, the collectives of the
+    # QC gather and of --slide-pooled, the core slice) with ONE rank -- what a single-GPU box can verify of it (tests/test_gpu_rccl.py)
+    dist_on = world > 1 or os.environ.get("SL_BENCH_FORCE_DIST") == "1"
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -444,7 +447,7 @@ def main():
 
     # one rank = one GPU = its own slice of the host cores (launch threads of different ranks never share a core)
     affinity = None
-    if world > 1:
+    if dist_on:
         allowed = sorted(os.sched_getaffinity(0))
         per = max(1, len(allowed) // max(local_world, 1))
         mine = allowed[local_rank * per:(local_rank + 1) * per] or allowed
@@ -466,8 +469,13 @@ def main():
     dev_index = local_rank % max(torch.cuda.device_count(), 1)        # bound by LOCAL_RANK
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:                                       # forced: works without a launcher too
+            for k, v in (("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")):
+                os.environ.setdefault(k, v)
+            import stainlib_amd.distributed as sld
+            sld.COLLECTIVES_AT_WORLD_1 = True
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -475,7 +483,7 @@ def main():
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
     def barrier():
-        if world > 1:
+        if dist_on:
             if backend == "nccl":
                 dist.barrier(device_ids=[dev_index])
             else:
@@ -537,7 +545,7 @@ def main():
     n_resweeps = int((resweeps != 0).sum())
 
     per_rank = [B * a.steps / t_mine]
-    if world > 1:
+    if dist_on:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax[0])
@@ -571,7 +579,7 @@ def main():
         tp = time.perf_counter() - tp0
         agree = torch.cat([M_s.reshape(-1), mc_s.reshape(-1)]).to(coll_dev)
         same = True
-        if world > 1:
+        if dist_on:
             lo, hi = agree.clone(), agree.clone()
             dist.all_reduce(lo, op=dist.ReduceOp.MIN)
             dist.all_reduce(hi, op=dist.ReduceOp.MAX)
@@ -728,7 +736,7 @@ def main():
                           "tiles_that_needed_the_separate_concentration_sweep": n_resweeps, "of_tiles": B,
                           "note": "i.i.d. synthetic tiles never need it; heavy colour ties (palette images) do -- see tests"},
             "parity": parity,
-            "distributed": {"backend": (dist.get_backend() if world > 1 else None), "world_size": (dist.get_world_size() if world > 1 else 1),
+            "distributed": {"backend": (dist.get_backend() if dist_on else None), "world_size": (dist.get_world_size() if dist_on else 1),
                             "per_rank_tiles_per_s": [round(x, 1) for x in per_rank], "device_of_rank0": dev_index,
                             "cpu_affinity_of_rank0": affinity, "slide_pooled": pooled},
         }
@@ -740,7 +748,7 @@ def main():
             torch.cuda.empty_cache()
             line["secondary"] = secondary_configs(dev, Mt, mct)
     ev.close()
-    if world > 1:
+    if dist_on:
         barrier()
         dist.destroy_process_group()
     if rank == 0:

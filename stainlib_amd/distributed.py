@@ -38,6 +38,18 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     return (rank * n) // world, ((rank + 1) * n) // world
 
 
+# Test hook: run the collectives even in a ONE-rank process group, so that a single GPU exercises the RCCL path end to end
+# (bench.py sets it under SL_BENCH_FORCE_DIST=1; tests/test_gpu_rccl.py).  Off: a one-rank job pays for no collective.
+COLLECTIVES_AT_WORLD_1 = False
+
+
+def _coll(world: int, group=None) -> bool:
+    """Whether the collectives of a step run: more than one rank, or the test hook above with a live process group."""
+    if world > 1:
+        return True
+    return bool(COLLECTIVES_AT_WORLD_1 and group is not False and dist.is_available() and dist.is_initialized())
+
+
 def _world(group=None):
     if group is False:           # "this process only": no collective even when a process group exists
         return 0, 1
@@ -54,7 +66,7 @@ def gather_tile_stats(M: torch.Tensor, maxC: torch.Tensor, status: torch.Tensor,
     n_local = M.shape[0]
     packed = torch.cat([M.reshape(n_local, 6).double(), maxC.reshape(n_local, 2).double(),
                         status.reshape(n_local, 1).double()], dim=1)
-    if world == 1:
+    if not _coll(world, group):
         return M.reshape(n_local, 2, 3), maxC.reshape(n_local, 2), status.reshape(n_local)
     counts = torch.zeros(world, dtype=torch.int64, device=packed.device)
     counts[rank] = n_local
@@ -122,7 +134,7 @@ def exact_rank_pairs(hist_fn, next_above_fn, ks, group=None, hist16_fn=None, fra
             rest = 32 - bits
             return [((prefix[t] << rest) | (1 << (rest - 1)), (prefix[t] << rest) | (1 << (rest - 1)), total[t]) for t in range(2)]
         h = hist16_fn(prefix) if width == 16 else hist_fn(prefix, bits)
-        if world > 1:
+        if _coll(world, group):
             dist.all_reduce(h, group=group)
         hc = h.detach().cpu().numpy().astype(np.int64)
         last = bits + width == 32
@@ -149,7 +161,7 @@ def exact_rank_pairs(hist_fn, next_above_fn, ks, group=None, hist16_fn=None, fra
             nxt[t], need[t] = succ[t], False
     if any(need) and next_above_fn is not None:
         got = next_above_fn(prefix)
-        if world > 1:
+        if _coll(world, group):
             tt = torch.tensor(got, dtype=torch.int64, device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MIN, group=group)
             got = [int(x) for x in tt.tolist()]
@@ -175,7 +187,7 @@ def window_rank_pairs(sample_hist_fn, window_fn, ks, totals, group=None):
         return None
     lo = [min(max(est[t][0] - 32768, 0), 0xffffffff - 65535) for t in range(2)]
     buf = window_fn(lo)
-    if world > 1:
+    if _coll(world, group):
         dist.all_reduce(buf, group=group)
     b = buf.detach().cpu().numpy().astype(np.int64)
     out = []
@@ -216,7 +228,7 @@ class PooledSlideStatistics:
         # 10 moment sums + this rank's pixel count (torch.full: a fill kernel -- a scalar copied from the host could not be captured)
         mom = torch.cat([engine.tile_moments(tiles_local, params=params, ws=ws).sum(dim=0),
                          torch.full((1,), float(n_local * h * w), dtype=torch.float64, device=dev)])
-        if world > 1:
+        if _coll(world, self.group):
             dist.all_reduce(mom, group=self.group)
         state = engine.pool_begin(mom, params=params)
         # the sample: ~4 M pixels of the slide or more (shards differ by at most one tile: every rank derives the same density)
@@ -227,11 +239,11 @@ class PooledSlideStatistics:
         for si, keyset in enumerate((_ffi.KEYSET_ANGLE, _ffi.KEYSET_CONC)):
             for rnd in range(3):
                 hb = engine.pool_histogram(tiles_local, keyset, state, rnd, slog, hists[si, rnd], params=params)
-                if world > 1:
+                if _coll(world, self.group):
                     dist.all_reduce(hb, group=self.group)
                 engine.pool_pick(state, keyset, rnd, hb)
             wb = engine.pool_window(tiles_local, keyset, state, wins[si], params=params)
-            if world > 1:
+            if _coll(world, self.group):
                 dist.all_reduce(wb, group=self.group)
             engine.pool_resolve(state, keyset, wb, params=params)
         return state
@@ -271,7 +283,7 @@ class PooledSlideStatistics:
         # ---- covariance of the optical density over every tissue pixel (macenko_stain_extractor.py:18-27)
         mom = engine.tile_moments(tiles_local, params=params).sum(dim=0)
         npx = torch.tensor([float(n_local * h * w)], dtype=torch.float64, device=mom.device)
-        if world > 1:
+        if _coll(world, self.group):
             dist.all_reduce(mom, group=self.group)
             dist.all_reduce(npx, group=self.group)
         m = mom.cpu().numpy()

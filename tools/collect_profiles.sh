@@ -9,6 +9,8 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 dev=$PWD/stainlib_amd/csrc/libstainlib_hip_dev.so
 python bench.py --steps 20 --warmup 3 2>/dev/null | tail -1 > "$out/${tag}_bench_n1.json"
+# the N > 1 path of bench.py on a real RCCL process group of one rank (what one GPU can verify of it)
+SL_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29612 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --slide-pooled 2>/dev/null | grep '^{' | tail -1 > "$out/${tag}_bench_rccl_world1.json"
 python tools/crossover.py 2>/dev/null | grep "size" > "$out/${tag}_crossover.txt"
 python tools/crossover.py macenko 700,512,384 2>/dev/null | grep "size" > "$out/${tag}_crossover_small.txt"
 python tools/phase_classes.py 1024 2>/dev/null | grep "^size" > "$out/${tag}_phase_classes.txt"
