@@ -62,7 +62,12 @@ Layout make_layout(int n, long P, int method = kMethodMacenko, int schedule = 0,
         const long want = (4L * L.max_grid + n - 1) / (n > 0 ? n : 1);
         if (L.parts > want) L.parts = (int)(want < 1 ? 1 : want);
     }
-    L.stride_log2 = 6;
+    // The pixel sample steers the brackets (never the results): its SIZE sets how many pixels a bracket holds (the rank uncertainty
+    // of a sample quantile goes with 1/sqrt(sample)), so Macenko tiles below 1 Mpixel are sampled more densely -- one pixel in 16 from
+    // 256 Ki pixels down, up to the 16 Ki entries of a 1024^2 tile -- or their member lists overflow on real tissue (a soak over
+    // 400 random tiles: 36 of 130 default-parameter tiles below 1 Mpixel lost the merged sweep to a full list at one pixel in 64).
+    // Vahadane iterates over the sample: it keeps one in 64.
+    L.stride_log2 = method == kMethodVahadane ? 6 : 4;
     while (((P + (1L << L.stride_log2) - 1) >> L.stride_log2) > kMaxSample) ++L.stride_log2;
     L.n_sample = (int)((P + (1L << L.stride_log2) - 1) >> L.stride_log2);
     long g = (long)(kGroupBytes / (size_t)(3 * P));
@@ -88,12 +93,13 @@ Layout make_layout(int n, long P, int method = kMethodMacenko, int schedule = 0,
     L.off_diag = o;     o = align_up(o + sizeof(int32_t) * (size_t)n);
     L.off_partials = o; o = align_up(o + sizeof(double) * 32 * (size_t)L.parts * L.G);     // 10 (Macenko) / 32 (Vahadane) per item
     L.off_sample = o;   o = align_up(o + sizeof(uint32_t) * (size_t)L.n_sample * slots);
-    // list capacities scale with the tile: ~7 % of the pixels are raw candidates of the merged selection sweep (angle ~2.5 %,
-    // concentrations ~4.5 %), ~1 % end up in a bracket
-    L.cap_raw = (int)(P / 8 > kMinCapRaw ? P / 8 : kMinCapRaw);
-    // (bracket members: P/40 held them on i.i.d. tiles; spatially smooth and real tissue tiles put 30-60 k pixels into the concentration
-    //  brackets the merged sweep widens by the box of stain matrices, and a full list costs the tile its separate sweep)
-    L.cap_list = (int)(P / 12 > kMinCapList ? P / 12 : kMinCapList);
+    // list capacities scale with the tile.  i.i.d. tiles: ~6 % of the pixels are raw candidates of the merged selection sweep (angle
+    // ~2.5 %, concentrations ~4 %) and ~4.5 % end up in a bracket.  Real tissue fills them further -- the concentration brackets the
+    // merged sweep widens by the box of stain matrices hold up to 8 % of the pixels of a stained-tissue tile with background, the raw
+    // list 11 % (tools/merged_diag.py on windows of the ihc fixture) -- and a full list costs the tile its separate sweep: 1/6 and 1/8
+    // of the pixels (round 3's first cut had 1/8 and 1/12: 13 of 400 soak tiles with default parameters still overflowed).
+    L.cap_raw = (int)(P / 6 > kMinCapRaw ? P / 6 : kMinCapRaw);
+    L.cap_list = (int)(P / 8 > kMinCapList ? P / 8 : kMinCapList);
     L.off_cand = o;     o = align_up(o + sizeof(uint32_t) * (size_t)L.cap_raw * slots);
     L.off_list = o;     o = align_up(o + sizeof(float) * 2 * (size_t)L.cap_list * slots);
     L.off_state = o;    o = align_up(o + sizeof(TileState) * (size_t)L.G);

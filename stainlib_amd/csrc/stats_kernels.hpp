@@ -39,8 +39,8 @@
 namespace sl {
 
 constexpr int kMaxSample = 16384;   // samples per tile (<= P/64)
-constexpr int kMinCapRaw = 65536;   // raw-pixel candidate capacity per tile and stage: max(this, P/12), set by the host
-constexpr int kMinCapList = 16384;  // exact-key bracket members per list after the refine pass: max(this, P/12)
+constexpr int kMinCapRaw = 65536;   // raw-pixel candidate capacity per tile and stage: max(this, P/6), set by the host
+constexpr int kMinCapList = 16384;  // exact-key bracket members per list after the refine pass: max(this, P/8)
 #ifdef SL_EXP_FIN512
 constexpr int kFinishThreads = 512;
 #else

@@ -412,25 +412,30 @@ def test_first_eigenvector_with_a_negative_component_takes_the_per_pixel_tissue_
 
 def test_resweep_reasons_are_reported_by_the_fused_schedule():
     """SlParams.resweeps_out: 0 for a tile whose concentration percentiles came out of the merged selection sweep, an SL_RESWEEP_*
-    reason otherwise (a 12-colour palette tile overflows its candidate list: SL_RESWEEP_LIST_FULL = 4; a 256^2 tile has a sample of
-    1 024 pixels, whose 6-sigma angular brackets are open at the low end -- no box of stain matrices: SL_RESWEEP_NO_BOX = 1, the
-    tile takes the separate concentration sweep like every tile did before round 3).  Diagnostics only -- the results are the
+    reason otherwise (a candidate list that overflows -- an angular percentile of 60 puts most of the tissue on it, a 12-colour palette tile
+    may -- gives SL_RESWEEP_LIST_FULL = 4; a 64^2 tile has a sample of
+    256 pixels, whose angular brackets are open at the low end -- no box of stain matrices: SL_RESWEEP_NO_BOX = 1, the tile takes the
+    separate concentration sweep like every tile did before round 3; a 256^2 tile, sampled one pixel in 16, has its box).
+    Diagnostics only -- the results are the
     oracle's either way; the one-launch-per-phase schedule leaves the buffer untouched."""
     from stainlib_amd import engine
     tgt = so.synth_tile(96, 96, 1001, so.M_TRUE_TGT)
     Mt, mct, _ = engine.macenko_fit(to_dev([tgt]))
     big = [so.synth_tile(1024, 1024, 11), so.structured_tile("palette12", 1024, 1024, 4), so.structured_tile("blobs", 1024, 1024, 5)]
-    small = [so.synth_tile(256, 256, 11), so.structured_tile("blobs", 256, 256, 5)]
-    for tiles, sched, want in ((big, 2, [0, 4, 0]), (big, 1, [-1, -1, -1]), (small, 2, [1, 1])):
-        p = engine.make_params(schedule=sched)
+    small = [so.synth_tile(64, 64, 11), so.structured_tile("blobs", 64, 64, 5)]
+    mid = [so.synth_tile(256, 256, 11), so.synth_tile(256, 256, 12)]
+    for tiles, sched, pct, want in ((big, 2, 99.0, [0, (0, 4), 0]), (big, 1, 99.0, [-1, -1, -1]), (small, 2, 99.0, [1, 1]), (mid, 2, 99.0, [0, 0]),
+                                    (big[:1], 2, 60.0, [4])):       # an angular percentile of 60: 80 % of the tissue lies outside the plain cone
+        p = engine.make_params(schedule=sched, angular_percentile=pct)
         rs = torch.full((len(tiles),), -1, dtype=torch.int32, device="cuda")
         p.resweeps_out = rs.data_ptr()
         out, M, mc, st = engine.macenko_transform(to_dev(tiles), Mt[0], mct[0], params=p)
         assert (st.cpu().numpy() == 0).all()
-        assert rs.cpu().tolist() == want
+        got = rs.cpu().tolist()
+        assert all((g in w) if isinstance(w, tuple) else g == w for g, w in zip(got, want)), (got, want)
         if sched == 2:
             for i, I in enumerate(tiles):
-                np.testing.assert_allclose(M.cpu().numpy()[i], so.macenko_stain_matrix(I), rtol=0, atol=M_ATOL)
+                np.testing.assert_allclose(M.cpu().numpy()[i], so.macenko_stain_matrix(I, 0.8, pct), rtol=0, atol=M_ATOL)
 
 
 def test_uniform_grey_background_does_not_flood_the_candidate_list():

@@ -68,22 +68,39 @@ def test_random_mid_size_tiles_against_the_oracle():
     """The same against the oracle at 512^2 ... 1024^2, where the merged selection sweep settles the concentration percentiles
     (smaller tiles have no box of stain matrices and take the separate sweep): i.i.d. / smooth / quantised content, a uniform grey or
     white background over 0-85 % of the tile, the default and two other extractor settings, both schedules.  The resweep reasons
-    are printed; every tile must come out with the oracle's statistics and bytes whatever route it took."""
+    are printed; every tile must come out with the oracle's statistics and bytes whatever route it took.
+    SL_FUZZ_CASES / SL_FUZZ_SEED (environment) turn it into a long soak: that many cases from that seed, with arbitrary tile shapes
+    (300..1100 pixels a side, any remainder modulo 4) and real stained tissue (the ihc fixture, mirror-tiled and cropped) among them."""
     import numpy as np
     import torch
     from oracle import stain_oracle as so
     from stainlib_amd import engine
     from tests.gpu_util import to_dev, u8_parity
-    rng = np.random.RandomState(77)
+    soak = "SL_FUZZ_CASES" in os.environ
+    rng = np.random.RandomState(int(os.environ.get("SL_FUZZ_SEED", "77")))
+    ihc = np.load(os.path.join(os.path.dirname(__file__), "golden", "tissue_ihc_512.npz"))["input"] if soak else None
     tgt = so.synth_tile(96, 96, 1001, so.M_TRUE_TGT)
     Mt = so.macenko_stain_matrix(tgt)
     mct = np.percentile(so.get_concentrations(tgt, Mt), 99, axis=0)
     routes = {}
-    for case in range(14):
+    for case in range(int(os.environ.get("SL_FUZZ_CASES", "14"))):
         h, w = int(rng.choice([512, 640, 768, 1024])), int(rng.choice([512, 600, 768, 1024]))
         kind = rng.choice(["iid", "iid", "quantized", "blobs"])
+        if soak and rng.rand() < 0.6:
+            h, w = int(rng.randint(300, 1101)), int(rng.randint(300, 1101))
+        if soak and rng.rand() < 0.25:
+            kind = "ihc"
         seed = int(rng.randint(1 << 20))
-        I = (so.synth_tile(h, w, seed) if kind == "iid" else so.structured_tile(kind, h, w, seed)).copy()
+        if kind == "ihc":                      # real tissue: mirror-tiled to 1024^2, a random window of it, optionally flipped / darkened
+            big = np.concatenate([ihc, ihc[::-1]], axis=0)
+            big = np.concatenate([big, big[:, ::-1]], axis=1)
+            y0, x0 = int(rng.randint(0, 1024 - min(h, 1024) + 1)), int(rng.randint(0, 1024 - min(w, 1024) + 1))
+            h, w = min(h, 1024), min(w, 1024)
+            I = big[y0:y0 + h, x0:x0 + w].copy()
+            if rng.rand() < 0.5:
+                I = (I.astype(np.float64) * rng.uniform(0.7, 1.0)).astype(np.uint8)
+        else:
+            I = (so.synth_tile(h, w, seed) if kind == "iid" else so.structured_tile(kind, h, w, seed)).copy()
         frac = float(rng.choice([0.0, 0.3, 0.6, 0.85]))
         if frac > 0:
             I[rng.rand(h, w) < frac] = int(rng.choice([255, 245, 235]))
