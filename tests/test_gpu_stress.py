@@ -32,12 +32,12 @@ def test_random_small_tiles_against_the_oracle():
     from oracle import stain_oracle as so
     from stainlib_amd import engine
     from tests.gpu_util import to_dev, u8_parity
-    rng = np.random.RandomState(2024)
+    rng = np.random.RandomState(int(os.environ.get("SL_FUZZ_SEED", "2024")))       # SL_FUZZ_CASES / SL_FUZZ_SEED: a longer soak
     tgt = so.synth_tile(96, 96, 1001, so.M_TRUE_TGT)
     Mt = so.macenko_stain_matrix(tgt)
     mct = np.percentile(so.get_concentrations(tgt, Mt), 99, axis=0)
     done = 0
-    while done < 24:
+    while done < int(os.environ.get("SL_FUZZ_CASES", "24")):
         h, w = int(rng.randint(6, 220)), int(rng.randint(8, 260))
         kind = rng.choice(["iid", "white_bg", "quantized", "blobs"])
         seed = int(rng.randint(1 << 20))
@@ -60,7 +60,7 @@ def test_random_small_tiles_against_the_oracle():
         np.testing.assert_allclose(M.cpu().numpy()[0], Mo, rtol=0, atol=5e-6, err_msg=label)
         np.testing.assert_allclose(mc.cpu().numpy()[0], mco, rtol=5e-6, err_msg=label)
         want = so.truncate_u8(255 * np.exp(-(Co * (mct / mco)) @ Mt)).reshape(I.shape)
-        u8_parity(out.cpu().numpy()[0], want, label=label)
+        u8_parity(out.cpu().numpy()[0], want, label=label, src=I)
         done += 1
 
 
@@ -125,6 +125,62 @@ def test_random_mid_size_tiles_against_the_oracle():
                 if int(rs[0]):
                     print("  separate sweep, reason", int(rs[0]), ":", label)
         assert torch.equal(outs[0], outs[1])
-        u8_parity(outs[0].cpu().numpy()[0], want, label=label)
+        u8_parity(outs[0].cpu().numpy()[0], want, label=label, src=I)
     print("resweep reasons over the cases (0 = merged sweep settled the tile):", routes)
     assert routes.get(0, 0) >= 7          # the merged route is the normal one at these sizes
+
+
+def test_random_tiles_through_the_secondary_operators_against_the_oracle():
+    """HED-lighter / HED-light, StainAugmentor.pop (with and without background), Reinhard (with and without masking) and the
+    luminosity standardizer on random shapes (ragged, any remainder modulo 4, 8...520 pixels a side) and contents, each against
+    the oracle: bytes within the stated bar for the floating-point operators, bit-exact for the integer Lab family.
+    SL_FUZZ_CASES / SL_FUZZ_SEED: a longer soak, with windows of the real-tissue fixture among the tiles."""
+    import numpy as np
+    import stainlib_amd as sl
+    from oracle import stain_oracle as so
+    from stainlib_amd import engine
+    from tests.gpu_util import to_dev, u8_parity
+    soak = "SL_FUZZ_CASES" in os.environ
+    rng = np.random.RandomState(int(os.environ.get("SL_FUZZ_SEED", "78")))
+    ihc = np.load(os.path.join(os.path.dirname(__file__), "golden", "tissue_ihc_512.npz"))["input"]
+    tgt = so.synth_tile(80, 80, 1001, so.M_TRUE_TGT)
+    rn, orn = sl.ReinhardStainNormalizer(), so.ReinhardStainNormalizer()
+    rn.fit(tgt)
+    orn.fit(tgt)
+    for case in range(int(os.environ.get("SL_FUZZ_CASES", "10"))):
+        h, w = int(rng.randint(8, 521)), int(rng.randint(8, 521))
+        kind = rng.choice(["iid", "white_bg", "quantized", "blobs", "ihc"])
+        seed = int(rng.randint(1 << 20))
+        if kind == "ihc":
+            y0, x0 = int(rng.randint(0, 512 - min(h, 512) + 1)), int(rng.randint(0, 512 - min(w, 512) + 1))
+            I = ihc[y0:y0 + h, x0:x0 + w].copy()
+        else:
+            I = so.synth_tile(h, w, seed) if kind == "iid" else so.structured_tile(kind, h, w, seed)
+        label = f"{kind} {I.shape[0]}x{I.shape[1]} seed {seed}"
+        dev = to_dev([I])
+        # HED: both augmenters' ranges
+        for cls in (sl.HedLighterColorAugmenter, sl.HedLightColorAugmenter):
+            sig, bia = cls().randomize_batch(1)
+            o, applied = engine.hed_augment(dev, sig, bia)
+            want = so.hed_transform(I, sig[0], bia[0])
+            if int(applied[0]):
+                u8_parity(o[0].cpu().numpy(), want, label="hed " + label, src=I)
+            else:
+                assert np.array_equal(o[0].cpu().numpy(), I) and np.array_equal(want, I), label
+        # StainAugmentor.pop on the device's own stain matrix
+        M, _, st = engine.macenko_fit(dev)
+        if int(st[0]) == 0:
+            ab = np.array([[rng.uniform(0.8, 1.2), rng.uniform(-0.2, 0.2), rng.uniform(0.8, 1.2), rng.uniform(-0.2, 0.2)]])
+            for bg in (False, True):
+                out = engine.stain_augment(dev, M, ab, augment_background=bg).cpu().numpy()
+                a = so.StainAugmentor("macenko", augment_background=bg)
+                a.image_shape, a.stain_matrix = I.shape, M[0].cpu().numpy()
+                a.source_concentrations, a.tissue_mask = so.get_concentrations(I, a.stain_matrix), so.tissue_mask(I).ravel()
+                u8_parity(out[0], a.pop_with([ab[0, 0], ab[0, 2]], [ab[0, 1], ab[0, 3]]), label=f"pop bg={bg} " + label, src=I)
+        # the integer Lab family: bit-exact
+        has_tissue = bool(so.tissue_mask(so.standardize_brightness(I)).any())
+        for mask in ((False, True) if has_tissue else (False,)):
+            out, _ = rn.transform_batch(dev, mask_background=mask)
+            assert np.array_equal(out[0].cpu().numpy(), orn.transform(I, mask_background=mask)), ("reinhard", mask, label)
+        lum, _ = engine.luminosity_standardize(dev, 95)
+        assert np.array_equal(lum[0].cpu().numpy(), so.luminosity_standardize(I)), ("luminosity", label)
