@@ -1920,6 +1920,38 @@ __device__ __forceinline__ void ab_from_class_moments(const double* mom /*[3][10
     }
 }
 
+// The dictionary objective at D, up to a constant, from the class moments of D's OWN partition (the moments a sweep
+// under D returns): with alpha the exact codes,
+//   sum_i 1/2 |x_i - D' alpha_i|^2 + lam 1' alpha_i  =  1/2 sum |x_i|^2  -  tr(D B)  +  1/2 tr(G A)  +  lam 1' sum alpha.
+// The first term does not depend on D; pixels without an active stain contribute to none of the others, so the three
+// active classes' moments are all it takes.  dict_iter_update holds the iteration to a monotone descent with it.
+__device__ __forceinline__ double dict_objective(const double* mom /*[3][10]*/, const double (&D)[2][3], double lam) {
+    double A[2][2], B[3][2];
+    ab_from_class_moments(mom, D, lam, A, B);
+    const double g11 = D[0][0] * D[0][0] + D[0][1] * D[0][1] + D[0][2] * D[0][2];
+    const double g22 = D[1][0] * D[1][0] + D[1][1] * D[1][1] + D[1][2] * D[1][2];
+    const double g12 = D[0][0] * D[1][0] + D[0][1] * D[1][1] + D[0][2] * D[1][2];
+    const double rdet = 1.0 / (g11 * g22 - g12 * g12);
+    double sa = 0.0;                                                     // 1' sum alpha
+    if (mom[0] > 0) {                                                    // both active: alpha = P (D x - lam 1)
+        const double c0 = (g22 - g12) * rdet, c1 = (g11 - g12) * rdet;   // 1' P
+        const double ds0 = D[0][0] * mom[1] + D[0][1] * mom[2] + D[0][2] * mom[3];
+        const double ds1 = D[1][0] * mom[1] + D[1][1] * mom[2] + D[1][2] * mom[3];
+        sa += c0 * (ds0 - lam * mom[0]) + c1 * (ds1 - lam * mom[0]);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const double* m = mom + 10 * (1 + j);
+        if (m[0] > 0) sa += (D[j][0] * m[1] + D[j][1] * m[2] + D[j][2] * m[3] - lam * m[0]) / (j == 0 ? g11 : g22);
+    }
+    double tdb = 0.0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) tdb = fma(D[j][k], B[k][j], tdb);
+    return -tdb + 0.5 * (g11 * A[0][0] + 2.0 * g12 * A[0][1] + g22 * A[1][1]) + lam * sa;
+}
+
 #ifdef SL_DEBUG_INNER
 __device__ unsigned long long g_dbg_inner[4];     // solves, passes, wall-clock ticks (development aid)
 #endif
@@ -1950,7 +1982,7 @@ __device__ __forceinline__ void dict_bcd_pass(const double* mom, double (&D)[2][
 // removes the dominant mode (same fixed points: it stops only where g(D) = D).  A mixed step is taken only while the
 // residual keeps shrinking and |gamma| is moderate; otherwise the pass is a plain one.  max_it = 1 is exactly one
 // plain pass.  Returns the largest change of D over the whole call.
-__device__ __forceinline__ double dict_inner_solve(const double* mom, double (&D)[2][3], double lam, int max_it, double inner_tol) {
+__device__ __forceinline__ double dict_inner_solve(const double* mom, double (&D)[2][3], double lam, int max_it, double inner_tol, bool mix) {
 #ifdef SL_DEBUG_INNER
     const long long dbg_t0 = wall_clock64();
     int dbg_its = 0;
@@ -1986,7 +2018,7 @@ __device__ __forceinline__ double dict_inner_solve(const double* mom, double (&D
             }
         const bool last = step < inner_tol || it + 1 == max_it;
         double gamma = 0.0;
-        if (!last && have_prev && fn < fn_prev && dfdf > 1e-300) {
+        if (mix && !last && have_prev && fn < fn_prev && dfdf > 1e-300) {
             gamma = fdf / dfdf;
             if (!(fabs(gamma) <= 20.0)) gamma = 0.0;
         }
@@ -2035,10 +2067,14 @@ struct DictIter {
     double D[6];
     double Dprev[6];
     double delta, delta_prev;   // max-abs change of D by the last update and by the one before it
+    double Facc;                // the lowest objective (dict_objective) an accepted iterate of this stage has shown
     int inner_cap;
     int status;
-    int cycled;                 // the last update was a cycle break (midpoint restart): its delta says nothing about the rate
-    int pad_;
+    int cycled;                 // the last update was a cycle break / a rejected step: its delta says nothing about the rate
+    int mix;                    // the frozen-partition solves use Anderson mixing (off after a rejected step)
+    int first_pending;          // the next solve is the capped first one (kDictFirstCap)
+    int last_first, last_cap;   // what the last solve was: the capped first one / its pass limit
+    int rejected;               // steps taken back so far (diagnostics)
 };
 __device__ __forceinline__ void dict_iter_init(DictIter& it) {
     // deterministic start: Ruifrok's H and E optical-density vectors, unit norm
@@ -2047,9 +2083,11 @@ __device__ __forceinline__ void dict_iter_init(DictIter& it) {
     for (int k = 0; k < 3; ++k) { it.D[k] = h[k] / nh; it.D[3 + k] = e[k] / ne; }
     it.status = SL_TILE_OK;
     it.delta = it.delta_prev = 1.0;
-    it.cycled = 0; it.pad_ = 0;
+    it.cycled = 0;
     for (int k = 0; k < 6; ++k) it.Dprev[k] = 1e300;
     it.inner_cap = 500;
+    it.Facc = 1e300;
+    it.mix = 1; it.first_pending = 1; it.last_first = 0; it.last_cap = 0; it.rejected = 0;
 }
 // one lane: the dictionary update from the 31 class-moment sums of a sweep (sum[30] = tissue pixels seen).
 // stage: 1 sample iteration, 2 full sweep; outer = steps already taken in this stage.
@@ -2065,7 +2103,36 @@ __device__ __forceinline__ void dict_iter_update(DictIter& it, const double* sum
     double D[2][3];
     for (int j = 0; j < 2; ++j)
         for (int k = 0; k < 3; ++k) D[j][k] = it.D[3 * j + k];
-    const double delta = dict_inner_solve(sum, D, lam, stage == 1 && outer == 0 && it.inner_cap > kDictFirstCap ? kDictFirstCap : it.inner_cap, fmax(1e-3 * goal, 1e-13));
+    // Safeguards.  The sums were taken under it.D's own partition, so they give the true objective there and say whether
+    // every atom still has pixels that use it.  The target is DEFINED as the point the plain block-coordinate scheme
+    // reaches from the Ruifrok start (oracle/stain_oracle.py vahadane_dictionary); the long frozen-partition solves and
+    // their mixed steps are an acceleration of it that can leave its path while the partition is still far from final:
+    //  - a step that RAISED the objective (beyond the binary32 bursts' noise) -- an over-extrapolated mixed step, seen
+    //    on a smooth tile at lambda 0.2: objective +10 %;
+    //  - a step that left an atom WITHOUT any pixel: a solve on a partition that no longer holds can shrink an atom
+    //    inside the unit ball until no pixel's projection on it exceeds lambda.  A dead atom is never updated again (its
+    //    A_jj is 0, in every scheme: a fixed point), and the objective may even have dropped on the way (seen on a
+    //    26 x 186 window of real tissue: from 0.567 at the start to 0.170 with one atom dead; the target has 0.163).
+    // Either step is taken back: D returns to the iterate before it (the next sweep re-evaluates its sums), the solves
+    // lose the mixing first and then three quarters of their passes per rejection.  At one unmixed pass the scheme IS
+    // the plain one and its steps stand, whatever they do.
+    const double F = dict_objective(sum, D, lam);
+    const bool dead = sum[0] + sum[10] <= 0.0 || sum[0] + sum[20] <= 0.0;
+    const bool plain = !it.mix && it.last_cap <= 1;
+    if ((dead || F > it.Facc + 1e-6 * sum[30]) && !plain && it.Dprev[0] < 1e299) {
+        for (int k = 0; k < 6; ++k) { it.D[k] = it.Dprev[k]; it.Dprev[k] = 1e300; }
+        if (it.mix) it.mix = 0;
+        else it.inner_cap = it.last_cap > 4 ? it.last_cap / 4 : 1;
+        if (it.last_first) it.first_pending = 1;
+        it.delta = it.delta_prev = 1.0;
+        it.cycled = 1;
+        ++it.rejected;
+        return;
+    }
+    it.Facc = fmin(it.Facc, F);
+    const int cap = it.first_pending && it.inner_cap > kDictFirstCap ? kDictFirstCap : it.inner_cap;
+    it.last_first = it.first_pending; it.last_cap = cap; it.first_pending = 0;
+    const double delta = dict_inner_solve(sum, D, lam, cap, fmax(1e-3 * goal, 1e-13), it.mix != 0);
     // The frozen-partition solve is a Newton-like step on a piecewise-smooth map and can fall
     // into a 2-cycle between two partitions: the new iterate then returns to the one before
     // last.  In that case restart from the midpoint and shorten the inner solve; at one inner
@@ -2087,10 +2154,13 @@ __device__ __forceinline__ void dict_iter_update(DictIter& it, const double* sum
 }
 // the sample stage is over: the full sweeps restart the cycle detector
 __device__ __forceinline__ void dict_iter_restart(DictIter& it) {
-    for (int k = 0; k < 6; ++k) it.Dprev[k] = 1e300;
+    // (Dprev stays: the cycle test waits for two steps of the new stage, and a first full sweep that finds an atom dead can
+    // still step back)
     it.inner_cap = 500;
     it.delta = it.delta_prev = 1.0;
     it.cycled = 0;
+    it.Facc = 1e300;            // (another pixel set: the sample's objective says nothing about the tile's)
+    it.mix = 1; it.first_pending = 0; it.last_cap = 500;
 }
 // H first: swap when D[0,0] < D[1,0] (vahadane_stain_extractor.py:40-41), unit-norm rows (:43)
 __device__ __forceinline__ void dict_iter_stain_matrix(const DictIter& it, double* M) {
