@@ -186,20 +186,25 @@ def test_random_tiles_through_the_secondary_operators_against_the_oracle():
         assert np.array_equal(lum[0].cpu().numpy(), so.luminosity_standardize(I)), ("luminosity", label)
 
 
-def vahadane_cases(seed):
+def vahadane_cases(seed, lo=24, hi=300):
     """The random Vahadane cases of the test below (tools/vahadane_case.py replays one of them): label, tile, threshold, lambda,
-    schedule."""
+    schedule.  Tiles of lo...hi pixels a side."""
     import numpy as np
     from oracle import stain_oracle as so
     rng = np.random.RandomState(seed)
     ihc = np.load(os.path.join(os.path.dirname(__file__), "golden", "tissue_ihc_512.npz"))["input"]
     while True:
-        h, w = int(rng.randint(24, 301)), int(rng.randint(24, 301))
+        h, w = int(rng.randint(lo, hi + 1)), int(rng.randint(lo, hi + 1))
         kind = rng.choice(["iid", "iid", "quantized", "blobs", "ihc"])
         seed_t = int(rng.randint(1 << 20))
         if kind == "ihc":
-            y0, x0 = int(rng.randint(0, 512 - h + 1)), int(rng.randint(0, 512 - w + 1))
-            I = ihc[y0:y0 + h, x0:x0 + w].copy()
+            big = ihc
+            if max(h, w) > 512:                                                    # (mirror-tiled beyond 512)
+                big = np.concatenate([ihc, ihc[:, ::-1]], axis=1)
+                big = np.concatenate([big, big[::-1]], axis=0)
+                big = np.tile(big, (-(-h // 1024), -(-w // 1024), 1))
+            y0, x0 = int(rng.randint(0, big.shape[0] - h + 1)), int(rng.randint(0, big.shape[1] - w + 1))
+            I = big[y0:y0 + h, x0:x0 + w].copy()
         else:
             I = so.synth_tile(h, w, seed_t) if kind == "iid" else so.structured_tile(kind, h, w, seed_t)
         thr, lam = float(rng.choice([0.8, 0.8, 0.7, 0.9])), float(rng.choice([0.1, 0.1, 0.05, 0.2]))
@@ -213,19 +218,25 @@ def test_random_tiles_through_the_vahadane_fit_against_the_converged_oracle():
     """Vahadane dictionaries of random tiles (ragged shapes 24...300 pixels a side; i.i.d., smooth, quantised content, windows of the
     real-tissue fixture; the default and other lambda / threshold settings; both schedules) against the oracle's block-coordinate
     descent run to 1e-12: unit-norm rows within 1e-5 where the optimum is well conditioned, and never a worse objective than the
-    oracle's (the certificate that does not depend on conditioning).  SL_FUZZ_CASES / SL_FUZZ_SEED: a longer soak."""
+    oracle's (the certificate that does not depend on conditioning).  Then the transform of the same tile onto a fixed target: the
+    tile's stain matrix must be the fit's, and maxC and the bytes those of the reference's remaining steps (normalizer.py:46-50,
+    restated by the oracle) run on that matrix.  SL_FUZZ_CASES / SL_FUZZ_SEED: a longer soak; SL_FUZZ_SIZE=lo,hi: other tile sizes."""
     import numpy as np
     from oracle import stain_oracle as so
     from stainlib_amd import engine
-    from tests.gpu_util import to_dev
+    from tests.gpu_util import to_dev, u8_parity
     seed = int(os.environ.get("SL_FUZZ_SEED", "79"))
+    lo, hi = (int(v) for v in os.environ.get("SL_FUZZ_SIZE", "24,300").split(","))
+    Mt = so.normalize_rows(np.array([[0.60, 0.72, 0.35], [0.12, 0.93, 0.34]]))
+    mct = np.array([1.7, 1.1])
     worst, failures = 0.0, []
-    for index, (label, I, thr, lam, sched) in enumerate(vahadane_cases(seed)):
+    for index, (label, I, thr, lam, sched) in enumerate(vahadane_cases(seed, lo, hi)):
         if index >= int(os.environ.get("SL_FUZZ_CASES", "8")):
             break
         label = f"case {index} of seed {seed}: {label}"
         p = engine.make_params(luminosity_threshold=thr, dl_lambda=lam, dl_tol=1e-9, dl_max_sweeps=400, schedule=sched)
-        M, mc, st, sweeps = engine.vahadane_fit(to_dev([I]), params=p)
+        dev = to_dev([I])
+        M, mc, st, sweeps = engine.vahadane_fit(dev, params=p)
         assert int(st[0]) == 0, label
         M = M.cpu().numpy()[0]
         Mo = so.vahadane_stain_matrix(I, luminosity_threshold=thr, regularizer=lam, max_sweeps=2000, tol=1e-12)
@@ -242,8 +253,17 @@ def test_random_tiles_through_the_vahadane_fit_against_the_converged_oracle():
         # the distance bar applies where the two atoms are separated
         if obj(M) > obj(Mo) + 1e-9 or (float(Mo[0] @ Mo[1]) < 0.98 and err >= 1e-5):
             failures.append((label, obj(M), obj(Mo), err, int(sweeps[0])))
-        else:
-            worst = max(worst, err)
+            continue
+        worst = max(worst, err)
+        out, M2, mc2, st2 = engine.vahadane_transform(dev, Mt, mct, params=p)
+        assert int(st2[0]) == 0, label
+        np.testing.assert_array_equal(M2.cpu().numpy()[0], M, err_msg=label)
+        C = so.get_concentrations(I, M)
+        maxC = np.percentile(C, 99, axis=0)
+        np.testing.assert_allclose(mc2.cpu().numpy()[0], maxC, rtol=2e-5, atol=1e-9, err_msg=label)
+        np.testing.assert_array_equal(mc.cpu().numpy()[0], mc2.cpu().numpy()[0], err_msg=label)
+        want = so.truncate_u8(255 * np.exp(-(C * (mct / maxC)) @ Mt)).reshape(I.shape)
+        u8_parity(out[0].cpu().numpy(), want, label=label, src=I)
     print(f"worst |M - M_oracle| over the passing cases: {worst:.2e}")
     assert not failures, failures
 
