@@ -60,8 +60,13 @@ __device__ __forceinline__ void rgb_to_lab8(const LabTabs& t, uint32_t r, uint32
 // OpenCV abToXZ_b[i - minABvalue] evaluated instead of stored (36864 entries): C integer arithmetic, division truncates.
 // Both branches are evaluated for every lane; the cubic one only counts for i > 3390, where every operand is positive and
 // the two divisions by 16384 are plain shifts (as signed divisions they cost a sign fix-up each).
+// The truncating division by 841 (a full-width multiply-high and a multiply-low at a quarter of the vector rate each, plus
+// the sign fix-up) is done in binary32 instead: x = 108 i is exact there (|x| < 2^23), x * (1/841) is off by at most
+// 1.3e-4 in the range the linear branch is used (|x / 841| < 1100), and exact quotients keep 1/841 = 1.19e-3 away from the
+// integers they do not hit -- so truncating x/841 pushed half of 1/841 away from zero gives C's quotient for every x.
 __device__ __forceinline__ int ab_to_xz(int i) {
-    const int lin = (i * 108) / 841 - 290;                // 290 = BASE*16/116*108/841
+    const float xf = (float)__mul24(i, 108);                  // (|i| < 2^17: a 24-bit multiply, the full-width one runs at quarter rate)
+    const int lin = (int)fmaf(xf, 1.0f / 841.0f, copysignf(0.5f / 841.0f, xf)) - 290;     // (i * 108) / 841 - 290;  290 = BASE*16/116*108/841
     const uint32_t u = (uint32_t)i;                       // (i < 2^17, (i*i) >> 14 < 2^20: 24-bit multiplies, the full-width ones run at quarter rate)
     const int cub = (int)(__umul24(__umul24(u, u) >> 14, u) >> 14);
     return i <= 3390 ? lin : cub;
@@ -73,9 +78,11 @@ __device__ __forceinline__ int lab_adiv(int a) { return ((5 * a * 53687 + 128) >
 __device__ __forceinline__ int lab_bdiv(int b) { return ((b * 41943 + 16) >> 9) - 10485 + 1; }
 __device__ __forceinline__ void yf_to_rgb(const LabTabs& t, int y, int ify, int adiv, int bdiv, uint32_t& r, uint32_t& g, uint32_t& bl) {
     const int x = ab_to_xz(ify + adiv), z = ab_to_xz(ify - bdiv);
-    int ro = (12615 * x - 6296 * y - 2223 * z + 8192) >> 14;
-    int go = (-3773 * x + 7684 * y + 185 * z + 8192) >> 14;
-    int bo = (217 * x - 836 * y + 4715 * z + 8192) >> 14;
+    // x, z < 2^17 (ab_to_xz of an argument below 2^15 + 2^14), y < 2^15: 24-bit multiplies (the compiler cannot see the ranges and
+    // would issue full-width ones at a quarter of the rate); every sum stays below 2^31 as in OpenCV's int arithmetic
+    int ro = (__mul24(12615, x) - __mul24(6296, y) - __mul24(2223, z) + 8192) >> 14;
+    int go = (__mul24(-3773, x) + __mul24(7684, y) + __mul24(185, z) + 8192) >> 14;
+    int bo = (__mul24(217, x) - __mul24(836, y) + __mul24(4715, z) + 8192) >> 14;
     ro = ro < 0 ? 0 : (ro > 4095 ? 4095 : ro);
     go = go < 0 ? 0 : (go > 4095 ? 4095 : go);
     bo = bo < 0 ? 0 : (bo > 4095 ? 4095 : bo);

@@ -1,7 +1,8 @@
 """Quick timings of the main kernels for A/B runs (development aid):
     for lib in A B A B; do STAINLIB_HIP_LIB=$PWD/stainlib_amd/csrc/libstainlib_hip_$lib.so python tools/time_kernels.py; done
 prints one line: fused Macenko transform (512 x 1024^2), k_apply, per-phase transform at 128 tiles, StainAugmentor.pop and
-HED (1250 x 512^2), Vahadane transform (128 and 512 x 1024^2); milliseconds, median of `reps` launches."""
+HED (1250 x 512^2), Vahadane transform (128 and 512 x 1024^2), and with `lab` the Lab family on 1250 x 512^2 (Reinhard
+transform, its statistics sweeps alone, LuminosityStandardizer, both plain conversions); milliseconds, median of `reps` launches."""
 import os
 import sys
 import time
@@ -62,4 +63,13 @@ if "aug" in what or "hed" in what:
         res["aug1250"] = med(lambda: engine.stain_augment(t5, M5, ab, out=o5))
     if "hed" in what:
         res["hed1250"] = med(lambda: engine.hed_augment(t5, sg, sg, out=o5, ws=ws))
+if "lab" in what:
+    t5 = rgb.view(-1, 512, 512, 3)[:1250]
+    o5 = out.view(-1, 512, 512, 3)[:1250]
+    tm, ts = np.array([60.0, 12.0, -8.0]), np.array([18.0, 6.0, 5.0])
+    res["reinhard1250"] = med(lambda: engine.reinhard_transform(t5, tm, ts, out=o5, ws=ws))
+    res["reinhard_stats1250"] = med(lambda: engine.reinhard_stats(t5, ws=ws))
+    res["luminosity1250"] = med(lambda: engine.luminosity_standardize(t5, 95, out=o5, ws=ws))
+    res["rgb2lab1250"] = med(lambda: engine.rgb_to_lab8(t5))
+    res["lab2rgb1250"] = med(lambda: engine.lab8_to_rgb(t5))
 print(os.path.basename(_ffi.LIB_PATH), " ".join(f"{k} {v:.3f}" for k, v in res.items()))
