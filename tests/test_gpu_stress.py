@@ -289,3 +289,66 @@ def test_vahadane_steps_that_leave_the_plain_schemes_path_are_taken_back():
             M, mc, st, sweeps = engine.vahadane_fit(to_dev([I]), params=p)
             assert int(st[0]) == 0, (label, sched)
             np.testing.assert_allclose(M.cpu().numpy()[0], Mo, atol=1e-5, rtol=0, err_msg=f"{label} schedule {sched}")
+
+
+def test_random_slides_through_the_pooled_statistics_against_the_oracle():
+    """Pooled slide statistics of random small slides -- 1...9 tiles of one ragged shape, contents mixed within a slide
+    (i.i.d., smooth, quantised, real-tissue windows, white tiles, a grey background band) -- against the reference recipe on the
+    vertical concatenation of the tiles: stain matrix, maxC, and the bytes of the normalised slide.  Both the device-driven chain
+    and the host-driven rounds.  SL_FUZZ_CASES / SL_FUZZ_SEED: a longer soak."""
+    import numpy as np
+    from oracle import stain_oracle as so
+    import stainlib_amd as sl
+    from stainlib_amd.distributed import PooledSlideStatistics, SlideNormalizer
+    from tests.gpu_util import to_dev, u8_parity
+    rng = np.random.RandomState(int(os.environ.get("SL_FUZZ_SEED", "83")))
+    ihc = np.load(os.path.join(os.path.dirname(__file__), "golden", "tissue_ihc_512.npz"))["input"]
+    tgt = so.synth_tile(128, 128, 1001, so.M_TRUE_TGT)
+    n = sl.MacenkoNormalizer()
+    n.fit(tgt)
+    on = so.ExtractiveStainNormalizer("macenko")
+    on.fit(tgt)
+    done, failures = 0, []
+    while done < int(os.environ.get("SL_FUZZ_CASES", "6")):
+        n_tiles = int(rng.randint(1, 10))
+        h, w = int(rng.randint(32, 201)), int(rng.randint(32, 201))
+        tiles, kinds = [], []
+        for _ in range(n_tiles):
+            kind = rng.choice(["iid", "iid", "blobs", "quantized", "ihc", "white", "grey_band"])
+            seed = int(rng.randint(1 << 20))
+            if kind == "ihc":
+                y0, x0 = int(rng.randint(0, 512 - h + 1)), int(rng.randint(0, 512 - w + 1))
+                t = ihc[y0:y0 + h, x0:x0 + w].copy()
+            elif kind == "white":
+                t = np.full((h, w, 3), 255, np.uint8)
+            elif kind == "grey_band":
+                t = so.synth_tile(h, w, seed)
+                t[:, : w // 3] = 245
+            else:
+                t = so.synth_tile(h, w, seed) if kind == "iid" else so.structured_tile(kind, h, w, seed)
+            tiles.append(t)
+            kinds.append(f"{kind}:{seed}")
+        tall = np.concatenate(tiles, axis=0)
+        try:
+            if int(so.tissue_mask(tall, 0.8).sum()) < 2000:
+                continue
+        except so.TissueMaskException:
+            continue
+        label = f"case {done}: {n_tiles} tiles {h}x{w} {' '.join(kinds)}"
+        M_want = so.macenko_stain_matrix(tall)
+        maxC_want = np.percentile(so.get_concentrations(tall, M_want), 99, axis=0)
+        dev = to_dev(tiles)
+        s1, s2 = PooledSlideStatistics(), PooledSlideStatistics()
+        M1, c1 = s1(dev)
+        M2, c2 = s2.host_driven(dev)
+        try:
+            np.testing.assert_allclose(M1, M_want, rtol=0, atol=2e-6, err_msg=label)
+            np.testing.assert_allclose(c1, maxC_want, rtol=2e-6, err_msg=label)
+            np.testing.assert_allclose(M2, M1, rtol=0, atol=1e-12, err_msg=label)
+            np.testing.assert_allclose(c2, c1, rtol=1e-12, err_msg=label)
+            out, M_s, mc_s, status = SlideNormalizer(n, mode="pooled").transform_shard(dev)
+            u8_parity(out.cpu().numpy().reshape(tall.shape), on.transform(tall), label=label, src=tall)
+        except AssertionError as e:
+            failures.append((label, s1.last_path, s2.last_path, str(e)[:400]))
+        done += 1
+    assert not failures, failures
