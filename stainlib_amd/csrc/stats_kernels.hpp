@@ -3087,7 +3087,8 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
         int fallbacks = 0;
         int sweeps_used = 0;
 #ifdef SL_DEVTOOLS
-#define SL_PHASE(i) { if (a.phase_clock && tid == 0) a.phase_clock[(size_t)tile * 8 + (i)] = wall_clock64(); if (a.debug_stop == (i) + 1) { __syncthreads(); continue; } }
+// (Macenko only: in k_fused<vahadane, transform, unaligned> the extra `continue` edges run into the hipcc bug described in the Makefile)
+#define SL_PHASE(i) { if (METHOD == kMethodMacenko) { if (a.phase_clock && tid == 0) a.phase_clock[(size_t)tile * 8 + (i)] = wall_clock64(); if (a.debug_stop == (i) + 1) { __syncthreads(); continue; } } }
 #else
 #define SL_PHASE(i)
 #endif
