@@ -1860,8 +1860,11 @@ __device__ __forceinline__ void dict_sweep_sample_b(const uint32_t* samp, int n_
 // A[0][0], B[:,0] resp. A[1][1], B[:,1] receive anything.  One lane runs this several hundred times per tile, so
 // its latency is a fixed cost of every tile: the one-stain classes are written out (a third of the generic
 // arithmetic) and the binary64 divisions (~100 dependent cycles each) are three reciprocals.
+// WITH_SA: also 1' sum alpha (for dict_objective), from the same W s - n w the class blocks form anyway.
+template <bool WITH_SA = false>
 __device__ __forceinline__ void ab_from_class_moments(const double* mom /*[3][10]*/, const double (&D)[2][3], double lam,
-                                                      double (&A)[2][2], double (&B)[3][2]) {
+                                                      double (&A)[2][2], double (&B)[3][2], double* sa = nullptr) {
+    double sa_ = 0.0;
     const double g11 = D[0][0] * D[0][0] + D[0][1] * D[0][1] + D[0][2] * D[0][2];
     const double g22 = D[1][0] * D[1][0] + D[1][1] * D[1][1] + D[1][2] * D[1][2];
     const double g12 = D[0][0] * D[1][0] + D[0][1] * D[1][1] + D[0][2] * D[1][2];
@@ -1893,6 +1896,7 @@ __device__ __forceinline__ void ab_from_class_moments(const double* mom /*[3][10
                     A[r][q] = WS2[r][0] * W[q][0] + WS2[r][1] * W[q][1] + WS2[r][2] * W[q][2] - Ws1[r] * w[q] - w[r] * Ws1[q] +
                               n * w[r] * w[q];
             A[1][0] = A[0][1];                                              // S is symmetric
+            if (WITH_SA) sa_ += Ws1[0] + Ws1[1] - n * (w[0] + w[1]);
 #pragma unroll
             for (int k = 0; k < 3; ++k)
 #pragma unroll
@@ -1916,34 +1920,22 @@ __device__ __forceinline__ void ab_from_class_moments(const double* mom /*[3][10
             A[j][j] += WS2[0] * W[0] + WS2[1] * W[1] + WS2[2] * W[2] - 2.0 * Ws1 * w + n * w * w;
 #pragma unroll
             for (int k = 0; k < 3; ++k) B[k][j] += WS2[k] - s1[k] * w;
+            if (WITH_SA) sa_ += Ws1 - n * w;
         }
     }
+    if (WITH_SA) *sa = sa_;
 }
 
 // The dictionary objective at D, up to a constant, from the class moments of D's OWN partition (the moments a sweep
 // under D returns): with alpha the exact codes,
 //   sum_i 1/2 |x_i - D' alpha_i|^2 + lam 1' alpha_i  =  1/2 sum |x_i|^2  -  tr(D B)  +  1/2 tr(G A)  +  lam 1' sum alpha.
 // The first term does not depend on D; pixels without an active stain contribute to none of the others, so the three
-// active classes' moments are all it takes.  dict_iter_update holds the iteration to a monotone descent with it.
-__device__ __forceinline__ double dict_objective(const double* mom /*[3][10]*/, const double (&D)[2][3], double lam) {
-    double A[2][2], B[3][2];
-    ab_from_class_moments(mom, D, lam, A, B);
+// active classes' moments are all it takes -- and A, B are what the first pass of the update needs anyway
+// (ab_from_class_moments<true> adds 1' sum alpha).  dict_iter_update holds the iteration to a monotone descent with it.
+__device__ __forceinline__ double dict_objective(const double (&D)[2][3], double lam, const double (&A)[2][2], const double (&B)[3][2], double sa) {
     const double g11 = D[0][0] * D[0][0] + D[0][1] * D[0][1] + D[0][2] * D[0][2];
     const double g22 = D[1][0] * D[1][0] + D[1][1] * D[1][1] + D[1][2] * D[1][2];
     const double g12 = D[0][0] * D[1][0] + D[0][1] * D[1][1] + D[0][2] * D[1][2];
-    const double rdet = 1.0 / (g11 * g22 - g12 * g12);
-    double sa = 0.0;                                                     // 1' sum alpha
-    if (mom[0] > 0) {                                                    // both active: alpha = P (D x - lam 1)
-        const double c0 = (g22 - g12) * rdet, c1 = (g11 - g12) * rdet;   // 1' P
-        const double ds0 = D[0][0] * mom[1] + D[0][1] * mom[2] + D[0][2] * mom[3];
-        const double ds1 = D[1][0] * mom[1] + D[1][1] * mom[2] + D[1][2] * mom[3];
-        sa += c0 * (ds0 - lam * mom[0]) + c1 * (ds1 - lam * mom[0]);
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const double* m = mom + 10 * (1 + j);
-        if (m[0] > 0) sa += (D[j][0] * m[1] + D[j][1] * m[2] + D[j][2] * m[3] - lam * m[0]) / (j == 0 ? g11 : g22);
-    }
     double tdb = 0.0;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -1956,9 +1948,7 @@ __device__ __forceinline__ double dict_objective(const double* mom /*[3][10]*/, 
 __device__ unsigned long long g_dbg_inner[4];     // solves, passes, wall-clock ticks (development aid)
 #endif
 // one pass of the block-coordinate dictionary update on frozen class moments: D <- g(D)
-__device__ __forceinline__ void dict_bcd_pass(const double* mom, double (&D)[2][3], double lam) {
-    double A[2][2], B[3][2];
-    ab_from_class_moments(mom, D, lam, A, B);
+__device__ __forceinline__ void dict_bcd_update(const double (&A)[2][2], const double (&B)[3][2], double (&D)[2][3]) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         if (A[j][j] > 1e-300) {
@@ -1975,6 +1965,11 @@ __device__ __forceinline__ void dict_bcd_pass(const double* mom, double (&D)[2][
         }
     }
 }
+__device__ __forceinline__ void dict_bcd_pass(const double* mom, double (&D)[2][3], double lam) {
+    double A[2][2], B[3][2];
+    ab_from_class_moments(mom, D, lam, A, B);
+    dict_bcd_update(A, B, D);
+}
 
 // Iterate D <- g(D) until a pass moves D by less than inner_tol (the caller ties it to what the outer iteration still
 // needs).  The plain iteration contracts at ~0.7 per pass (~37 passes); depth-1 Anderson mixing
@@ -1982,7 +1977,9 @@ __device__ __forceinline__ void dict_bcd_pass(const double* mom, double (&D)[2][
 // removes the dominant mode (same fixed points: it stops only where g(D) = D).  A mixed step is taken only while the
 // residual keeps shrinking and |gamma| is moderate; otherwise the pass is a plain one.  max_it = 1 is exactly one
 // plain pass.  Returns the largest change of D over the whole call.
-__device__ __forceinline__ double dict_inner_solve(const double* mom, double (&D)[2][3], double lam, int max_it, double inner_tol, bool mix) {
+// G_first = g(D) of the incoming D, which the caller has from evaluating the objective there (the first pass is not computed twice).
+__device__ __forceinline__ double dict_inner_solve(const double* mom, double (&D)[2][3], double lam, int max_it, double inner_tol, bool mix,
+                                                   const double (&G_first)[2][3]) {
 #ifdef SL_DEBUG_INNER
     const long long dbg_t0 = wall_clock64();
     int dbg_its = 0;
@@ -1996,11 +1993,18 @@ __device__ __forceinline__ double dict_inner_solve(const double* mom, double (&D
     bool have_prev = false;
     for (int it = 0; it < max_it; ++it) {
         double G[2][3];
+        if (it == 0) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) G[j][k] = D[j][k];
-        dict_bcd_pass(mom, G, lam);
+                for (int k = 0; k < 3; ++k) G[j][k] = G_first[j][k];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) G[j][k] = D[j][k];
+            dict_bcd_pass(mom, G, lam);
+        }
 #ifdef SL_DEBUG_INNER
         ++dbg_its;
 #endif
@@ -2061,7 +2065,10 @@ __device__ __forceinline__ double dict_inner_solve(const double* mom, double (&D
 // The state of one tile's dictionary iteration (shared memory in the fused kernel, workspace in the per-phase schedule)
 // The first update works on the partition of the Ruifrok start: solved to the end it collapses both atoms onto one
 // direction (the sample stage then has to pull them apart again); a few passes keep them apart (measured: 12 -> 10
-// solves per tile, 143 -> 108 passes).
+// solves per tile, 143 -> 108 passes) -- and they are PLAIN passes since late round 3: with the objective in hand
+// (dict_iter_update) the mixed first step turned out to raise it on every tile of the bench batch (0.138 -> 0.146: both atoms
+// pushed towards each other, the state the two soak failures started from) and to cost the sample stage two more
+// iterations than six unmixed passes do (7 iterations / 103 passes -> 5 / 40 on i.i.d. tiles).
 constexpr int kDictFirstCap = 6;
 struct DictIter {
     double D[6];
@@ -2071,10 +2078,12 @@ struct DictIter {
     int inner_cap;
     int status;
     int cycled;                 // the last update was a cycle break / a rejected step: its delta says nothing about the rate
-    int mix;                    // the frozen-partition solves use Anderson mixing (off after a rejected step)
-    int first_pending;          // the next solve is the capped first one (kDictFirstCap)
-    int last_first, last_cap;   // what the last solve was: the capped first one / its pass limit
+    int mix;                    // the frozen-partition solves use Anderson mixing (off for the rest of the stage after a rejected mixed step)
+    int first_pending;          // the next solve is the first one: kDictFirstCap plain passes
+    int rej_cap;                // pass limit imposed by rejected steps; recovers fourfold per solve
+    int last_mix, last_cap;     // what the last solve was: mixed or not, its pass limit
     int rejected;               // steps taken back so far (diagnostics)
+    int pad_;
 };
 __device__ __forceinline__ void dict_iter_init(DictIter& it) {
     // deterministic start: Ruifrok's H and E optical-density vectors, unit norm
@@ -2087,7 +2096,7 @@ __device__ __forceinline__ void dict_iter_init(DictIter& it) {
     for (int k = 0; k < 6; ++k) it.Dprev[k] = 1e300;
     it.inner_cap = 500;
     it.Facc = 1e300;
-    it.mix = 1; it.first_pending = 1; it.last_first = 0; it.last_cap = 0; it.rejected = 0;
+    it.mix = 1; it.first_pending = 1; it.rej_cap = 500; it.last_mix = 0; it.last_cap = 0; it.rejected = 0; it.pad_ = 0;
 }
 // one lane: the dictionary update from the 31 class-moment sums of a sweep (sum[30] = tissue pixels seen).
 // stage: 1 sample iteration, 2 full sweep; outer = steps already taken in this stage.
@@ -2113,26 +2122,34 @@ __device__ __forceinline__ void dict_iter_update(DictIter& it, const double* sum
     //    inside the unit ball until no pixel's projection on it exceeds lambda.  A dead atom is never updated again (its
     //    A_jj is 0, in every scheme: a fixed point), and the objective may even have dropped on the way (seen on a
     //    26 x 186 window of real tissue: from 0.567 at the start to 0.170 with one atom dead; the target has 0.163).
-    // Either step is taken back: D returns to the iterate before it (the next sweep re-evaluates its sums), the solves
-    // lose the mixing first and then three quarters of their passes per rejection.  At one unmixed pass the scheme IS
-    // the plain one and its steps stand, whatever they do.
-    const double F = dict_objective(sum, D, lam);
+    // Either step is taken back: D returns to the iterate before it (the next sweep re-evaluates its sums); a mixed step
+    // costs the stage its mixing, an unmixed one three quarters of its passes (the limit recovers fourfold per solve).
+    // At one unmixed pass the scheme IS the plain one and its steps stand, whatever they do.
+    double A0[2][2], B0[3][2], sa0;
+    ab_from_class_moments<true>(sum, D, lam, A0, B0, &sa0);
+    const double F = dict_objective(D, lam, A0, B0, sa0);
     const bool dead = sum[0] + sum[10] <= 0.0 || sum[0] + sum[20] <= 0.0;
-    const bool plain = !it.mix && it.last_cap <= 1;
-    if ((dead || F > it.Facc + 1e-6 * sum[30]) && !plain && it.Dprev[0] < 1e299) {
+    const bool plain = !it.last_mix && it.last_cap <= 1;
+    if ((dead || !(F <= it.Facc + 1e-6 * sum[30])) && !plain && it.Dprev[0] < 1e299) {      // (a NaN objective is a rejection too)
         for (int k = 0; k < 6; ++k) { it.D[k] = it.Dprev[k]; it.Dprev[k] = 1e300; }
-        if (it.mix) it.mix = 0;
-        else it.inner_cap = it.last_cap > 4 ? it.last_cap / 4 : 1;
-        if (it.last_first) it.first_pending = 1;
+        if (it.last_mix) it.mix = 0;
+        else it.rej_cap = it.last_cap > 4 ? it.last_cap / 4 : 1;
         it.delta = it.delta_prev = 1.0;
         it.cycled = 1;
         ++it.rejected;
         return;
     }
     it.Facc = fmin(it.Facc, F);
-    const int cap = it.first_pending && it.inner_cap > kDictFirstCap ? kDictFirstCap : it.inner_cap;
-    it.last_first = it.first_pending; it.last_cap = cap; it.first_pending = 0;
-    const double delta = dict_inner_solve(sum, D, lam, cap, fmax(1e-3 * goal, 1e-13), it.mix != 0);
+    int cap = it.inner_cap < it.rej_cap ? it.inner_cap : it.rej_cap;
+    if (it.first_pending && cap > kDictFirstCap) cap = kDictFirstCap;
+    const bool mix = it.mix && !it.first_pending;
+    it.last_mix = mix ? 1 : 0; it.last_cap = cap; it.first_pending = 0;
+    if (it.rej_cap < 500) it.rej_cap = it.rej_cap * 4 < 500 ? it.rej_cap * 4 : 500;
+    double G1[2][3];
+    for (int j = 0; j < 2; ++j)
+        for (int k = 0; k < 3; ++k) G1[j][k] = D[j][k];
+    dict_bcd_update(A0, B0, G1);                                   // the first pass, from the A and B the objective was read off
+    const double delta = dict_inner_solve(sum, D, lam, cap, fmax(1e-3 * goal, 1e-13), mix, G1);
     // The frozen-partition solve is a Newton-like step on a piecewise-smooth map and can fall
     // into a 2-cycle between two partitions: the new iterate then returns to the one before
     // last.  In that case restart from the midpoint and shorten the inner solve; at one inner
@@ -2160,7 +2177,7 @@ __device__ __forceinline__ void dict_iter_restart(DictIter& it) {
     it.delta = it.delta_prev = 1.0;
     it.cycled = 0;
     it.Facc = 1e300;            // (another pixel set: the sample's objective says nothing about the tile's)
-    it.mix = 1; it.first_pending = 0; it.last_cap = 500;
+    it.mix = 1; it.first_pending = 0; it.rej_cap = 500; it.last_mix = 1; it.last_cap = 500;
 }
 // H first: swap when D[0,0] < D[1,0] (vahadane_stain_extractor.py:40-41), unit-norm rows (:43)
 __device__ __forceinline__ void dict_iter_stain_matrix(const DictIter& it, double* M) {
@@ -2635,7 +2652,11 @@ static __global__ __launch_bounds__(kDictFinishThreads) void k_dict_tail(StatsAr
     if (tid == 0) {
         st.fallbacks = 0;
         st.n_raw = 0; st.overflow = 0;
+#ifdef SL_EXP_DICT_DIAG      // development: sample iterations and rejected steps ride in the sweep count (x 100, x 10000)
+        if (a.sweeps_out) a.sweeps_out[a.tile0 + tile] = ds.pr.sweeps_used + 100 * ds.pr.sample_its + 10000 * ds.it.rejected;
+#else
         if (a.sweeps_out) a.sweeps_out[a.tile0 + tile] = ds.pr.sweeps_used;
+#endif
         s_status = st.status;
         if (st.status == SL_TILE_OK) { LassoK L; lasso_consts(st.M, a.lam, L); s_L = L; }
     }
