@@ -158,7 +158,10 @@ SL_API int sl_macenko_fit(const uint8_t* rgb, int n, int h, int w, const SlParam
                    void* workspace, size_t workspace_bytes, void* stream);
 
 /* VahadaneStainExtractor.get_stain_matrix (extraction/vahadane_stain_extractor.py:19-43) with
- * spams.trainDL replaced by the converged optimum of the same objective, then as above.
+ * spams.trainDL replaced by the converged optimum of the same objective, then as above.  "The" optimum of this
+ * non-convex problem is the point plain full-batch block-coordinate descent reaches from Ruifrok's H and E vectors
+ * (oracle/stain_oracle.py vahadane_dictionary); the device iteration is an acceleration of that scheme that takes a
+ * step back whenever the objective rose or an atom lost all its pixels, so that it stays on the plain scheme's path.
  *   sweeps_out  n int32 (may be NULL): dictionary sweeps used per tile */
 SL_API int sl_vahadane_fit(const uint8_t* rgb, int n, int h, int w, const SlParams* params,
                     double* M_out, double* maxC_out, int32_t* status, int32_t* sweeps_out,
