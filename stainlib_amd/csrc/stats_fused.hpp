@@ -1,0 +1,657 @@
+// stats_fused.hpp -- the merged finish steps (fused_finish1/2), their per-phase kernels k_finish1m/2m, and the persistent k_fused.
+// Part of stats_kernels.hpp (split by phase in round 4, no functional change); include that umbrella, not this file.
+#pragma once
+#include "stats_phase_kernels.hpp"
+
+namespace sl {
+
+// ------------------------------------------------------------------------------------------
+// fused persistent schedule: one workgroup = one tile at a time, all phases
+// ------------------------------------------------------------------------------------------
+struct FusedArgs {
+    const uint8_t* rgb;
+    uint8_t* out;            // transform only
+    int n_tiles;
+    int P;
+    int stride_log2;
+    int n_sample;
+    float ylimf;
+    double lam;
+    double pct;
+    const double* M_tgt;     // transform only
+    const double* maxC_tgt;  // transform only
+    int cap_raw, cap_list;
+    uint32_t* raw;           // [gridDim.x][cap_raw]
+    float* cand;             // [gridDim.x][2][cap_list]
+    uint32_t* sample;        // [gridDim.x][n_sample]
+    double* M_out;           // [n_tiles][6]
+    double* maxC_out;        // [n_tiles][2]
+    int32_t* status_out;     // [n_tiles]
+    int32_t* diag_out;       // [n_tiles] fallbacks (may be NULL)
+    int32_t* resweep_out;    // [n_tiles] 1 when the tile needed the separate concentration sweep (may be NULL)
+#ifdef SL_DEVTOOLS
+    long long* phase_clock;  // [n_tiles][8] wall_clock64() at phase boundaries (development build only, may be NULL)
+    int debug_stop;          // development build only: leave the tile after phase marker debug_stop-1 (0 = run everything)
+#endif
+    // Vahadane
+    double dl_lambda;
+    double dl_tol;
+    int dl_max_sweeps;
+    int32_t* sweeps_out;     // [n_tiles] (may be NULL)
+};
+
+template <int NT>
+struct FusedShared {
+    RowTab tab;              // 64 KB, first member: LDS offset 0
+    uint32_t stage[NT / 64][kStageWave];     // 1 KB per wave
+    unsigned int n_raw, overflow;
+    SelScratch S;
+    double red[NT / 64][32];
+    double sum[32];
+    DictIter it;
+    double Vd[6];
+    double M[6];
+    double maxC[2];
+    float Vf[6];
+    float lo[2], hi[2];
+    float box[4];            // where the merged sweep assumes the two percentile angles (angle_brackets)
+    float res[4];
+    LassoK L;
+    int status;
+    int conc_done;           // the merged sweep's candidates settled maxC: sweep 3 is skipped
+    float xmin;              // tissue_x_bound of the tile (merged sweep)
+    int why;                 // why the merged sweep's concentration candidates were not used (SL_RESWEEP_*; 0 = they were)
+    MergedConc mk;
+};
+
+// wave-uniform values arrive in VGPRs at an out-of-line function: back to SGPRs
+template <class T>
+__device__ __forceinline__ T* uni_ptr(T* p) {
+    const unsigned long long v = (unsigned long long)(uintptr_t)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return (T*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double uni_d(double x) {
+    const unsigned long long v = (unsigned long long)__double_as_longlong(x);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// Finish 1 of the merged schedule after the eigenvectors: brackets and thresholds into sh.lo / sh.hi / sh.mk.
+template <int NT>
+__device__ __noinline__ void fused_finish1(FusedShared<NT>* shp, uint32_t* samp_, int n_sample_, int stride_log2_, int P_, float ylimf_, double pct_, double lam_,
+                                           long long* subclk_) {
+    FusedShared<NT>& sh = *shp;
+    uint32_t* samp = uni_ptr(samp_);
+    const int n_sample = __builtin_amdgcn_readfirstlane(n_sample_), stride_log2 = __builtin_amdgcn_readfirstlane(stride_log2_), P = __builtin_amdgcn_readfirstlane(P_);
+    const float ylimf = uni(ylimf_);
+    const double pct = uni_d(pct_), lam = uni_d(lam_);
+    long long* subclk = uni_ptr(subclk_);
+    const int tid = threadIdx.x;
+#ifdef SL_DEBUG_SUBCLK
+#define SL_SUB(j) { __syncthreads(); if (subclk && tid == 0) subclk[(j)] = wall_clock64(); }
+#else
+#define SL_SUB(j)
+#endif
+    (void)subclk;
+    {
+        SampleAngleKey key;
+        key.sample = samp; key.tab = view_of_b(sh.tab); key.cps_log2 = stride_log2 - 2; key.P = P; key.ylimf = ylimf;
+        for (int i = 0; i < 6; ++i) key.V[i] = sh.Vf[i];
+        float lo[2], hi[2];
+        float box[4];
+        angle_brackets<NT>(key, n_sample, pct, lo, hi, sh.S, box);
+        if (tid == 0) {
+            sh.lo[0] = lo[0]; sh.hi[0] = hi[0]; sh.lo[1] = lo[1]; sh.hi[1] = hi[1];
+            for (int i = 0; i < 4; ++i) sh.box[i] = box[i];
+            sh.xmin = tissue_x_bound(sh.Vf, ylimf, view_of_b(sh.tab));
+            sh.S.misc[32] = 0;
+        }
+        __syncthreads();
+        // The projection bound makes the sweep collect NON-tissue pixels too when they pass it and lie outside the cone.  On most
+        // tiles those are few; a uniform bright-but-not-white background (say 245, 245, 245: not tissue, first projection above the
+        // bound, direction outside the stains' cone) would put most of the tile on the candidate list and cost it the exact
+        // fallback (measured: 21 ms per 512 such tiles).  The sample says beforehand: if the pixels the bound would add exceed
+        // P/40, this tile's sweep keeps the per-pixel tissue test.
+        const float xm = sh.xmin;
+        if (xm > -INFINITY && xm < INFINITY) {                    // block-uniform
+            const float hi0 = sh.hi[0], lo1 = sh.lo[1];
+            uint32_t extra = 0;
+            for (int b = tid; b < n_sample; b += NT) {
+                if (!key.present(b, n_sample)) continue;
+                const uint32_t w = samp[b];
+                const uint32_t r = w & 255u, g = (w >> 8) & 255u, bl = (w >> 16) & 255u;
+                const bool tissue = is_tissue_f(key.tab.gam(r), key.tab.gam(g), key.tab.gam(bl), ylimf);
+                const float ox = key.tab.odf(r), oy = key.tab.odf(g), oz = key.tab.odf(bl);
+                const float x = fmaf(key.V[4], oz, fmaf(key.V[2], oy, key.V[0] * ox));
+                const float p = angle_key(key.V, ox, oy, oz);
+                extra += (!tissue && x > xm && !(p > hi0 && p < lo1)) ? 1u : 0u;
+            }
+            for (int o = 32; o > 0; o >>= 1) extra += __shfl_xor((int)extra, o, 64);
+            if ((tid & 63) == 0 && extra) atomicAdd(&sh.S.misc[32], extra);
+            __syncthreads();
+            if (tid == 0 && ((unsigned long long)sh.S.misc[32] << stride_log2) > (unsigned long long)P / 40ull) sh.xmin = -INFINITY;
+            __syncthreads();
+        }
+    }
+    SL_SUB(12);
+    // ---------------- the box of stain matrices the sample leaves possible, concentration brackets under its centre
+    if (tid < 64) merged_box(sh.Vd, sh.box, lam, tid, sh.mk);
+    __syncthreads();
+    SL_SUB(13);
+    if (sh.mk.ok) {                                               // block-uniform
+        SampleConcKey ckey;
+        ckey.sample = samp; ckey.tab = view_of_b(sh.tab); ckey.L = sh.mk.Lc; ckey.cps_log2 = stride_log2 - 2;
+        ckey.P = P; ckey.col = 0;
+        float lo[2], hi[2];
+        conc_brackets<NT>(ckey, n_sample, lo, hi, sh.S);
+        if (tid == 0) merged_thresholds(sh.mk, lo[0], lo[1], hi[0], hi[1]);
+    } else if (tid == 0) {
+        merged_thresholds(sh.mk, -INFINITY, -INFINITY, -INFINITY, -INFINITY);       // disarms the concentration test
+    }
+    __syncthreads();
+#undef SL_SUB
+}
+
+// Finish 2 of the merged schedule for the tile whose state sits in *shp: returns the number of slow exact fallbacks.
+// Leaves sh.M, sh.status, sh.conc_done (and sh.maxC, sh.L when conc_done) behind and the row table rebuilt.
+template <int NT>
+__device__ __noinline__ int fused_finish2(FusedShared<NT>* shp, const uint8_t* src_, uint32_t* rawl_, float* cand0_, float* cand1_, int P_, int cap_raw_,
+                                          int cap_list_, float ylimf_, double pct_, double lam_, long long* subclk_) {
+    FusedShared<NT>& sh = *shp;
+    const uint8_t* src = uni_ptr(src_);
+    uint32_t* rawl = uni_ptr(rawl_);
+    float* cand0 = uni_ptr(cand0_);
+    float* cand1 = uni_ptr(cand1_);
+    const int P = __builtin_amdgcn_readfirstlane(P_), cap_raw = __builtin_amdgcn_readfirstlane(cap_raw_), cap_list = __builtin_amdgcn_readfirstlane(cap_list_);
+    const float ylimf = uni(ylimf_);
+    const double pct = uni_d(pct_), lam = uni_d(lam_);
+    long long* subclk = uni_ptr(subclk_);
+    const int tid = threadIdx.x, wave = tid >> 6;
+    int fallbacks = 0;
+#ifdef SL_DEBUG_SUBCLK
+#define SL_SUB(j) { __syncthreads(); if (subclk && tid == 0) subclk[(j)] = wall_clock64(); }
+#else
+#define SL_SUB(j)
+#endif
+    (void)subclk;
+    // ---------------- finish 2: exact angular percentiles -> M  (see "Finish 2 of the fused kernel" above wg_refine_s)
+    const uint32_t T = (uint32_t)sh.sum[0];
+    long long k[2];
+    double gfrac[2];
+    percentile_pos((double)T, 100.0 - pct, k[0], gfrac[0]);
+    percentile_pos((double)T, pct, k[1], gfrac[1]);
+    fin_tab_build(sh.tab);                                        // the row table's space: one-copy table + member staging
+    const FinTab FT{lds_address(&sh.tab)};
+    const uint32_t stage_lds = lds_address(&sh.tab) + kFinTabBytes + (uint32_t)wave * fin_stage_bytes(NT);
+    const uint32_t stage_entries = fin_stage_bytes(NT) / 8u;      // two lists per wave
+    AngleTileKey tkey;
+    tkey.src = src; tkey.tab = FT.view(); tkey.ylimf = ylimf;
+    WordAngleKey rkey;
+    rkey.T = FT; rkey.ylimf = ylimf;
+    for (int i = 0; i < 6; ++i) { tkey.V[i] = sh.Vf[i]; rkey.V[i] = sh.Vf[i]; }
+    const bool complete = sh.n_raw <= (uint32_t)cap_raw && sh.overflow == 0;
+    const uint32_t n_raw = sh.n_raw < (uint32_t)cap_raw ? sh.n_raw : (uint32_t)cap_raw;
+    const float los[2] = {sh.lo[0], sh.lo[1]}, his[2] = {sh.hi[0], sh.hi[1]};
+    SL_SUB(2);
+    const RefineOut ra = wg_refine_s(rawl, (int)n_raw, rkey, los[0], his[0], los[1], his[1], cand0, cand1, (uint32_t)cap_list, stage_lds,
+                                     stage_entries, sh.S);
+    SL_SUB(3);
+    {
+        // plain = tissue pixels the sweep did not collect: they sit between the two brackets (the list also holds
+        // pixels collected for their concentrations; those with an angle key count like any other candidate)
+        const long long lt[2] = {(long long)ra.n_lt[0], (long long)T - (long long)ra.n_valid + (long long)ra.n_lt[1]};
+        float res[4];
+        stage_pick2<false>(cand0, cand1, ra.n_in, (uint32_t)cap_list, complete, los, his, lt, P, tkey, T, k, ra.ps, res, fallbacks, sh.S);
+        if (tid == 0) { sh.res[0] = res[0]; sh.res[1] = res[1]; sh.res[2] = res[2]; sh.res[3] = res[3]; }
+        __syncthreads();
+    }
+    SL_SUB(5);
+    if (tid < 64) {
+        double M[6];
+        stain_matrix_from_angles(sh.Vd, sh.res, gfrac, M, tid);
+        if (tid == 0) {
+            for (int i = 0; i < 6; ++i) sh.M[i] = M[i];
+            if (stain_matrix_singular(M)) sh.status = SL_TILE_DEGENERATE_COV;
+            // the concentration candidates of the merged sweep are usable iff the exact M lies where the sweep assumed
+            const bool use = sh.status == SL_TILE_OK && complete && merged_verify(sh.mk, M, lam);
+            sh.conc_done = use ? 1 : 0;
+            sh.why = use ? 0 : (!sh.mk.ok ? SL_RESWEEP_NO_BOX : (!complete ? SL_RESWEEP_LIST_FULL : SL_RESWEEP_OUTSIDE_BOX));
+            if (use) { LassoK L; lasso_consts(M, lam, L); sh.L = L; }
+        }
+    }
+    __syncthreads();
+    SL_SUB(6);
+    if (sh.conc_done) {                                           // block-uniform
+        // ---------------- finish 2b: exact 99th percentiles of the concentrations from the same raw list
+        long long kc;
+        double gc;
+        percentile_pos((double)P, 99.0, kc, gc);
+        const long long kc2 = kc + 1 < (long long)P ? kc + 1 : kc;
+        WordConcKey ckey2;
+        ckey2.T = FT; ckey2.L = sh.L;
+        const float cl[2] = {sh.mk.L[0], sh.mk.L[1]}, chh[2] = {sh.mk.H[0], sh.mk.H[1]};
+        const RefineOut rc = wg_refine_s(rawl, (int)n_raw, ckey2, cl[0], chh[0], cl[1], chh[1], cand0, cand1, (uint32_t)cap_list,
+                                         stage_lds, stage_entries, sh.S);
+        SL_SUB(14);
+#ifdef SL_DEBUG_SUBCLK
+        if (subclk && tid == 0) {             // list sizes beside the clocks, x 100: the tools scale by 0.01 (slots 8..11 are clocks only on the resweep path)
+            long long* q = subclk;
+            q[8] = 100ll * ra.n_valid; q[9] = 100ll * n_raw; q[10] = 100ll * (ra.n_in[0] + ra.n_in[1]); q[11] = 100ll * (rc.n_in[0] + rc.n_in[1]);
+        }
+#endif
+        const long long n_plain = (long long)P - (long long)sh.n_raw;       // proven below both brackets
+        const long long clt[2] = {n_plain + rc.n_lt[0], n_plain + rc.n_lt[1]};
+        bool covered = true;
+#pragma unroll
+        for (int col = 0; col < 2; ++col)
+            covered = covered & (kc >= clt[col]) & (kc2 < clt[col] + (long long)rc.n_in[col]) & (rc.n_in[col] <= (uint32_t)cap_list);
+        if (covered) {
+            ConcTileKey ctk;
+            ctk.src = src; ctk.tab = FT.view(); ctk.L = sh.L; ctk.col = 0;
+            const long long kk[2] = {kc, kc};
+            float res[4];
+            stage_pick2<true>(cand0, cand1, rc.n_in, (uint32_t)cap_list, true, cl, chh, clt, P, ctk, (uint32_t)P, kk, rc.ps, res, fallbacks, sh.S);
+            if (tid == 0) {
+                sh.maxC[0] = np_lerp((double)res[0], (double)res[1], gc);   // normalizer.py:36,47
+                sh.maxC[1] = np_lerp((double)res[2], (double)res[3], gc);
+                if (!(sh.maxC[0] > 0.0) || !(sh.maxC[1] > 0.0)) sh.status = SL_TILE_ZERO_MAXC;
+            }
+        } else if (tid == 0) {
+            sh.conc_done = 0;                                     // a bracket missed (or holds more members than a list): sweep 3 settles it
+            sh.why = (rc.n_in[0] > (uint32_t)cap_list || rc.n_in[1] > (uint32_t)cap_list) ? SL_RESWEEP_LIST_FULL : SL_RESWEEP_BRACKET_MISSED;
+        }
+        __syncthreads();
+        SL_SUB(15);
+    }
+    fin_tab_expand<NT>(sh.tab);                                   // the row table back for the sweeps to come
+    return fallbacks;
+#undef SL_SUB
+}
+
+// ---- the merged schedule, one launch per phase: k_moments -> k_finish1m -> k_select<merged> -> k_finish2m [-> k_select<conc>,
+// k_finish_conc for the rare tile whose exact stain matrix left the assumed box] -> k_apply.  The finish kernels ARE the fused
+// kernel's finish steps (fused_finish1 / fused_finish2) on a FusedShared block of their own, with the tile's state carried in
+// TileState / TileMerged between the launches: both schedules select the same values by construction.
+constexpr int kMFinishThreads = 1024;
+static __global__ __launch_bounds__(kMFinishThreads) void k_finish1m(StatsArgs a) {
+    __shared__ FusedShared<kMFinishThreads> sh;
+    const int tile = blockIdx.x, tid = threadIdx.x;
+    TileState& st = a.state[tile];
+    sh.tab.fill_b();
+    if (tid < 10) {                                   // fixed order => run-to-run identical sums
+        double t = 0;
+        for (int p = 0; p < a.parts; ++p) t += a.partials[((size_t)tile * a.parts + p) * 10 + tid];
+        sh.sum[tid] = t;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double Vd[6];
+        float Vf[6];
+        sh.status = eigvecs_from_moments(sh.sum, Vd, Vf);
+        for (int i = 0; i < 6; ++i) { sh.Vd[i] = Vd[i]; sh.Vf[i] = Vf[i]; }
+        sh.mk.ok = 0;
+        sh.xmin = -INFINITY;
+    }
+    __syncthreads();
+    if (sh.status == SL_TILE_OK)                                               // block-uniform
+        fused_finish1<kMFinishThreads>(&sh, a.sample + (size_t)tile * a.n_sample, a.n_sample, a.stride_log2, a.P, a.ylimf, a.pct, a.lam, nullptr);
+    __syncthreads();
+    if (tid == 0) {
+        st.status = sh.status;
+        st.n_tissue = sh.sum[0];
+        for (int i = 0; i < 6; ++i) { st.Vd[i] = sh.Vd[i]; st.Vf[i] = sh.Vf[i]; }
+        st.lo[0] = sh.lo[0]; st.hi[0] = sh.hi[0]; st.lo[1] = sh.lo[1]; st.hi[1] = sh.hi[1];
+        st.fallbacks = 0;
+        st.n_raw = 0; st.overflow = 0;
+        TileMerged& tm = a.mstate[tile];
+        tm.mk = sh.mk;
+        tm.xmin = sh.xmin;
+        tm.conc_done = 0;
+    }
+}
+
+static __global__ __launch_bounds__(kMFinishThreads) void k_finish2m(StatsArgs a, double* M_out, double* maxC_out, int32_t* status_out,
+                                                                    int32_t* fallbacks_out, int tile0) {
+    __shared__ FusedShared<kMFinishThreads> sh;
+    const int tile = blockIdx.x, tid = threadIdx.x;
+    TileState& st = a.state[tile];
+    TileMerged& tm = a.mstate[tile];
+    const bool bad = st.status != SL_TILE_OK;                                  // block-uniform
+    int fallbacks = 0;
+    if (!bad) {
+        sh.tab.fill_b();
+        if (tid == 0) {
+            sh.status = SL_TILE_OK;
+            sh.sum[0] = st.n_tissue;
+            for (int i = 0; i < 6; ++i) { sh.Vd[i] = st.Vd[i]; sh.Vf[i] = st.Vf[i]; }
+            sh.lo[0] = st.lo[0]; sh.hi[0] = st.hi[0]; sh.lo[1] = st.lo[1]; sh.hi[1] = st.hi[1];
+            sh.n_raw = st.n_raw; sh.overflow = st.overflow;
+            sh.mk = tm.mk;
+            sh.conc_done = 0;
+            sh.maxC[0] = sh.maxC[1] = nan_d();
+        }
+        __syncthreads();
+        fallbacks = fused_finish2<kMFinishThreads>(&sh, a.rgb + (size_t)tile * a.P * 3, a.raw + (size_t)tile * a.cap_raw,
+                                                   a.cand + ((size_t)tile * 2 + 0) * a.cap_list, a.cand + ((size_t)tile * 2 + 1) * a.cap_list, a.P,
+                                                   a.cap_raw, a.cap_list, a.ylimf, a.pct, a.lam, nullptr);
+        __syncthreads();
+        const bool singular = sh.status == SL_TILE_DEGENERATE_COV;             // block-uniform
+        const bool settled = sh.conc_done != 0 || singular;                    // nothing left for the concentration stage to do
+        if (tid == 0) {
+            st.status = sh.status;
+            for (int i = 0; i < 6; ++i) st.M[i] = singular ? nan_d() : sh.M[i];
+            st.maxC[0] = (singular || !sh.conc_done) ? nan_d() : sh.maxC[0];
+            st.maxC[1] = (singular || !sh.conc_done) ? nan_d() : sh.maxC[1];
+            st.fallbacks += fallbacks;
+            st.n_raw = 0; st.overflow = 0;
+            tm.conc_done = settled ? 1 : 0;
+        }
+        if (!settled) {
+            // the exact matrix left the box the sweep assumed (or a bracket missed): brackets for the separate concentration sweep,
+            // as k_finish_angle leaves them
+            if (tid == 0) { LassoK L; lasso_consts(sh.M, a.lam, L); sh.L = L; }
+            __syncthreads();
+            SampleConcKey ckey;
+            ckey.sample = a.sample + (size_t)tile * a.n_sample; ckey.tab = view_of_b(sh.tab); ckey.L = sh.L; ckey.cps_log2 = a.stride_log2 - 2;
+            ckey.P = a.P; ckey.col = 0;
+            float lo[2], hi[2];
+            conc_brackets<kMFinishThreads>(ckey, a.n_sample, lo, hi, sh.S);
+            if (tid == 0) { st.lo[0] = lo[0]; st.hi[0] = hi[0]; st.lo[1] = lo[1]; st.hi[1] = hi[1]; }
+            return;                                                            // k_select<conc> / k_finish_conc take it from here
+        }
+    } else if (tid == 0) {
+        for (int i = 0; i < 6; ++i) st.M[i] = nan_d();
+        st.maxC[0] = st.maxC[1] = nan_d();
+        tm.conc_done = 1;
+    }
+    __syncthreads();
+    if (tid < 6 && M_out) M_out[(size_t)(tile0 + tile) * 6 + tid] = st.M[tid];
+    if (tid < 2 && maxC_out) maxC_out[(size_t)(tile0 + tile) * 2 + tid] = st.maxC[tid];
+    if (tid == 0 && status_out) status_out[tile0 + tile] = st.status;
+    if (tid == 0 && fallbacks_out) fallbacks_out[tile0 + tile] = bad ? 0 : st.fallbacks;
+}
+
+enum { kMethodMacenko = 0, kMethodVahadane = 1 };
+
+// NT = 512: two workgroups per CU (the throughput configuration).  NT = 1024: one workgroup per CU, used when the batch
+// has no more tiles than CUs -- the tile's latency halves (Vahadane below 257 tiles; Macenko runs per phase there).
+template <int METHOD, bool TRANSFORM, bool ALIGNED, int NT>
+static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
+    __shared__ FusedShared<NT> sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const TabReaderB TB = TabReaderB::make(sh.tab);       // the 8-byte {gamma, od32} rows serve every sweep
+    const int nch = (a.P + 3) >> 2;
+    uint32_t* samp = a.sample + (size_t)blockIdx.x * a.n_sample;
+    uint32_t* rawl = a.raw + (size_t)blockIdx.x * a.cap_raw;
+    float* cand0 = a.cand + ((size_t)blockIdx.x * 2 + 0) * a.cap_list;
+    float* cand1 = a.cand + ((size_t)blockIdx.x * 2 + 1) * a.cap_list;
+
+    // sweeps 2/3 share this: classify against sh.lo/hi with constants K; plain count and raw candidates into sh.*
+    const bool stream = (size_t)a.P * 3 >= kStreamBytes;       // non-temporal tile accesses (uniform; see kStreamBytes)
+    auto run_select = [&](auto stage_tag, const uint8_t* src, SelConsts& K) {
+        constexpr int STAGE = decltype(stage_tag)::value;
+        K.lo0 = uni(sh.lo[0]); K.hi0 = uni(sh.hi[0]); K.lo1 = uni(sh.lo[1]); K.hi1 = uni(sh.hi[1]);
+        RawSink sink{(uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(sh.stage[wave])), 0u, rawl, &sh.n_raw, &sh.overflow, (uint32_t)a.cap_raw,
+                     (uint32_t)kStageWave};
+        if (STAGE == kStageMerged && K.xmin > -INFINITY) {       // block-uniform: the projection bound stands in for the tissue test
+            if (stream) select_sweep<kStageMerged, ALIGNED, kFusedTrip, true, true>(src, a.P, 0, nch, tid, NT, TB, a.ylimf, K, sink);
+            else select_sweep<kStageMerged, ALIGNED, kFusedTrip, false, true>(src, a.P, 0, nch, tid, NT, TB, a.ylimf, K, sink);
+        } else {
+            if (stream) select_sweep<STAGE, ALIGNED, kFusedTrip, true>(src, a.P, 0, nch, tid, NT, TB, a.ylimf, K, sink);
+            else select_sweep<STAGE, ALIGNED, kFusedTrip, false>(src, a.P, 0, nch, tid, NT, TB, a.ylimf, K, sink);
+        }
+        sink.flush(lane);
+        __threadfence_block();
+        __syncthreads();
+    };
+
+    // ---- sharing the CU.  Two workgroups live on a CU and the instruction arbiter serves the OLDER one's waves first: left alone,
+    // the first-launched workgroup of every CU runs its sweeps ~20 % faster than its partner, whose latency-bound finish steps
+    // stretch by half (measured: tile latency 1.50 vs 1.83 ms; the launch ends when the slow half does, with the CU
+    // half empty for the last 0.3 ms).  s_setprio overrides age: the finish steps (few instructions, long dependent
+    // latencies) always run at top priority, and the sweeps' priorities alternate between the two workgroups by sweep.
+    uint32_t lds_alloc_;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_LDS_ALLOC)" : "=s"(lds_alloc_));
+    const bool younger = (lds_alloc_ & 0xffu) != 0u;          // the workgroup that got the upper half of the CU's LDS was launched second
+#ifndef SL_PRIO_SCHEME
+#define SL_PRIO_SCHEME 0
+#endif
+    auto prio_finish = [&]() { if (SL_PRIO_SCHEME >= 1) __builtin_amdgcn_s_setprio(3); };
+    auto prio_sweep = [&](int which) {              // which: 0 moments, 1 select, 2 conc resweep / dictionary, 3 apply
+        if (SL_PRIO_SCHEME == 1) __builtin_amdgcn_s_setprio(0);
+        if (SL_PRIO_SCHEME == 2) {
+            if (younger) __builtin_amdgcn_s_setprio(1);
+            else if (which & 1) __builtin_amdgcn_s_setprio(2);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+        if (SL_PRIO_SCHEME == 3) {
+            if (younger) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        }
+    };
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const size_t nbytes = (size_t)a.P * 3;
+#ifdef SL_DEBUG_SAMETILE
+        const uint8_t* src = a.rgb + (size_t)(tile & SL_DEBUG_SAMETILE) * nbytes;   // development aid: cache-resident input (0: one tile, 7: eight)
+#else
+        const uint8_t* src = a.rgb + (size_t)tile * nbytes;
+#endif
+        int fallbacks = 0;
+        int sweeps_used = 0;
+#ifdef SL_DEVTOOLS
+// (Macenko only: in k_fused<vahadane, transform, unaligned> the extra `continue` edges run into the hipcc bug described in the Makefile)
+#define SL_PHASE(i) { if (METHOD == kMethodMacenko) { if (a.phase_clock && tid == 0) a.phase_clock[(size_t)tile * 8 + (i)] = wall_clock64(); if (a.debug_stop == (i) + 1) { __syncthreads(); continue; } } }
+#else
+#define SL_PHASE(i)
+#endif
+#ifdef SL_DEBUG_SUBCLK
+#define SL_SUB(j) { __syncthreads(); if (a.phase_clock && tid == 0) a.phase_clock[(size_t)a.n_tiles * 8 + (size_t)tile * 16 + (j)] = wall_clock64(); }
+#else
+#define SL_SUB(j)
+#endif
+        SL_PHASE(0);
+        if (tile == (int)blockIdx.x) sh.tab.fill_b();       // the row table: written once, before the workgroup's first tile
+        __syncthreads();
+
+        if (METHOD == kMethodMacenko) {
+            // ---------------- sweep 1: moments + sample
+            prio_sweep(0);
+            {
+                Moments mo;
+                uint32_t n_tissue = 0;
+                if (stream) moments_sweep_b<ALIGNED, kFusedTrip, true>(src, a.P, 0, nch, tid, NT, TB, a.ylimf, a.stride_log2, samp, mo, n_tissue);
+                else moments_sweep_b<ALIGNED, kFusedTrip, false>(src, a.P, 0, nch, tid, NT, TB, a.ylimf, a.stride_log2, samp, mo, n_tissue);
+                double v[10];
+                mo.to_array(v, n_tissue, lane);
+#pragma unroll
+                for (int i = 0; i < 10; ++i) v[i] = wave_sum(v[i]);
+                if (lane == 0)
+                    for (int i = 0; i < 10; ++i) sh.red[wave][i] = v[i];
+            }
+            prio_finish();
+            __syncthreads();
+            if (tid < 10) {
+                double t = 0;
+                for (int w = 0; w < NT / 64; ++w) t += sh.red[w][tid];
+                sh.sum[tid] = t;
+            }
+            __syncthreads();
+            SL_PHASE(1);
+            // ---------------- finish 1: eigenvectors, angle brackets
+            SL_SUB(0);
+            if (tid == 0) {
+                double Vd[6];
+                float Vf[6];
+                sh.status = eigvecs_from_moments(sh.sum, Vd, Vf);
+                for (int i = 0; i < 6; ++i) { sh.Vd[i] = Vd[i]; sh.Vf[i] = Vf[i]; }
+                sh.n_raw = 0; sh.overflow = 0;
+                sh.conc_done = 0;
+            }
+            __syncthreads();
+            SL_SUB(1);
+            if (sh.status == SL_TILE_OK) {                                    // block-uniform
+                // ---------------- finish 1, the rest of it (out of line like finish 2): angle brackets, the box of stain matrices the
+                // sample leaves possible, concentration brackets under its centre
+                fused_finish1<NT>(&sh, samp, a.n_sample, a.stride_log2, a.P, a.ylimf, a.pct, a.lam,
+#ifdef SL_DEBUG_SUBCLK
+                                  a.phase_clock ? a.phase_clock + (size_t)a.n_tiles * 8 + (size_t)tile * 16 : nullptr
+#else
+                                  nullptr
+#endif
+                                  );
+                SL_PHASE(2);
+                // ---------------- sweep 2: angle select + concentration select under the box
+                {
+                    SelConsts K;
+                    for (int i = 0; i < 6; ++i) K.V[i] = in_vgpr(sh.Vf[i]);
+                    K.L.g12 = 0.0f;
+                    K.xmin = uni(sh.xmin);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        K.u[i][0] = in_vgpr(sh.mk.u[i][0]); K.u[i][1] = in_vgpr(sh.mk.u[i][1]); K.kt[i] = in_vgpr(sh.mk.kt[i]);
+                        K.eps[i] = in_vgpr(sh.mk.eps[i]); K.thr[i] = in_vgpr(sh.mk.thr[i]);
+                    }
+                    prio_sweep(1);
+                    run_select(std::integral_constant<int, kStageMerged>{}, src, K);
+                    prio_finish();
+                }
+                SL_PHASE(3);
+                // ---------------- finish 2 (out of line: its registers are allocated apart from the sweeps'): exact angular percentiles
+                // -> M, then the concentration percentiles -> maxC from the same raw list
+                fallbacks += fused_finish2<NT>(&sh, src, rawl, cand0, cand1, a.P, a.cap_raw, a.cap_list, a.ylimf, a.pct, a.lam,
+#ifdef SL_DEBUG_SUBCLK
+                                               a.phase_clock ? a.phase_clock + (size_t)a.n_tiles * 8 + (size_t)tile * 16 : nullptr
+#else
+                                               nullptr
+#endif
+                                               );
+            }
+        } else {
+            // ---------------- Vahadane: class-moment dictionary learning
+            prio_sweep(0);
+            gather_sample<ALIGNED>(src, a.P, a.stride_log2, samp, a.n_sample, tid, NT);
+            if (tid == 0) {
+                dict_iter_init(sh.it);
+                sh.n_raw = 0; sh.overflow = 0;
+                sh.conc_done = 0;
+            }
+            __syncthreads();
+            DictProgress pr{1, 0, 0, 0};
+            if (stream) dict_learn<ALIGNED, NT, false, true>(src, a.P, nch, tid, TB, a.ylimf, a.stride_log2, samp, a.n_sample, a.dl_lambda,
+                                                             a.dl_tol, a.dl_max_sweeps, sh.it, sh.red, sh.sum, pr);
+            else dict_learn<ALIGNED, NT, false, false>(src, a.P, nch, tid, TB, a.ylimf, a.stride_log2, samp, a.n_sample, a.dl_lambda,
+                                                       a.dl_tol, a.dl_max_sweeps, sh.it, sh.red, sh.sum, pr);
+            sweeps_used = pr.sweeps_used;
+            if (tid == 0) {
+                sh.status = sh.it.status;
+                if (sh.status == SL_TILE_OK) {
+                    dict_iter_stain_matrix(sh.it, sh.M);
+                    if (stain_matrix_singular(sh.M)) sh.status = SL_TILE_DEGENERATE_COV;
+                }
+            }
+        }
+        __syncthreads();
+        const bool bad = sh.status != SL_TILE_OK;                               // block-uniform
+        const bool resweep = !bad && !sh.conc_done;                             // block-uniform: sweep 3 of the four-sweep schedule
+        if (resweep) {
+            if (tid == 0) {
+                LassoK L;
+                lasso_consts(sh.M, a.lam, L);
+                sh.L = L;
+                sh.n_raw = 0; sh.overflow = 0;
+            }
+            __syncthreads();
+            SL_SUB(7);
+            // ---------------- concentration brackets from the sample
+            {
+                SampleConcKey ckey;
+                ckey.sample = samp; ckey.tab = view_of_b(sh.tab); ckey.L = sh.L; ckey.cps_log2 = a.stride_log2 - 2;
+                ckey.P = a.P; ckey.col = 0;
+                float lo[2], hi[2];
+                conc_brackets<NT>(ckey, a.n_sample, lo, hi, sh.S);
+                if (tid == 0) { sh.lo[0] = lo[0]; sh.hi[0] = hi[0]; sh.lo[1] = lo[1]; sh.hi[1] = hi[1]; }
+                __syncthreads();
+            }
+            SL_PHASE(4);
+            // ---------------- sweep 3: concentration select
+            {
+                SelConsts K;
+                K.L = sh.L;
+                K.xmin = -INFINITY;
+                vgpr(K.L);
+                prio_sweep(2);
+                run_select(std::integral_constant<int, kStageConc>{}, src, K);
+                prio_finish();
+            }
+            SL_PHASE(5);
+            // ---------------- finish 3: exact 99th percentiles -> maxC
+            {
+                long long k;
+                double gfrac;
+                percentile_pos((double)a.P, 99.0, k, gfrac);
+                ConcTileKey tkey;
+                tkey.src = src; tkey.tab = view_of_b(sh.tab); tkey.L = sh.L;
+                RawConcKey2 rkey;
+                rkey.raw = rawl; rkey.tab = view_of_b(sh.tab); rkey.L = sh.L;
+                const bool complete = sh.n_raw <= (uint32_t)a.cap_raw && sh.overflow == 0;
+                const uint32_t n_raw = sh.n_raw < (uint32_t)a.cap_raw ? sh.n_raw : (uint32_t)a.cap_raw;
+                const float los[2] = {sh.lo[0], sh.lo[1]}, his[2] = {sh.hi[0], sh.hi[1]};
+                const long long n_plain = (long long)a.P - (long long)sh.n_raw;        // plain = pixels not collected
+                uint32_t n_lt[2], n_in[2];
+                SL_SUB(8);
+                wg_refine((int)n_raw, rkey, los, his, cand0, cand1, (uint32_t)a.cap_list, n_lt, n_in, sh.S);
+                SL_SUB(9);
+                for (int col = 0; col < 2; ++col) {
+                    tkey.col = col;
+                    float xa, xb;
+                    stage_order_stats(col ? cand1 : cand0, n_in[col], (uint32_t)a.cap_list, complete, los[col], his[col], n_plain + n_lt[col], a.P,
+                                      tkey, (uint32_t)a.P, k, xa, xb, fallbacks, sh.S);
+                    if (tid == 0) { sh.res[2 * col] = xa; sh.res[2 * col + 1] = xb; }
+                    __syncthreads();
+                    SL_SUB(10 + col);
+                }
+                if (tid == 0) {
+                    sh.maxC[0] = np_lerp((double)sh.res[0], (double)sh.res[1], gfrac);   // normalizer.py:36,47
+                    sh.maxC[1] = np_lerp((double)sh.res[2], (double)sh.res[3], gfrac);
+                    if (!(sh.maxC[0] > 0.0) || !(sh.maxC[1] > 0.0)) sh.status = SL_TILE_ZERO_MAXC;
+                }
+                __syncthreads();
+            }
+        } else if (bad && sh.status != SL_TILE_ZERO_MAXC && tid == 0) {     // (a zero maxC keeps its M and maxC, as after finish 3)
+            for (int i = 0; i < 6; ++i) sh.M[i] = nan_d();
+            sh.maxC[0] = sh.maxC[1] = nan_d();
+        }
+        __syncthreads();
+        if (tid == 0 && a.resweep_out) a.resweep_out[tile] = (METHOD == kMethodMacenko && resweep) ? (sh.why ? sh.why : SL_RESWEEP_NO_BOX) : 0;
+        if (tid < 6 && a.M_out) a.M_out[(size_t)tile * 6 + tid] = sh.M[tid];
+        if (tid < 2 && a.maxC_out) a.maxC_out[(size_t)tile * 2 + tid] = sh.maxC[tid];
+        if (tid == 0 && a.status_out) a.status_out[tile] = sh.status;
+        if (tid == 0 && a.diag_out) a.diag_out[tile] = fallbacks;
+        if (tid == 0 && a.sweeps_out) a.sweeps_out[tile] = sweeps_used;
+        SL_PHASE(6);
+        // ---------------- sweep 4: apply
+        if (TRANSFORM) {
+            uint8_t* dst = a.out + (size_t)tile * nbytes;
+            if (sh.status != SL_TILE_OK) {       // block-uniform (sh.status is final: barrier above); includes a zero maxC found in finish 3
+                for (int c = tid; c < nch; c += NT) store_chunk<ALIGNED>(dst, nbytes, c, load_chunk<ALIGNED>(src, nbytes, c));
+            } else {
+                ApplyK K;
+                apply_consts(sh.M, sh.maxC, a.M_tgt, a.maxC_tgt, a.lam, K);
+                prio_sweep(3);
+                if (stream) {
+                    if (K.fast) apply_sweep<ALIGNED, true, TabReaderB, true>(src, dst, a.P, 0, nch, tid, NT, TB, K);
+                    else apply_sweep<ALIGNED, false, TabReaderB, true>(src, dst, a.P, 0, nch, tid, NT, TB, K);
+                } else {
+                    if (K.fast) apply_sweep<ALIGNED, true, TabReaderB, false>(src, dst, a.P, 0, nch, tid, NT, TB, K);
+                    else apply_sweep<ALIGNED, false, TabReaderB, false>(src, dst, a.P, 0, nch, tid, NT, TB, K);
+                }
+            }
+        }
+        __syncthreads();     // sh.* is reused by the next tile
+        SL_PHASE(7);
+#undef SL_PHASE
+#undef SL_SUB
+    }
+}
+
+}  // namespace sl
