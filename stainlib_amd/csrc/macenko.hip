@@ -3,6 +3,8 @@
 // One-launch-per-phase schedule (batches below kFusedMinTiles): tiles are processed in groups of up to 2 GiB of
 // uint8 (bounds the workspace); per group 3 sweeps + 3 one-workgroup-per-tile finish kernels (+ the apply sweep
 // for transform), all on the caller's stream, no host sync.  Larger batches run the persistent fused kernel.
+#include <cassert>
+
 #include "stats_kernels.hpp"
 #include "sl_host.hpp"
 
@@ -70,6 +72,7 @@ Layout make_layout(int n, long P, int method = kMethodMacenko, int schedule = 0,
     L.stride_log2 = method == kMethodVahadane ? 6 : 4;
     while (((P + (1L << L.stride_log2) - 1) >> L.stride_log2) > kMaxSample) ++L.stride_log2;
     L.n_sample = (int)((P + (1L << L.stride_log2) - 1) >> L.stride_log2);
+    assert(L.stride_log2 >= 4 && L.n_sample <= kMaxSample);     // sample_row / sample_pixel: cps_log2 = stride_log2 - 2 >= 2
     long g = (long)(kGroupBytes / (size_t)(3 * P));
     const long min_g = (1024 + L.parts - 1) / L.parts;      // keep >= ~1024 workgroups per sweep launch
     if (g < min_g) g = min_g;

@@ -585,8 +585,20 @@ __global__ __launch_bounds__(1024) void k_pool_resolve(double* st, const unsigne
         __syncthreads();
     }
     __syncthreads();
+    // The apply pass is enqueued behind this chain before the host has looked at the state: whenever the state is unusable at the
+    // END of the chain (a window missed a rank in either stage, an empty tissue mask, a degenerate covariance) the concentration
+    // stage leaves NaN in (M, maxC), which k_apply treats like any tile with unusable statistics -- it passes the tiles through
+    // unchanged instead of writing exp(NaN) bytes (round-3 advisor finding).
+    auto poison = [&]() {
+        const double nan = nan_d();
+        for (int i = 0; i < 6; ++i) st[kPoolM + i] = nan;
+        st[kPoolMaxC] = st[kPoolMaxC + 1] = nan;
+    };
     if (s_miss) {
-        if (tid == 0) st[kPoolMiss] = (double)((int)st[kPoolMiss] | (keyset == SL_KEYSET_ANGLE ? 1 : 2));
+        if (tid == 0) {
+            st[kPoolMiss] = (double)((int)st[kPoolMiss] | (keyset == SL_KEYSET_ANGLE ? 1 : 2));
+            if (keyset != SL_KEYSET_ANGLE) poison();
+        }
         return;
     }
     if (tid < 4) st[kPoolRes + tid] = (double)s_res[tid];
@@ -611,6 +623,7 @@ __global__ __launch_bounds__(1024) void k_pool_resolve(double* st, const unsigne
         }
     } else if (tid == 0) {
         for (int t = 0; t < 2; ++t) st[kPoolMaxC + t] = np_lerp((double)s_res[2 * t], (double)s_res[2 * t + 1], st[kPoolG + t]);
+        if ((int)st[kPoolMiss] != 0 || (int)st[kPoolStatus] != SL_TILE_OK) poison();      // (an angle-stage miss, an empty mask, ...)
         (void)lam;
     }
 }

@@ -53,7 +53,7 @@ struct StatsArgs {
     int P;
     int parts;               // parts per tile (multi-kernel schedule)
     int n_items;             // tiles x parts of this group: the work list of the persistent sweep kernels
-    int stride_log2;         // sampling stride = 1 << stride_log2 (>= 6)
+    int stride_log2;         // sampling stride = 1 << stride_log2 (>= 4: Macenko tiles below 1 Mpixel; 6 from 1 Mpixel on and for Vahadane)
     int n_sample;            // ceil(P / stride)
     float ylimf;             // tissue test threshold: y_lim - 2048 (see is_tissue_f)
     double lam;
@@ -107,7 +107,10 @@ struct SmallTab {
 };
 __device__ __forceinline__ TabView view_of(const SmallTab& t) { return TabView{lds_address(&t), 4u, 0u, 1024u}; }
 
-// ---- stratified sample: one pixel per block of 2^stride_log2 pixels (2^cps_log2 chunks, cps_log2 >= 4) ----
+// ---- stratified sample: one pixel per block of 2^stride_log2 pixels (2^cps_log2 chunks, cps_log2 >= 2, i.e. stride_log2 >= 4;
+// make_layout asserts it) ----
+// With cps_log2 < 6 a 64-chunk wave row holds several blocks (16 at cps_log2 = 2) that all share ONE draw -- the same chunk offset
+// and pixel choice in each: the sample is still one pixel per block, only less randomised within a row than at cps_log2 >= 6.
 // Which pixel is decided per HASH GROUP = the 64 chunks one wave covers with one load (or the whole block when
 // it is larger): every lane of a wave row then shares the draw, so the sweep computes it on the scalar unit and
 // pays one compare per chunk.  The draw picks a chunk of the block and pixel 0 or 3 of that chunk (the two a

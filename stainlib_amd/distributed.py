@@ -213,7 +213,7 @@ class PooledSlideStatistics:
         self.thr, self.pct, self.lam = luminosity_threshold, angular_percentile, lasso_lambda
         self.last_path = []          # per stage of the last call: "window" (one sweep) or "radix" (the fallback rounds)
 
-    def enqueue(self, tiles_local: torch.Tensor, ws=None) -> torch.Tensor:
+    def enqueue(self, tiles_local: torch.Tensor, ws=None, n_tiles_total: Optional[int] = None) -> torch.Tensor:
         """DEVICE-DRIVEN: enqueue the whole computation (4 full sweeps, 6 sampled passes, the all-reduces between them and the
         single-workgroup decision steps) on the current stream and return the pool state tensor (device float64,
         _ffi.POOL_STATE_DOUBLES) WITHOUT reading anything back: state[POOL_M:POOL_M+6] / state[POOL_MAXC:+2] are the slide's stain
@@ -231,8 +231,19 @@ class PooledSlideStatistics:
         if _coll(world, self.group):
             dist.all_reduce(mom, group=self.group)
         state = engine.pool_begin(mom, params=params)
-        # the sample: ~4 M pixels of the slide or more (shards differ by at most one tile: every rank derives the same density)
-        n_pixels = world * n_local * h * w
+        # the sample: ~4 M pixels of the slide or more.  The density must be the SAME on every rank (the sampled histograms are
+        # all-reduced), so it is derived from a rank-independent tile count: the caller's n_tiles_total, else the largest shard
+        # (shard_range gives ceil(n / world) to some rank) agreed on with one tiny MAX all-reduce -- NOT from this rank's own
+        # n_local, which differs by one tile across ranks on uneven shards and can sit on the other side of a power of two
+        # (3 vs 4 tiles of 1024^2 on two ranks; round-3 advisor finding).  Results never depended on it, the window hit rate did.
+        if n_tiles_total is not None:
+            n_pixels = int(n_tiles_total) * h * w
+        elif _coll(world, self.group) and world > 1:
+            nl = torch.tensor([n_local], dtype=torch.int64, device=dev if dist.get_backend(self.group) == "nccl" else "cpu")
+            dist.all_reduce(nl, op=dist.ReduceOp.MAX, group=self.group)
+            n_pixels = world * int(nl.item()) * h * w
+        else:
+            n_pixels = world * n_local * h * w
         slog = min(6, max(0, int(math.floor(math.log2(max(n_pixels, 1) / 4.0e6))))) if n_pixels > 4.0e6 else 0
         hists = torch.zeros((2, 3, 2, 256), dtype=torch.int64, device=dev)
         wins = torch.zeros((2, 2 * 65536 + 2), dtype=torch.int64, device=dev)
@@ -346,8 +357,10 @@ class SlideNormalizer:
         self.group = group
         self.mode = mode
 
-    def transform_shard(self, tiles_local: torch.Tensor, out: Optional[torch.Tensor] = None):
-        """tiles_local: this rank's (n_local,H,W,3) uint8 device tensor.  Returns (out, M_slide, maxC_slide, status_local)."""
+    def transform_shard(self, tiles_local: torch.Tensor, out: Optional[torch.Tensor] = None, n_tiles_total: Optional[int] = None):
+        """tiles_local: this rank's (n_local,H,W,3) uint8 device tensor.  Returns (out, M_slide, maxC_slide, status_local).
+        n_tiles_total (pooled mode, optional): the slide's tile count over all ranks; saves the one tiny all-reduce that otherwise
+        agrees on the sample density.  On failure (TissueMaskException) `out` holds a copy of the input tiles."""
         from . import engine
         if self.mode == "pooled":
             from . import _ffi
@@ -355,8 +368,12 @@ class SlideNormalizer:
             dev = tiles_local.device
             n = tiles_local.shape[0]
             # device-driven: the statistics AND the apply pass are enqueued before anything is read back; the one read-back
-            # afterwards only confirms that both windows caught their ranks (else: the host-driven rounds, and the pass again)
-            state = stats.enqueue(tiles_local)
+            # afterwards only confirms that both windows caught their ranks (else: the host-driven rounds, and the pass again).
+            # When the chain ends in an unusable state (a window miss, an empty tissue mask, a degenerate covariance) its last step
+            # leaves NaN in (M, maxC) and the enqueued apply pass COPIES the tiles through (k_apply's rule for unusable statistics):
+            # `out` then holds the input, never exp(NaN) bytes, until the host-driven rounds below rewrite it -- or, on an empty
+            # mask, when TissueMaskException leaves this function.
+            state = stats.enqueue(tiles_local, n_tiles_total=n_tiles_total)
             M_s = state[_ffi.POOL_M:_ffi.POOL_M + 6].reshape(2, 3)
             maxC_s = state[_ffi.POOL_MAXC:_ffi.POOL_MAXC + 2]
             Mt, mct = self.normalizer.stain_matrix_target, self.normalizer.maxC_target.reshape(2)

@@ -418,6 +418,9 @@ def _install_numpy_engine(force_radix=False):
             k1 = min(k + 1, N - 1)
             if not (N >= 1 and below <= k and k1 < below + int(histo.sum())):
                 state[_ffi.POOL_MISS] = float(int(state[_ffi.POOL_MISS]) | (1 if keyset == _ffi.KEYSET_ANGLE else 2))
+                if keyset != _ffi.KEYSET_ANGLE:                  # like k_pool_resolve: an unusable state ends with NaN in (M, maxC)
+                    state[_ffi.POOL_M:_ffi.POOL_M + 6] = float("nan")
+                    state[_ffi.POOL_MAXC:_ffi.POOL_MAXC + 2] = float("nan")
                 return
             cum = np.cumsum(histo)
             lo = int(state[K_WLO + t])
@@ -442,6 +445,9 @@ def _install_numpy_engine(force_radix=False):
         else:
             for t in range(2):
                 state[_ffi.POOL_MAXC + t] = sd.np_lerp(res[2 * t], res[2 * t + 1], float(state[K_G + t]))
+            if int(state[_ffi.POOL_MISS]) != 0 or int(state[_ffi.POOL_STATUS]) != 0:
+                state[_ffi.POOL_M:_ffi.POOL_M + 6] = float("nan")
+                state[_ffi.POOL_MAXC:_ffi.POOL_MAXC + 2] = float("nan")
 
     engine.pool_begin, engine.pool_histogram, engine.pool_pick = pool_begin, pool_histogram, pool_pick
     engine.pool_window, engine.pool_resolve = pool_window, pool_resolve
@@ -556,3 +562,48 @@ def test_device_driven_pooled_statistics_on_two_gloo_ranks():
         np.testing.assert_allclose(M, M_ref, rtol=0, atol=2e-6)
         np.testing.assert_allclose(maxC, c_ref, rtol=2e-6)
         assert np.array_equal(M_s, M) and np.array_equal(mc_s, maxC)
+
+
+def _density_worker(rank, world, port, q, pass_total):
+    """Uneven shards (3 + 4 tiles of 1024^2 on two ranks): what sample density does each rank hand to the sampled histogram passes?"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from stainlib_amd import _ffi, engine
+    seen = []
+    engine.make_params = lambda **kw: None
+    engine.tile_moments = lambda tiles, params=None, ws=None: torch.zeros((tiles.shape[0], 10), dtype=torch.float64)
+    engine.pool_begin = lambda mom, state=None, params=None: torch.zeros((_ffi.POOL_STATE_DOUBLES,), dtype=torch.float64)
+
+    def pool_histogram(tiles, keyset, state, rnd, slog, hist_out, params=None):
+        seen.append(int(slog))
+        return hist_out
+    engine.pool_histogram = pool_histogram
+    engine.pool_pick = lambda state, keyset, rnd, h: None
+    engine.pool_window = lambda tiles, keyset, state, buf, params=None: buf
+    engine.pool_resolve = lambda state, keyset, win, params=None: None
+    lo, hi = sd.shard_range(7, rank, world)
+    mine = torch.empty((hi - lo, 1024, 1024, 3), dtype=torch.uint8)
+    sd.PooledSlideStatistics().enqueue(mine, n_tiles_total=7 if pass_total else None)
+    q.put((rank, hi - lo, seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("pass_total", [False, True])
+def test_uneven_shards_agree_on_the_sample_density(pass_total):
+    """Round-3 advisor finding: the density was derived from each rank's OWN tile count; with 3 + 4 tiles of 1024^2 on two ranks
+    (2 x 4 Mpx = 8.4 Mpx -> every other row; 2 x 3 Mpx = 6.3 Mpx -> every row) the all-reduced sample histograms mixed densities."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_density_worker, args=(r, 2, port, q, pass_total)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[1] for r in res) == [3, 4]
+    assert res[0][2] == res[1][2] and len(res[0][2]) == 6 and len(set(res[0][2])) == 1
+    assert res[0][2][0] == (0 if pass_total else 1)          # 7 Mpx -> every row; agreed-on 2 x 4 Mpx -> every other row

@@ -1,6 +1,9 @@
 """-m gpu: Vahadane (sparse-NMF) path.  The reference's spams.trainDL call is wall-clock budgeted and
 randomly initialised, so parity is defined against the CONVERGED optimum of the same objective (oracle:
-full-batch block-coordinate descent, run to 1e-12).  Tolerance on unit-norm rows: 1e-5."""
+full-batch block-coordinate descent, run to 1e-12).  SURVEY 8c allows 1e-5 on the unit-norm rows; the tests hold the kernel to
+what it promises and delivers (round-3 review, item 5): the iteration's own stopping tolerance, 1e-7 by default (measured: 3e-9 to
+7e-8; test_vahadane_error_stays_within_the_tolerance checks the promise "error <= 0.7 dl_tol" over five tolerances), and the north
+star's 1e-4 of the bytes."""
 import numpy as np
 import pytest
 import torch
@@ -9,7 +12,7 @@ from oracle import stain_oracle as so
 from tests.gpu_util import to_dev, u8_parity
 
 pytestmark = pytest.mark.gpu
-V_ATOL = 1e-5
+V_ATOL = 1e-7
 
 
 def _oracle_fit(I):
@@ -62,7 +65,7 @@ def test_vahadane_default_tolerance_and_transform():
     Cs = so.get_concentrations(I, Ms) * (on.maxC_target / mcs)
     want = so.truncate_u8(255 * np.exp(-Cs @ Mo)).reshape(I.shape)
     d = np.abs(out.astype(np.int16) - want.astype(np.int16))
-    assert d.max() <= 1 and (d != 0).mean() < 5e-3          # dictionary agrees to ~1e-6: a few bytes flip by one level
+    assert d.max() <= 1 and (d != 0).sum() <= max(4, 1e-4 * d.size)   # the dictionary agrees to < 1e-7: a few bytes flip by one level
     M1 = sl.VahadaneStainExtractor.get_stain_matrix(I)
     np.testing.assert_allclose(M1, Ms, rtol=0, atol=V_ATOL)
     # batch: failed tile passes through, others unaffected; sweeps reported
@@ -109,9 +112,9 @@ def test_vahadane_1024_tiles_fit_and_transform():
             flips = int((d != 0).sum())
             print(f"vahadane 1024^2 schedule {sched} tile {i}: {flips} of {d.size} bytes differ ({flips / d.size:.2e}); "
                   f"|dM| {np.abs(M[i].cpu().numpy() - fits[i][0]).max():.1e}")
-            # the dictionary agrees with the oracle's to ~1e-6 (its own stopping tolerance), which moves every pixel:
-            # the byte bound is the dictionary tolerance times the density of values near an integer
-            assert d.max() <= 1 and flips <= 2e-3 * d.size
+            # the dictionary agrees with the oracle's to < 1e-7 (its own stopping tolerance), which moves every pixel a little:
+            # measured 10-30 of 3.1 M bytes; the bar is the north star's 1e-4
+            assert d.max() <= 1 and flips <= 1e-4 * d.size
         outs.append(out)
     assert (outs[0] != outs[1]).float().mean().item() < 1e-4
 
@@ -187,7 +190,7 @@ def test_vahadane_error_stays_within_the_tolerance():
 def test_vahadane_on_spatially_smooth_tiles():
     """Nuclei, slow eosin gradients, a lumen, little noise (oracle.structured_tile 'blobs'): neighbouring pixels are strongly
     correlated, so the stratified sample the iteration starts from is a poorer stand-in than on i.i.d. tiles.  The result
-    must not care: converged oracle within 1e-5, both schedules, and the Macenko path takes no exact fallback on them."""
+    must not care: converged oracle within 1e-7, both schedules, and the Macenko path takes no exact fallback on them."""
     from stainlib_amd import engine
     tiles = [so.structured_tile("blobs", 256, 320, s) for s in (5, 6, 7)]
     fits = [_oracle_fit(I) for I in tiles]
