@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SL_VERSION 300 /* 0.3.0: SlParams grew (fused_min_tiles), sl_pool_* added, resweeps_out carries reasons */
+#define SL_VERSION 400 /* 0.4.0: SlParams.reserved_ became prefilter, SlParams grew (prefilter_out); 0.3.0: fused_min_tiles, sl_pool_*, resweeps_out carries reasons */
 
 /* The library is built with -fvisibility=hidden: exactly the functions declared here are exported. */
 #if defined(__GNUC__)
@@ -134,7 +134,14 @@ typedef struct SlParams {
                                    kernel's resident grid (2 x compute units) is split: whole fused rounds, and a remainder below this
                                    number of tiles one launch per phase (default: 416 / 224 / 192 tiles by the same tile sizes, never for
                                    tiles up to 64 Ki pixels).  Results do not depend on the schedule. */
-    int32_t reserved_;          /* 0 */
+    int32_t prefilter;          /* the colour-cube pre-filter of the fused Macenko kernel's selection sweep (a 32^3-cell mask of colours that are
+                                   provably "plain", built per tile by finish 1; pixels of the other cells are re-tested exactly):
+                                   0 (default) = per tile, wherever the tile's pixel sample says it pays; 1 = never (the per-pixel sweep);
+                                   2 = wherever the mask can be built, whatever the sample says (tests).  Results do not depend on it. */
+    int32_t* prefilter_out;     /* NULL (default) or DEVICE pointer to n ints: bit 0 set for a tile whose selection sweep ran behind the mask,
+                                   bits 8.. the share (percent) of the tile's sample pixels that fell into cells the mask could not
+                                   prove plain (0 when no mask was built; diagnostics).  Written by the fused schedule of sl_macenko_*;
+                                   left untouched otherwise. */
 } SlParams;
 
 SL_API int sl_version(void);

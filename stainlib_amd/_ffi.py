@@ -44,7 +44,8 @@ class SlParams(C.Structure):
         ("fallbacks_out", C.c_void_p),
         ("resweeps_out", C.c_void_p),
         ("fused_min_tiles", C.c_int32),
-        ("reserved_", C.c_int32),
+        ("prefilter", C.c_int32),
+        ("prefilter_out", C.c_void_p),
     ]
 
 

@@ -251,6 +251,8 @@ int run_fused(int method, const uint8_t* rgb, uint8_t* out, int n, long P, const
     a.dl_tol = p.dl_tol;
     a.dl_max_sweeps = p.dl_max_sweeps > 0 ? p.dl_max_sweeps : 1;
     a.sweeps_out = sweeps_out;
+    a.use_cube = p.prefilter == 1 ? 0 : (p.prefilter == 2 ? 2 : 1);
+    a.cube_out = p.prefilter_out;
     const bool al = aligned4(rgb, P) && (!out || aligned4(out, P));
     const dim3 g((unsigned)L.grid), b(kFusedThreads);
     ProfScope ps(p.profile, out ? SL_PROF_FUSED_TRANSFORM : SL_PROF_FUSED_FIT, n, s);

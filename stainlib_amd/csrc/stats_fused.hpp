@@ -2,6 +2,7 @@
 // Part of stats_kernels.hpp (split by phase in round 4, no functional change); include that umbrella, not this file.
 #pragma once
 #include "stats_phase_kernels.hpp"
+#include "stats_cube.hpp"
 
 namespace sl {
 
@@ -38,14 +39,17 @@ struct FusedArgs {
     double dl_tol;
     int dl_max_sweeps;
     int32_t* sweeps_out;     // [n_tiles] (may be NULL)
+    int use_cube;            // Macenko: let finish 1 build the colour-cube mask for sweep 2 (stats_cube.hpp); 0 = always the per-pixel sweep
+    int32_t* cube_out;       // [n_tiles] 1 where sweep 2 ran behind the cube mask (diagnostics, may be NULL)
 };
 
 template <int NT>
 struct FusedShared {
     RowTab tab;              // 64 KB, first member: LDS offset 0
     uint32_t stage[NT / 64][kStageWave];     // 1 KB per wave
+    SelScratch S;            // 4 KB aligned (LDS offset 72 KB): between the finish steps S.hist holds the colour-cube mask, whose base the
+                             // cube sweep ORs into its addresses
     unsigned int n_raw, overflow;
-    SelScratch S;
     double red[NT / 64][32];
     double sum[32];
     DictIter it;
@@ -61,6 +65,7 @@ struct FusedShared {
     int conc_done;           // the merged sweep's candidates settled maxC: sweep 3 is skipped
     float xmin;              // tissue_x_bound of the tile (merged sweep)
     int why;                 // why the merged sweep's concentration candidates were not used (SL_RESWEEP_*; 0 = they were)
+    int use_cube;            // finish 1 built the colour-cube mask (in S.hist) and the sample says it pays: sweep 2 = select_sweep_cube
     MergedConc mk;
 };
 
@@ -80,10 +85,11 @@ __device__ __forceinline__ double uni_d(double x) {
 // Finish 1 of the merged schedule after the eigenvectors: brackets and thresholds into sh.lo / sh.hi / sh.mk.
 template <int NT>
 __device__ __noinline__ void fused_finish1(FusedShared<NT>* shp, uint32_t* samp_, int n_sample_, int stride_log2_, int P_, float ylimf_, double pct_, double lam_,
-                                           long long* subclk_) {
+                                           long long* subclk_, int want_cube_) {
     FusedShared<NT>& sh = *shp;
     uint32_t* samp = uni_ptr(samp_);
     const int n_sample = __builtin_amdgcn_readfirstlane(n_sample_), stride_log2 = __builtin_amdgcn_readfirstlane(stride_log2_), P = __builtin_amdgcn_readfirstlane(P_);
+    const int want_cube = __builtin_amdgcn_readfirstlane(want_cube_);
     const float ylimf = uni(ylimf_);
     const double pct = uni_d(pct_), lam = uni_d(lam_);
     long long* subclk = uni_ptr(subclk_);
@@ -94,10 +100,10 @@ __device__ __noinline__ void fused_finish1(FusedShared<NT>* shp, uint32_t* samp_
 #define SL_SUB(j)
 #endif
     (void)subclk;
+    SampleAngleKey key;
+    key.sample = samp; key.tab = view_of_b(sh.tab); key.cps_log2 = stride_log2 - 2; key.P = P; key.ylimf = ylimf;
+    for (int i = 0; i < 6; ++i) key.V[i] = sh.Vf[i];
     {
-        SampleAngleKey key;
-        key.sample = samp; key.tab = view_of_b(sh.tab); key.cps_log2 = stride_log2 - 2; key.P = P; key.ylimf = ylimf;
-        for (int i = 0; i < 6; ++i) key.V[i] = sh.Vf[i];
         float lo[2], hi[2];
         float box[4];
         angle_brackets<NT>(key, n_sample, pct, lo, hi, sh.S, box);
@@ -105,34 +111,9 @@ __device__ __noinline__ void fused_finish1(FusedShared<NT>* shp, uint32_t* samp_
             sh.lo[0] = lo[0]; sh.hi[0] = hi[0]; sh.lo[1] = lo[1]; sh.hi[1] = hi[1];
             for (int i = 0; i < 4; ++i) sh.box[i] = box[i];
             sh.xmin = tissue_x_bound(sh.Vf, ylimf, view_of_b(sh.tab));
-            sh.S.misc[32] = 0;
+            sh.use_cube = 0;
         }
         __syncthreads();
-        // The projection bound makes the sweep collect NON-tissue pixels too when they pass it and lie outside the cone.  On most
-        // tiles those are few; a uniform bright-but-not-white background (say 245, 245, 245: not tissue, first projection above the
-        // bound, direction outside the stains' cone) would put most of the tile on the candidate list and cost it the exact
-        // fallback (measured: 21 ms per 512 such tiles).  The sample says beforehand: if the pixels the bound would add exceed
-        // P/40, this tile's sweep keeps the per-pixel tissue test.
-        const float xm = sh.xmin;
-        if (xm > -INFINITY && xm < INFINITY) {                    // block-uniform
-            const float hi0 = sh.hi[0], lo1 = sh.lo[1];
-            uint32_t extra = 0;
-            for (int b = tid; b < n_sample; b += NT) {
-                if (!key.present(b, n_sample)) continue;
-                const uint32_t w = samp[b];
-                const uint32_t r = w & 255u, g = (w >> 8) & 255u, bl = (w >> 16) & 255u;
-                const bool tissue = is_tissue_f(key.tab.gam(r), key.tab.gam(g), key.tab.gam(bl), ylimf);
-                const float ox = key.tab.odf(r), oy = key.tab.odf(g), oz = key.tab.odf(bl);
-                const float x = fmaf(key.V[4], oz, fmaf(key.V[2], oy, key.V[0] * ox));
-                const float p = angle_key(key.V, ox, oy, oz);
-                extra += (!tissue && x > xm && !(p > hi0 && p < lo1)) ? 1u : 0u;
-            }
-            for (int o = 32; o > 0; o >>= 1) extra += __shfl_xor((int)extra, o, 64);
-            if ((tid & 63) == 0 && extra) atomicAdd(&sh.S.misc[32], extra);
-            __syncthreads();
-            if (tid == 0 && ((unsigned long long)sh.S.misc[32] << stride_log2) > (unsigned long long)P / 40ull) sh.xmin = -INFINITY;
-            __syncthreads();
-        }
     }
     SL_SUB(12);
     // ---------------- the box of stain matrices the sample leaves possible, concentration brackets under its centre
@@ -150,7 +131,183 @@ __device__ __noinline__ void fused_finish1(FusedShared<NT>* shp, uint32_t* samp_
         merged_thresholds(sh.mk, -INFINITY, -INFINITY, -INFINITY, -INFINITY);       // disarms the concentration test
     }
     __syncthreads();
+    SL_SUB(4);
+    // ---------------- the colour-cube mask of the merged sweep (stats_cube.hpp): per-channel tables in the sweeps' staging space,
+    // the mask where the finish steps' histogram lives (neither is in use between finish 1 and finish 2)
+    const float hi0 = sh.hi[0], lo1 = sh.lo[1];
+    if (want_cube && hi0 > -INFINITY && hi0 < INFINITY && lo1 > -INFINITY && lo1 < INFINITY) {       // block-uniform
+        float* ctab = reinterpret_cast<float*>(&sh.stage[0][0]);
+        static_assert(sizeof(sh.stage) >= sizeof(float) * kCubeTabFloats && sizeof(sh.S.hist) >= 4 * kCubeWords, "");
+        const CubeConsts cc = cube_tables(key.tab, sh.Vf, hi0, lo1, sh.mk, ctab, tid);
+        __syncthreads();
+        cube_mask<NT>(ctab, cc, ylimf, sh.S.hist, tid);
+        __syncthreads();
+        int share_pct;
+        const bool pays = cube_worthwhile<NT>(samp, n_sample, stride_log2 - 2, P, sh.S.hist, &sh.S.misc[33], tid, share_pct);
+        if (tid == 0) sh.use_cube = ((pays || want_cube == 2) ? 1 : 0) | (share_pct << 8);       // (the share rides along for prefilter_out)
+        __syncthreads();
+    }
+    SL_SUB(7);      // (slot 7 is otherwise written on the resweep path only)
+    // ---------------- the per-pixel sweep: does the projection bound stand in for its tissue test?
+    // The bound makes the sweep collect NON-tissue pixels too when they pass it and lie outside the cone.  On most
+    // tiles those are few; a uniform bright-but-not-white background (say 245, 245, 245: not tissue, first projection above the
+    // bound, direction outside the stains' cone) would put most of the tile on the candidate list and cost it the exact
+    // fallback (measured: 21 ms per 512 such tiles).  The sample says beforehand: if the pixels the bound would add exceed
+    // P/40, this tile's sweep keeps the per-pixel tissue test.  (Not needed behind the cube mask, which tests the tissue bound
+    // of a cell exactly.)
+    const float xm = sh.xmin;
+    if (!(sh.use_cube & 1) && xm > -INFINITY && xm < INFINITY) {  // block-uniform
+        if (tid == 0) sh.S.misc[32] = 0;
+        __syncthreads();
+        uint32_t extra = 0;
+        for (int b = tid; b < n_sample; b += NT) {
+            if (!key.present(b, n_sample)) continue;
+            const uint32_t w = samp[b];
+            const uint32_t r = w & 255u, g = (w >> 8) & 255u, bl = (w >> 16) & 255u;
+            const bool tissue = is_tissue_f(key.tab.gam(r), key.tab.gam(g), key.tab.gam(bl), ylimf);
+            const float ox = key.tab.odf(r), oy = key.tab.odf(g), oz = key.tab.odf(bl);
+            const float x = fmaf(key.V[4], oz, fmaf(key.V[2], oy, key.V[0] * ox));
+            const float p = angle_key(key.V, ox, oy, oz);
+            extra += (!tissue && x > xm && !(p > hi0 && p < lo1)) ? 1u : 0u;
+        }
+        for (int o = 32; o > 0; o >>= 1) extra += __shfl_xor((int)extra, o, 64);
+        if ((tid & 63) == 0 && extra) atomicAdd(&sh.S.misc[32], extra);
+        __syncthreads();
+        if (tid == 0 && ((unsigned long long)sh.S.misc[32] << stride_log2) > (unsigned long long)P / 40ull) sh.xmin = -INFINITY;
+        __syncthreads();
+    }
 #undef SL_SUB
+}
+
+// ---- The sweeps of the fused kernel, each OUT OF LINE (round 4) like the finish steps since round 3: every one of them gets
+// the kernel's whole register budget to itself.  Inlined side by side in the 128-register kernel, a change to one sweep (or to a
+// finish step) moved spills and copies into the loops of the others -- the same source measured 1.70 or 1.83 ms depending on
+// what else the kernel held.  Uniform arguments arrive in VGPRs and are re-read into SGPRs; per-tile constants come from *shp.
+
+#ifdef SL_EXP_INLINE_SWEEPS
+#define SL_SWEEP_ATTR __forceinline__
+#else
+#define SL_SWEEP_ATTR __noinline__
+#endif
+// Sweep 1: tissue test, moments, sample; leaves the ten wave sums in sh.red (the caller adds them up after a barrier).
+template <int NT, bool ALIGNED>
+__device__ SL_SWEEP_ATTR void fused_sweep1(FusedShared<NT>* shp, const uint8_t* src_, uint32_t* samp_, int P_, float ylimf_, int stride_log2_, int stream_) {
+    FusedShared<NT>& sh = *shp;
+    const uint8_t* src = uni_ptr(src_);
+    uint32_t* samp = uni_ptr(samp_);
+    const int P = __builtin_amdgcn_readfirstlane(P_), stride_log2 = __builtin_amdgcn_readfirstlane(stride_log2_), stream = __builtin_amdgcn_readfirstlane(stream_);
+    const float ylimf = uni(ylimf_);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const TabReaderB TB = TabReaderB::make(sh.tab);
+    const int nch = (P + 3) >> 2;
+    Moments mo;
+    uint32_t n_tissue = 0;
+    if (stream) moments_sweep_b<ALIGNED, kFusedTrip, true>(src, P, 0, nch, tid, NT, TB, ylimf, stride_log2, samp, mo, n_tissue);
+    else moments_sweep_b<ALIGNED, kFusedTrip, false>(src, P, 0, nch, tid, NT, TB, ylimf, stride_log2, samp, mo, n_tissue);
+    double v[10];
+    mo.to_array(v, n_tissue, lane);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) v[i] = wave_sum(v[i]);
+    if (lane == 0)
+        for (int i = 0; i < 10; ++i) sh.red[wave][i] = v[i];
+}
+
+// Sweeps 2 (merged stage, per-pixel test) and 3 (concentration stage): classify against sh.lo / sh.hi, raw candidates to the tile's
+// list through the wave's staging in sh.stage.  merged: constants from sh.Vf / sh.mk / sh.xmin; otherwise from sh.L.
+template <int NT, bool ALIGNED>
+__device__ SL_SWEEP_ATTR void fused_select(FusedShared<NT>* shp, const uint8_t* src_, uint32_t* rawl_, int P_, int cap_raw_, float ylimf_, int stream_, int merged_) {
+    FusedShared<NT>& sh = *shp;
+    const uint8_t* src = uni_ptr(src_);
+    uint32_t* rawl = uni_ptr(rawl_);
+    const int P = __builtin_amdgcn_readfirstlane(P_), cap_raw = __builtin_amdgcn_readfirstlane(cap_raw_), stream = __builtin_amdgcn_readfirstlane(stream_);
+    const int merged = __builtin_amdgcn_readfirstlane(merged_);
+    const float ylimf = uni(ylimf_);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const TabReaderB TB = TabReaderB::make(sh.tab);
+    const int nch = (P + 3) >> 2;
+    SelConsts K;
+    K.lo0 = uni(sh.lo[0]); K.hi0 = uni(sh.hi[0]); K.lo1 = uni(sh.lo[1]); K.hi1 = uni(sh.hi[1]);
+    RawSinkFinish sink{(uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(sh.stage[wave])), 0u, rawl, &sh.n_raw, &sh.overflow, (uint32_t)cap_raw,
+                       (uint32_t)kStageWave};     // (the burst inlined: this function has registers to spare, see RawSinkT)
+    if (merged) {
+        for (int i = 0; i < 6; ++i) K.V[i] = in_vgpr(sh.Vf[i]);
+        K.L.g12 = 0.0f;
+        K.xmin = uni(sh.xmin);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            K.u[i][0] = in_vgpr(sh.mk.u[i][0]); K.u[i][1] = in_vgpr(sh.mk.u[i][1]); K.kt[i] = in_vgpr(sh.mk.kt[i]);
+            K.eps[i] = in_vgpr(sh.mk.eps[i]); K.thr[i] = in_vgpr(sh.mk.thr[i]);
+        }
+        if (K.xmin > -INFINITY) {                                // block-uniform: the projection bound stands in for the tissue test
+            if (stream) select_sweep<kStageMerged, ALIGNED, kFusedTrip, true, true>(src, P, 0, nch, tid, NT, TB, ylimf, K, sink);
+            else select_sweep<kStageMerged, ALIGNED, kFusedTrip, false, true>(src, P, 0, nch, tid, NT, TB, ylimf, K, sink);
+        } else {
+            if (stream) select_sweep<kStageMerged, ALIGNED, kFusedTrip, true>(src, P, 0, nch, tid, NT, TB, ylimf, K, sink);
+            else select_sweep<kStageMerged, ALIGNED, kFusedTrip, false>(src, P, 0, nch, tid, NT, TB, ylimf, K, sink);
+        }
+    } else {
+        K.L = sh.L;
+        K.xmin = -INFINITY;
+        vgpr(K.L);
+        if (stream) select_sweep<kStageConc, ALIGNED, kFusedTrip, true>(src, P, 0, nch, tid, NT, TB, ylimf, K, sink);
+        else select_sweep<kStageConc, ALIGNED, kFusedTrip, false>(src, P, 0, nch, tid, NT, TB, ylimf, K, sink);
+    }
+    sink.flush(lane);
+}
+
+// Sweep 4: the apply pass with the tile's (sh.M, sh.maxC).
+template <int NT, bool ALIGNED>
+__device__ SL_SWEEP_ATTR void fused_apply(FusedShared<NT>* shp, const uint8_t* src_, uint8_t* dst_, int P_, const double* M_tgt_, const double* maxC_tgt_,
+                                         double lam_, int stream_) {
+    FusedShared<NT>& sh = *shp;
+    const uint8_t* src = uni_ptr(src_);
+    uint8_t* dst = uni_ptr(dst_);
+    const double* M_tgt = uni_ptr(M_tgt_);
+    const double* maxC_tgt = uni_ptr(maxC_tgt_);
+    const int P = __builtin_amdgcn_readfirstlane(P_), stream = __builtin_amdgcn_readfirstlane(stream_);
+    const double lam = uni_d(lam_);
+    const int tid = threadIdx.x;
+    const TabReaderB TB = TabReaderB::make(sh.tab);
+    const int nch = (P + 3) >> 2;
+    ApplyK K;
+    apply_consts(sh.M, sh.maxC, M_tgt, maxC_tgt, lam, K);
+    if (stream) {
+        if (K.fast) apply_sweep<ALIGNED, true, TabReaderB, true>(src, dst, P, 0, nch, tid, NT, TB, K);
+        else apply_sweep<ALIGNED, false, TabReaderB, true>(src, dst, P, 0, nch, tid, NT, TB, K);
+    } else {
+        if (K.fast) apply_sweep<ALIGNED, true, TabReaderB, false>(src, dst, P, 0, nch, tid, NT, TB, K);
+        else apply_sweep<ALIGNED, false, TabReaderB, false>(src, dst, P, 0, nch, tid, NT, TB, K);
+    }
+}
+
+// Sweep 2 behind the colour-cube mask, out of line like the finish steps: its registers are allocated apart from the other sweeps'
+// (the fused kernel sits at its 128-register limit; inlined, this sweep made the others spill).  Constants come from *shp.
+template <int NT, bool ALIGNED>
+__device__ SL_SWEEP_ATTR void fused_sweep2_cube(FusedShared<NT>* shp, const uint8_t* src_, uint32_t* rawl_, int P_, int cap_raw_, float ylimf_, int stream_) {
+    FusedShared<NT>& sh = *shp;
+    const uint8_t* src = uni_ptr(src_);
+    uint32_t* rawl = uni_ptr(rawl_);
+    const int P = __builtin_amdgcn_readfirstlane(P_), cap_raw = __builtin_amdgcn_readfirstlane(cap_raw_), stream = __builtin_amdgcn_readfirstlane(stream_);
+    const float ylimf = uni(ylimf_);
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const TabReaderB TB = TabReaderB::make(sh.tab);
+    const int nch = (P + 3) >> 2;
+    SelConsts K;
+    for (int i = 0; i < 6; ++i) K.V[i] = in_vgpr(sh.Vf[i]);
+    K.L.g12 = 0.0f;
+    K.xmin = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        K.u[i][0] = in_vgpr(sh.mk.u[i][0]); K.u[i][1] = in_vgpr(sh.mk.u[i][1]); K.kt[i] = in_vgpr(sh.mk.kt[i]);
+        K.eps[i] = in_vgpr(sh.mk.eps[i]); K.thr[i] = in_vgpr(sh.mk.thr[i]);
+    }
+    K.lo0 = uni(sh.lo[0]); K.hi0 = uni(sh.hi[0]); K.lo1 = uni(sh.lo[1]); K.hi1 = uni(sh.hi[1]);
+    const RawDirect direct{rawl, &sh.n_raw, (uint32_t)cap_raw};
+    static_assert(offsetof(FusedShared<NT>, S) % 4096 == 0 && offsetof(SelScratch, hist) == 0, "the cube mask must be 4 KB aligned");
+    const uint32_t bits_lds = lds_address(sh.S.hist);
+    const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(&sh.stage[wave][0]));
+    if (stream) select_sweep_cube<ALIGNED, kFusedTrip, true>(src, P, 0, nch, tid, NT, TB, ylimf, K, bits_lds, ring_lds, direct);
+    else select_sweep_cube<ALIGNED, kFusedTrip, false>(src, P, 0, nch, tid, NT, TB, ylimf, K, bits_lds, ring_lds, direct);
 }
 
 // Finish 2 of the merged schedule for the tile whose state sits in *shp: returns the number of slow exact fallbacks.
@@ -295,7 +452,7 @@ static __global__ __launch_bounds__(kMFinishThreads) void k_finish1m(StatsArgs a
     }
     __syncthreads();
     if (sh.status == SL_TILE_OK)                                               // block-uniform
-        fused_finish1<kMFinishThreads>(&sh, a.sample + (size_t)tile * a.n_sample, a.n_sample, a.stride_log2, a.P, a.ylimf, a.pct, a.lam, nullptr);
+        fused_finish1<kMFinishThreads>(&sh, a.sample + (size_t)tile * a.n_sample, a.n_sample, a.stride_log2, a.P, a.ylimf, a.pct, a.lam, nullptr, 0);
     __syncthreads();
     if (tid == 0) {
         st.status = sh.status;
@@ -379,7 +536,7 @@ enum { kMethodMacenko = 0, kMethodVahadane = 1 };
 template <int METHOD, bool TRANSFORM, bool ALIGNED, int NT>
 static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
     __shared__ FusedShared<NT> sh;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     const TabReaderB TB = TabReaderB::make(sh.tab);       // the 8-byte {gamma, od32} rows serve every sweep
     const int nch = (a.P + 3) >> 2;
     uint32_t* samp = a.sample + (size_t)blockIdx.x * a.n_sample;
@@ -387,21 +544,11 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
     float* cand0 = a.cand + ((size_t)blockIdx.x * 2 + 0) * a.cap_list;
     float* cand1 = a.cand + ((size_t)blockIdx.x * 2 + 1) * a.cap_list;
 
-    // sweeps 2/3 share this: classify against sh.lo/hi with constants K; plain count and raw candidates into sh.*
     const bool stream = (size_t)a.P * 3 >= kStreamBytes;       // non-temporal tile accesses (uniform; see kStreamBytes)
-    auto run_select = [&](auto stage_tag, const uint8_t* src, SelConsts& K) {
-        constexpr int STAGE = decltype(stage_tag)::value;
-        K.lo0 = uni(sh.lo[0]); K.hi0 = uni(sh.hi[0]); K.lo1 = uni(sh.lo[1]); K.hi1 = uni(sh.hi[1]);
-        RawSink sink{(uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(sh.stage[wave])), 0u, rawl, &sh.n_raw, &sh.overflow, (uint32_t)a.cap_raw,
-                     (uint32_t)kStageWave};
-        if (STAGE == kStageMerged && K.xmin > -INFINITY) {       // block-uniform: the projection bound stands in for the tissue test
-            if (stream) select_sweep<kStageMerged, ALIGNED, kFusedTrip, true, true>(src, a.P, 0, nch, tid, NT, TB, a.ylimf, K, sink);
-            else select_sweep<kStageMerged, ALIGNED, kFusedTrip, false, true>(src, a.P, 0, nch, tid, NT, TB, a.ylimf, K, sink);
-        } else {
-            if (stream) select_sweep<STAGE, ALIGNED, kFusedTrip, true>(src, a.P, 0, nch, tid, NT, TB, a.ylimf, K, sink);
-            else select_sweep<STAGE, ALIGNED, kFusedTrip, false>(src, a.P, 0, nch, tid, NT, TB, a.ylimf, K, sink);
-        }
-        sink.flush(lane);
+    // sweeps 2/3: out of line (fused_select / fused_sweep2_cube); plain count and raw candidates into sh.*
+    auto run_select = [&](bool merged, const uint8_t* src) {
+        if (merged && (sh.use_cube & 1)) fused_sweep2_cube<NT, ALIGNED>(&sh, src, rawl, a.P, a.cap_raw, a.ylimf, stream ? 1 : 0);   // block-uniform
+        else fused_select<NT, ALIGNED>(&sh, src, rawl, a.P, a.cap_raw, a.ylimf, stream ? 1 : 0, merged ? 1 : 0);
         __threadfence_block();
         __syncthreads();
     };
@@ -456,18 +603,7 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
         if (METHOD == kMethodMacenko) {
             // ---------------- sweep 1: moments + sample
             prio_sweep(0);
-            {
-                Moments mo;
-                uint32_t n_tissue = 0;
-                if (stream) moments_sweep_b<ALIGNED, kFusedTrip, true>(src, a.P, 0, nch, tid, NT, TB, a.ylimf, a.stride_log2, samp, mo, n_tissue);
-                else moments_sweep_b<ALIGNED, kFusedTrip, false>(src, a.P, 0, nch, tid, NT, TB, a.ylimf, a.stride_log2, samp, mo, n_tissue);
-                double v[10];
-                mo.to_array(v, n_tissue, lane);
-#pragma unroll
-                for (int i = 0; i < 10; ++i) v[i] = wave_sum(v[i]);
-                if (lane == 0)
-                    for (int i = 0; i < 10; ++i) sh.red[wave][i] = v[i];
-            }
+            fused_sweep1<NT, ALIGNED>(&sh, src, samp, a.P, a.ylimf, a.stride_log2, stream ? 1 : 0);
             prio_finish();
             __syncthreads();
             if (tid < 10) {
@@ -486,6 +622,7 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
                 for (int i = 0; i < 6; ++i) { sh.Vd[i] = Vd[i]; sh.Vf[i] = Vf[i]; }
                 sh.n_raw = 0; sh.overflow = 0;
                 sh.conc_done = 0;
+                sh.use_cube = 0;
             }
             __syncthreads();
             SL_SUB(1);
@@ -498,23 +635,12 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
 #else
                                   nullptr
 #endif
-                                  );
+                                  , a.use_cube);
                 SL_PHASE(2);
                 // ---------------- sweep 2: angle select + concentration select under the box
-                {
-                    SelConsts K;
-                    for (int i = 0; i < 6; ++i) K.V[i] = in_vgpr(sh.Vf[i]);
-                    K.L.g12 = 0.0f;
-                    K.xmin = uni(sh.xmin);
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        K.u[i][0] = in_vgpr(sh.mk.u[i][0]); K.u[i][1] = in_vgpr(sh.mk.u[i][1]); K.kt[i] = in_vgpr(sh.mk.kt[i]);
-                        K.eps[i] = in_vgpr(sh.mk.eps[i]); K.thr[i] = in_vgpr(sh.mk.thr[i]);
-                    }
-                    prio_sweep(1);
-                    run_select(std::integral_constant<int, kStageMerged>{}, src, K);
-                    prio_finish();
-                }
+                prio_sweep(1);
+                run_select(true, src);
+                prio_finish();
                 SL_PHASE(3);
                 // ---------------- finish 2 (out of line: its registers are allocated apart from the sweeps'): exact angular percentiles
                 // -> M, then the concentration percentiles -> maxC from the same raw list
@@ -574,15 +700,9 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
             }
             SL_PHASE(4);
             // ---------------- sweep 3: concentration select
-            {
-                SelConsts K;
-                K.L = sh.L;
-                K.xmin = -INFINITY;
-                vgpr(K.L);
-                prio_sweep(2);
-                run_select(std::integral_constant<int, kStageConc>{}, src, K);
-                prio_finish();
-            }
+            prio_sweep(2);
+            run_select(false, src);
+            prio_finish();
             SL_PHASE(5);
             // ---------------- finish 3: exact 99th percentiles -> maxC
             {
@@ -628,6 +748,7 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
         if (tid == 0 && a.status_out) a.status_out[tile] = sh.status;
         if (tid == 0 && a.diag_out) a.diag_out[tile] = fallbacks;
         if (tid == 0 && a.sweeps_out) a.sweeps_out[tile] = sweeps_used;
+        if (METHOD == kMethodMacenko && tid == 0 && a.cube_out) a.cube_out[tile] = (sh.status == SL_TILE_OK || sh.status == SL_TILE_ZERO_MAXC) ? sh.use_cube : 0;
         SL_PHASE(6);
         // ---------------- sweep 4: apply
         if (TRANSFORM) {
@@ -635,16 +756,8 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
             if (sh.status != SL_TILE_OK) {       // block-uniform (sh.status is final: barrier above); includes a zero maxC found in finish 3
                 for (int c = tid; c < nch; c += NT) store_chunk<ALIGNED>(dst, nbytes, c, load_chunk<ALIGNED>(src, nbytes, c));
             } else {
-                ApplyK K;
-                apply_consts(sh.M, sh.maxC, a.M_tgt, a.maxC_tgt, a.lam, K);
                 prio_sweep(3);
-                if (stream) {
-                    if (K.fast) apply_sweep<ALIGNED, true, TabReaderB, true>(src, dst, a.P, 0, nch, tid, NT, TB, K);
-                    else apply_sweep<ALIGNED, false, TabReaderB, true>(src, dst, a.P, 0, nch, tid, NT, TB, K);
-                } else {
-                    if (K.fast) apply_sweep<ALIGNED, true, TabReaderB, false>(src, dst, a.P, 0, nch, tid, NT, TB, K);
-                    else apply_sweep<ALIGNED, false, TabReaderB, false>(src, dst, a.P, 0, nch, tid, NT, TB, K);
-                }
+                fused_apply<NT, ALIGNED>(&sh, src, dst, a.P, a.M_tgt, a.maxC_tgt, a.lam, stream ? 1 : 0);
             }
         }
         __syncthreads();     // sh.* is reused by the next tile

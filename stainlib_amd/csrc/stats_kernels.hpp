@@ -36,6 +36,7 @@
 #include "stats_linalg.hpp"        // eigh, stain matrix, merged box
 #include "stats_sweeps.hpp"        // moments_sweep_b, select_sweep
 #include "stats_finish.hpp"        // refine / census / pick, RawSink, sample brackets
+#include "stats_cube.hpp"          // colour-cube pre-filter of the merged sweep (mask build + sweep)
 #include "stats_dict.hpp"          // Vahadane dictionary
 #include "stats_phase_kernels.hpp" // one launch per phase
 #include "stats_fused.hpp"         // fused_finish1/2, k_finish1m/2m, k_fused

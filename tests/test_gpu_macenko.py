@@ -497,3 +497,83 @@ def test_a_batch_beyond_the_resident_grid_is_split_between_the_schedules():
         good = res[0][3] == 0
         assert float((res[0][1][good] - res[sched][1][good]).abs().max()) < 1e-12
         assert float((res[0][2][good] / res[sched][2][good] - 1).abs().max()) < 1e-12
+
+
+# ---- the colour-cube pre-filter of the fused kernel's selection sweep (round 4; stats_cube.hpp) ----
+def _prefilter_run(dev, Mt, mct, prefilter, **kw):
+    from stainlib_amd import engine
+    n = dev.shape[0]
+    p = engine.make_params(schedule=2, prefilter=prefilter, **kw)
+    fb = engine.attach_fallbacks(p, n, device="cuda")
+    rsw = torch.zeros((n,), dtype=torch.int32, device="cuda")
+    cub = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    p.resweeps_out, p.prefilter_out = rsw.data_ptr(), cub.data_ptr()
+    out, M, mc, st = engine.macenko_transform(dev, Mt, mct, params=p)
+    torch.cuda.synchronize()
+    return out, M, mc, st, fb, rsw, cub
+
+
+@pytest.mark.parametrize("h,w", [(128, 128), (96, 130), (33, 47), (256, 320), (1, 517)])
+def test_prefilter_never_changes_a_result(h, w):
+    """SlParams.prefilter: 1 = the per-pixel selection sweep, 2 = behind the colour-cube mask wherever it can be built, 0 = where the
+    tile's sample says it pays.  Bytes, statistics, status, fallbacks and resweep reasons must be identical in all three (the mask
+    only decides which pixels take the exact test), and equal to the oracle's."""
+    tiles = _fused_batch(h, w, n=24)
+    tiles[9] = so.structured_tile("white_bg", h, w, 5) if h > 1 else tiles[9]
+    tiles[10] = so.structured_tile("blobs", h, w, 6) if h > 1 else tiles[10]
+    tgt = so.synth_tile(128, 128, 1001, so.M_TRUE_TGT)
+    Mt, mct = _fit_oracle(tgt)
+    dev = to_dev(tiles)
+    runs = {pf: _prefilter_run(dev, Mt, mct, pf) for pf in (1, 2, 0)}
+    ref = runs[1]
+    assert (ref[6].cpu().numpy() == 0).all()                                        # prefilter off: no mask anywhere
+    for pf in (2, 0):
+        r = runs[pf]
+        for k in range(6):
+            a, b = ref[k], r[k]
+            assert torch.equal(torch.nan_to_num(a.double(), nan=-7.0), torch.nan_to_num(b.double(), nan=-7.0)), (pf, k)
+    used = runs[2][6].cpu().numpy()
+    st = ref[3].cpu().numpy()
+    assert (used[st == 1] == 0).all()                                               # an empty mask builds nothing
+    if h * w >= 4096:
+        assert (used[st == 0] & 1).sum() >= (st == 0).sum() - 2, used                # forced: every tile with closed brackets
+        share = used[st == 0] >> 8
+        assert (share >= 0).all() and (share <= 100).all()
+    n = so.ExtractiveStainNormalizer("macenko")
+    n.stain_matrix_target, n.maxC_target = Mt, mct.reshape(1, 2)
+    out = runs[2][0].cpu().numpy()
+    for i in (0, 1, 9, 10, 23):
+        if st[i] == 0:
+            u8_parity(out[i], n.transform(tiles[i]), label=f"prefilter forced, tile {i}")
+
+
+def test_prefilter_at_full_size_on_structured_and_real_tissue_tiles():
+    """1024 x 1024: i.i.d., white background, quantised colours, spatially smooth (most of its pixels sit in ambiguous cells: the
+    automatic mode must decline there), the real-tissue fixture mirror-tiled, a uniform grey background, a 12-colour palette."""
+    from stainlib_amd import engine  # noqa: F401
+    ihc = np.load(os.path.join(os.path.dirname(__file__), "golden", "tissue_ihc_512.npz"))["input"]
+    row = np.concatenate([ihc, ihc[:, ::-1]], axis=1)
+    real = np.ascontiguousarray(np.concatenate([row, row[::-1]], axis=0))
+    grey = so.synth_tile(1024, 1024, 40).copy()
+    grey[np.random.RandomState(8).rand(1024, 1024) < 0.6] = 245
+    tiles = [so.synth_tile(1024, 1024, 7), so.structured_tile("white_bg", 1024, 1024, 20), so.structured_tile("quantized", 1024, 1024, 21),
+             so.structured_tile("blobs", 1024, 1024, 22), real, grey, so.structured_tile("palette12", 1024, 1024, 23)]
+    tgt = so.synth_tile(256, 256, 1001, so.M_TRUE_TGT)
+    Mt, mct = _fit_oracle(tgt)
+    dev = to_dev(tiles)
+    runs = {pf: _prefilter_run(dev, Mt, mct, pf) for pf in (1, 2, 0)}
+    for pf in (2, 0):
+        for k in range(6):
+            assert torch.equal(torch.nan_to_num(runs[1][k].double(), nan=-7.0), torch.nan_to_num(runs[pf][k].double(), nan=-7.0)), (pf, k)
+    auto, forced = runs[0][6].cpu().numpy(), runs[2][6].cpu().numpy()
+    print("share of sample pixels in ambiguous cells (%):", (forced >> 8).tolist(), " automatic mode used the mask:", (auto & 1).tolist())
+    assert (forced[:6] & 1).all()
+    assert (auto[[0, 1, 2]] & 1).all() and not (auto[3] & 1)                          # smooth tile: declined
+    assert ((forced >> 8)[[0, 1, 2]] <= 20).all() and (forced >> 8)[3] >= 35
+    st = runs[1][3].cpu().numpy()
+    assert (st == 0).all()
+    n = so.ExtractiveStainNormalizer("macenko")
+    n.stain_matrix_target, n.maxC_target = Mt, mct.reshape(1, 2)
+    out = runs[0][0].cpu().numpy()
+    for i in (0, 4):
+        u8_parity(out[i], n.transform(tiles[i]), label=f"prefilter auto, 1024^2 tile {i}")

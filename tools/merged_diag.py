@@ -3,6 +3,7 @@ percentiles (resweeps = tiles that needed sweep 3), slow exact fallbacks, and --
 (make -C stainlib_amd/csrc dev; STAINLIB_HIP_LIB=.../libstainlib_hip_dev.so) -- per-tile phase times, the sub-steps of both finish
 steps, list sizes and the bracket step timers.    python tools/merged_diag.py [tiles] [size]"""
 import ctypes as C
+import os
 import sys
 
 import numpy as np
@@ -17,7 +18,7 @@ size = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 rgb = synth_tiles(n, size, size, seed=3)
 tgt = synth_tiles(1, size, size, seed=1, M_true=[[0.55, 0.75, 0.35], [0.10, 0.95, 0.20]])
 Mt, mct, st = engine.macenko_fit(tgt)
-p = engine.make_params(schedule=2)
+p = engine.make_params(schedule=2, prefilter=int(os.environ.get("SL_PREFILTER", "0")))      # SL_PREFILTER=1: the per-pixel selection sweep
 fb = engine.attach_fallbacks(p, n)
 rs = torch.full((n,), -1, dtype=torch.int32, device="cuda")
 p.resweeps_out = rs.data_ptr()
@@ -63,7 +64,8 @@ if hasattr(lib, "sl_debug_set_phase_clock"):
         sub = tall[n * 8:].reshape(n, 16)
         ph = t
         steps = [("F1 eig", sub[:, 1] - sub[:, 0]), ("F1 angle brackets", sub[:, 12] - sub[:, 1]), ("F1 box", sub[:, 13] - sub[:, 12]),
-                 ("F1 conc brackets", ph[:, 2] - sub[:, 13]), ("F2 pre", sub[:, 2] - ph[:, 3]), ("F2 refine angle", sub[:, 3] - sub[:, 2]),
+                 ("F1 conc brackets", sub[:, 4] - sub[:, 13]), ("F1 cube mask + share", sub[:, 7] - sub[:, 4]), ("F1 bound guard", ph[:, 2] - sub[:, 7]),
+                 ("F2 pre", sub[:, 2] - ph[:, 3]), ("F2 refine angle", sub[:, 3] - sub[:, 2]),
                  ("F2 pick angle", sub[:, 5] - sub[:, 3]), ("F2 M + verify", sub[:, 6] - sub[:, 5]), ("F2b refine conc", sub[:, 14] - sub[:, 6]),
                  ("F2b pick conc", sub[:, 15] - sub[:, 14]), ("F2b tail -> apply", ph[:, 6] - sub[:, 15])]
         cnt = tall[n * 8:].reshape(n, 16)[:, 8:12]       # slots 8..11: list sizes x 100 written by the kernel (not clocks)
