@@ -372,12 +372,14 @@ def secondary_configs(dev, Mt, mct):
         fb = engine.attach_fallbacks(p, 512, device=dev)
         rsw = torch.zeros((512,), dtype=torch.int32, device=dev)
         p.resweeps_out = rsw.data_ptr()
+        cub = torch.zeros((512,), dtype=torch.int32, device=dev)
+        p.prefilter_out = cub.data_ptr()
         ms = _timed(lambda: engine.macenko_transform(rgb, Mt_d, mct_d, params=p, out=out, ws=wss), reps=5)
         o, Mg, mcg, st = engine.macenko_transform(rgb, Mt_d, mct_d, params=p, out=out, ws=wss)
         on = so.ExtractiveStainNormalizer("macenko")
         on.stain_matrix_target, on.maxC_target = Mt_np, mct_np.reshape(1, 2)
         structured[kind] = {"ms_per_batch": round(ms, 4), "tiles_per_s": round(512 / ms * 1e3, 1), "failed_tiles": int((st != 0).sum()),
-                            "exact_fallbacks": int(fb.sum()), "of": 2048, "resweeps": int((rsw != 0).sum()), "resweep_reasons": {str(k): int((rsw == k).sum()) for k in (1, 2, 3, 4) if int((rsw == k).sum())},
+                            "exact_fallbacks": int(fb.sum()), "of": 2048, "behind_cube_mask": int((cub & 1).sum()), "ambiguous_share_pct": round(float((cub >> 8).float().mean()), 1), "resweeps": int((rsw != 0).sum()), "resweep_reasons": {str(k): int((rsw == k).sum()) for k in (1, 2, 3, 4) if int((rsw == k).sum())},
                             "parity_tile0": _flips(o[0].cpu().numpy(), on.transform(four[0]))}
         del rgb
     structured["note"] = ("oracle.structured_tile: 'blobs' = nuclei, slow eosin gradients, a lumen, little noise (neighbouring pixels strongly "
@@ -700,6 +702,8 @@ def main():
     fallbacks = engine.attach_fallbacks(params, B, device=dev)
     resweeps = torch.zeros((B,), dtype=torch.int32, device=dev)     # tiles whose concentration percentiles needed the separate sweep 3
     params.resweeps_out = resweeps.data_ptr()
+    prefilter = torch.zeros((B,), dtype=torch.int32, device=dev)    # bit 0: the selection sweep ran behind the colour-cube mask; bits 8..: share (%)
+    params.prefilter_out = prefilter.data_ptr()
 
     def step(p):
         return engine.macenko_transform(rgb, Mt, mct, params=p, out=out, ws=ws)
@@ -979,6 +983,10 @@ def main():
             "fallbacks": {"order_statistics_on_the_slow_exact_path": n_fallbacks, "of": 4 * B * world,
                           "tiles_that_needed_the_separate_concentration_sweep": n_resweeps, "of_tiles": B,
                           "note": "i.i.d. synthetic tiles never need it; heavy colour ties (palette images) do -- see tests"},
+            "prefilter": {"tiles_swept_behind_the_colour_cube_mask": int((prefilter & 1).sum()), "of_tiles": B,
+                          "mean_share_of_sample_pixels_in_ambiguous_cells_pct": round(float((prefilter >> 8).float().mean()), 1),
+                          "note": "round 4: finish 1 builds a 32^3-cell mask of provably plain colours per tile; sweep 2 tests one bit per pixel and "
+                                  "re-tests only the pixels of the other cells exactly (SlParams.prefilter; results do not depend on it)"},
             "parity": parity,
             "distributed": {"backend": (dist.get_backend() if dist_on else None), "world_size": (dist.get_world_size() if dist_on else 1),
                             "per_rank_tiles_per_s": [round(x, 1) for x in per_rank], "ranks": ranks, "device_of_rank0": dev_index,

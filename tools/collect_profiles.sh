@@ -1,8 +1,8 @@
 #!/bin/bash
 # Collects every measurement the docs cite into gpurun_out/ (run on the GPU box from the repo root):
-#   make -C tools && /usr/local/graft/bin/gpurun --timeout 1800 -- 'bash tools/collect_profiles.sh r03'
-# then copy gpurun_out/r03_* to profiles/ (tracked); bench.py reads <tag>_pmc_traffic.json from there.
-tag=${1:-r03}
+#   make -C tools && /usr/local/graft/bin/gpurun --timeout 1800 -- 'bash tools/collect_profiles.sh r04'
+# then copy gpurun_out/r04_* to profiles/ (tracked); bench.py reads <tag>_pmc_traffic.json from there.
+tag=${1:-r04}
 cd "$GRAFT_REPO_ROOT" || exit 1
 out=$PWD/gpurun_out
 mkdir -p "$out"
@@ -55,6 +55,7 @@ python tools/make_pmc_traffic.py "$tag" "$out" > "$out/${tag}_pmc_traffic.json" 
 python tools/slide_scale.py 512,2048,12500 2>/dev/null | grep -v amdgpu > "$out/${tag}_slide_scale.txt"
 timeout 200 python tools/power_classes.py 2>/dev/null | grep -v amdgpu > "$out/${tag}_power_classes.txt"
 python tools/structured_rate.py 2>/dev/null | grep -v amdgpu > "$out/${tag}_structured_rate.txt"
+python tools/cube_ab.py iid white_bg quantized ihc grey_bg blobs 2>/dev/null | grep -v amdgpu > "$out/${tag}_cube_prefilter_ab.txt"
 rm -rf /tmp/kl; timeout 300 rocprofv3 --kernel-trace -d /tmp/kl -o p -- python tools/run_lab.py > /dev/null 2>&1
 python tools/rocpd_stats.py "$(ls /tmp/kl/*/*.db /tmp/kl/*.db 2>/dev/null | head -1)" 2>&1 | grep -v "at::native\|rocclr\|Cijk" > "$out/${tag}_kernel_stats_lab.md"
 [ -x tools/bin/ubench_ops ] && timeout 120 tools/bin/ubench_ops > "$out/${tag}_ubench_ops.txt" 2>&1
