@@ -113,7 +113,9 @@ typedef struct SlParams {
     double lasso_lambda;        /* 0.01 */
     double dl_lambda;           /* 0.1  (Vahadane) */
     int32_t dl_max_sweeps;      /* 200  (Vahadane; the reference is wall-clock budgeted) */
-    int32_t schedule;           /* 0 = automatic; 1 = one launch per phase; 2 = persistent fused kernel */
+    int32_t schedule;           /* 0 = automatic; 1 = one launch per phase; 2 = persistent fused kernel (two 512-thread workgroups per CU);
+                                   3 = Macenko only: the fused kernel with one 1024-thread workgroup per CU where the batch has no more tiles
+                                   than the device has CUs (else as 2) */
     double dl_tol;              /* 1e-7 the dictionary iteration stops when a full sweep moves D by less than this (max-abs), or
                                         when the a-posteriori estimate of its distance to the fixed point (the step the next sweep would
                                         take, predicted from the last two) is below it */

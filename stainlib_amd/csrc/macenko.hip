@@ -31,6 +31,7 @@ inline int fused_min_default(long P) { return P >= (1L << 19) ? kFusedMinTiles :
 inline int split_max_rest(long P) {
     return P >= (1L << 19) ? kSplitMaxRest : P > (1L << 18) ? kSplitMaxRestMid : P > (1L << 16) ? kSplitMaxRestSmall : kSplitMaxRestTiny;
 }
+constexpr int kWideMinTiles = 208;          // Macenko, tiles of 256 Ki pixels and more: from here to #CU tiles the 1024-thread fused kernel (1024^2: 192 tiles 0.818 vs 0.798 ms per phase, 224: 0.858 vs 0.881, 256: 0.915 vs 0.974)
 constexpr int kDictFusedMinTiles = 640;     // Vahadane: below it the dictionary sweeps run one launch per phase too (measured: 1024^2 tiles 3.70 vs
                                             // 3.85 ms at 512, 6.24 vs 5.76 at 768; in a fused launch of one tile per workgroup the few tiles
                                             // that need a third full sweep hold the whole launch, per phase they cost a short extra launch)
@@ -49,6 +50,7 @@ int g_debug_stop = 0;
 struct Layout {
     int parts, stride_log2, n_sample, G, cap_raw, cap_list;
     bool fused;
+    bool wide;                              // fused with 1024-thread workgroups, one per CU (Macenko, batches of up to #CU tiles)
     int grid;                               // fused: workgroups launched
     int max_grid;                           // resident sweep workgroups of the device
     size_t off_M, off_maxC, off_status, off_partials, off_sample, off_cand, off_list, off_state, off_dstate, off_mstate, off_diag, total;
@@ -87,6 +89,12 @@ Layout make_layout(int n, long P, int method = kMethodMacenko, int schedule = 0,
     // for the whole batch (1024^2: 640 tiles 5.65 vs 4.71 ms, 768 tiles 5.71 vs 6.20; 512^2: 576 tiles 1.93 vs 1.63, 768 tiles 1.98 vs 2.09)
     if (schedule == 0 && fused_min_tiles <= 0 && method == kMethodVahadane && P >= (1L << 18) && n > L.max_grid && 8L * n < 11L * L.max_grid)
         L.fused = false;
+    // Macenko batches of no more tiles than CUs: the fused kernel with ONE 1024-thread workgroup per CU (schedule 3 forces it where it
+    // fits; automatic from kWideMinTiles tiles of 256 Ki pixels and more -- below that one launch per phase fills the chip better)
+    const int n_cu = L.max_grid / 2;
+    L.wide = method == kMethodMacenko && n <= n_cu && (schedule == 3 || (schedule == 0 && fused_min_tiles <= 0 && n >= kWideMinTiles && P >= (1L << 18)));
+    if (schedule == 3) L.fused = true;
+    if (L.wide) L.fused = true;
     L.grid = n < L.max_grid ? n : L.max_grid;
     const size_t slots = L.fused ? (size_t)L.grid : (size_t)L.G;     // candidate buffers: per workgroup / per tile of a group
     size_t o = 0;
@@ -256,6 +264,14 @@ int run_fused(int method, const uint8_t* rgb, uint8_t* out, int n, long P, const
     const bool al = aligned4(rgb, P) && (!out || aligned4(out, P));
     const dim3 g((unsigned)L.grid), b(kFusedThreads);
     ProfScope ps(p.profile, out ? SL_PROF_FUSED_TRANSFORM : SL_PROF_FUSED_FIT, n, s);
+    if (method == kMethodMacenko && L.wide) {
+        const dim3 bw(2 * kFusedThreads);
+#define SL_GOW(T, A) hipLaunchKernelGGL((k_fused<kMethodMacenko, T, A, 2 * kFusedThreads>), g, bw, 0, s, a)
+        if (out) { if (al) SL_GOW(true, true); else SL_GOW(true, false); }
+        else     { if (al) SL_GOW(false, true); else SL_GOW(false, false); }
+#undef SL_GOW
+        return launch_status();
+    }
 #define SL_GO(M, T, A) hipLaunchKernelGGL((k_fused<M, T, A, kFusedThreads>), g, b, 0, s, a)
     if (method == kMethodMacenko) {
         if (out) { if (al) SL_GO(kMethodMacenko, true, true); else SL_GO(kMethodMacenko, true, false); }

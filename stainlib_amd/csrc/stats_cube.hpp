@@ -143,7 +143,7 @@ __device__ __forceinline__ void lds_append_masked(uint32_t buf, uint32_t n, unsi
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 #if defined(__HIP_DEVICE_COMPILE__)
     uint32_t sbase;
-    asm("s_lshl2_add_u32 %0, %1, %2" : "=s"(sbase) : "s"(n), "s"(buf) : "scc");
+    asm("s_lshl2_add_u32 %0, %1, %2" : "=s"(sbase) : "s"((uint32_t)__builtin_amdgcn_readfirstlane((int)n)), "s"(buf) : "scc");
     const uint32_t addr = sbase + 4u * rank;
     unsigned long long saved;
     asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_write_b32 %2, %3\n\ts_mov_b64 exec, %0"

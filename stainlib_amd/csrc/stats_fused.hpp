@@ -184,6 +184,21 @@ __device__ __noinline__ void fused_finish1(FusedShared<NT>* shp, uint32_t* samp_
 // finish step) moved spills and copies into the loops of the others -- the same source measured 1.70 or 1.83 ms depending on
 // what else the kernel held.  Uniform arguments arrive in VGPRs and are re-read into SGPRs; per-tile constants come from *shp.
 
+// Geometry of the sweeps inside the fused kernel: a 512-thread workgroup sweeps the whole tile; the 1024-thread variant (one
+// workgroup per CU, batches of up to #CU tiles) lets its two halves sweep the two halves of the tile exactly as two 512-thread
+// workgroups of the per-phase schedule would (part_range keeps the halves aligned to whole trips), so every (lane, trip) sums the
+// same 16 pixels in every variant and schedule: the binary32 bursts are bit-identical, only the order of the binary64 additions
+// differs -- as between the two schedules.
+template <int NT>
+__device__ __forceinline__ void fused_geometry(int nch, int tid, int& t, int& c0, int& c1) {
+    constexpr int H = NT / kFusedThreads;
+    static_assert(NT % kFusedThreads == 0, "");
+    if (H == 1) { t = tid; c0 = 0; c1 = nch; return; }
+    t = tid % kFusedThreads;
+    part_range(nch, H, __builtin_amdgcn_readfirstlane(tid / kFusedThreads), c0, c1);      // (the half is wave-uniform: tell the compiler)
+    c0 = __builtin_amdgcn_readfirstlane(c0); c1 = __builtin_amdgcn_readfirstlane(c1);
+}
+
 #ifdef SL_EXP_INLINE_SWEEPS
 #define SL_SWEEP_ATTR __forceinline__
 #else
@@ -202,8 +217,11 @@ __device__ SL_SWEEP_ATTR void fused_sweep1(FusedShared<NT>* shp, const uint8_t* 
     const int nch = (P + 3) >> 2;
     Moments mo;
     uint32_t n_tissue = 0;
-    if (stream) moments_sweep_b<ALIGNED, kFusedTrip, true>(src, P, 0, nch, tid, NT, TB, ylimf, stride_log2, samp, mo, n_tissue);
-    else moments_sweep_b<ALIGNED, kFusedTrip, false>(src, P, 0, nch, tid, NT, TB, ylimf, stride_log2, samp, mo, n_tissue);
+    int t, c0, c1;
+    fused_geometry<NT>(nch, tid, t, c0, c1);
+    if (c0 >= c1) {                                              // (a half without pixels: wave-uniform)
+    } else if (stream) moments_sweep_b<ALIGNED, kFusedTrip, true>(src, P, c0, c1, t, kFusedThreads, TB, ylimf, stride_log2, samp, mo, n_tissue);
+    else moments_sweep_b<ALIGNED, kFusedTrip, false>(src, P, c0, c1, t, kFusedThreads, TB, ylimf, stride_log2, samp, mo, n_tissue);
     double v[10];
     mo.to_array(v, n_tissue, lane);
 #pragma unroll
@@ -225,6 +243,8 @@ __device__ SL_SWEEP_ATTR void fused_select(FusedShared<NT>* shp, const uint8_t* 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const TabReaderB TB = TabReaderB::make(sh.tab);
     const int nch = (P + 3) >> 2;
+    int t, c0, c1;
+    fused_geometry<NT>(nch, tid, t, c0, c1);
     SelConsts K;
     K.lo0 = uni(sh.lo[0]); K.hi0 = uni(sh.hi[0]); K.lo1 = uni(sh.lo[1]); K.hi1 = uni(sh.hi[1]);
     RawSinkFinish sink{(uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(sh.stage[wave])), 0u, rawl, &sh.n_raw, &sh.overflow, (uint32_t)cap_raw,
@@ -238,19 +258,21 @@ __device__ SL_SWEEP_ATTR void fused_select(FusedShared<NT>* shp, const uint8_t* 
             K.u[i][0] = in_vgpr(sh.mk.u[i][0]); K.u[i][1] = in_vgpr(sh.mk.u[i][1]); K.kt[i] = in_vgpr(sh.mk.kt[i]);
             K.eps[i] = in_vgpr(sh.mk.eps[i]); K.thr[i] = in_vgpr(sh.mk.thr[i]);
         }
-        if (K.xmin > -INFINITY) {                                // block-uniform: the projection bound stands in for the tissue test
-            if (stream) select_sweep<kStageMerged, ALIGNED, kFusedTrip, true, true>(src, P, 0, nch, tid, NT, TB, ylimf, K, sink);
-            else select_sweep<kStageMerged, ALIGNED, kFusedTrip, false, true>(src, P, 0, nch, tid, NT, TB, ylimf, K, sink);
+        if (c0 >= c1) {                                          // (a half without pixels: wave-uniform)
+        } else if (K.xmin > -INFINITY) {                         // block-uniform: the projection bound stands in for the tissue test
+            if (stream) select_sweep<kStageMerged, ALIGNED, kFusedTrip, true, true>(src, P, c0, c1, t, kFusedThreads, TB, ylimf, K, sink);
+            else select_sweep<kStageMerged, ALIGNED, kFusedTrip, false, true>(src, P, c0, c1, t, kFusedThreads, TB, ylimf, K, sink);
         } else {
-            if (stream) select_sweep<kStageMerged, ALIGNED, kFusedTrip, true>(src, P, 0, nch, tid, NT, TB, ylimf, K, sink);
-            else select_sweep<kStageMerged, ALIGNED, kFusedTrip, false>(src, P, 0, nch, tid, NT, TB, ylimf, K, sink);
+            if (stream) select_sweep<kStageMerged, ALIGNED, kFusedTrip, true>(src, P, c0, c1, t, kFusedThreads, TB, ylimf, K, sink);
+            else select_sweep<kStageMerged, ALIGNED, kFusedTrip, false>(src, P, c0, c1, t, kFusedThreads, TB, ylimf, K, sink);
         }
     } else {
         K.L = sh.L;
         K.xmin = -INFINITY;
         vgpr(K.L);
-        if (stream) select_sweep<kStageConc, ALIGNED, kFusedTrip, true>(src, P, 0, nch, tid, NT, TB, ylimf, K, sink);
-        else select_sweep<kStageConc, ALIGNED, kFusedTrip, false>(src, P, 0, nch, tid, NT, TB, ylimf, K, sink);
+        if (c0 >= c1) {
+        } else if (stream) select_sweep<kStageConc, ALIGNED, kFusedTrip, true>(src, P, c0, c1, t, kFusedThreads, TB, ylimf, K, sink);
+        else select_sweep<kStageConc, ALIGNED, kFusedTrip, false>(src, P, c0, c1, t, kFusedThreads, TB, ylimf, K, sink);
     }
     sink.flush(lane);
 }
@@ -271,12 +293,15 @@ __device__ SL_SWEEP_ATTR void fused_apply(FusedShared<NT>* shp, const uint8_t* s
     const int nch = (P + 3) >> 2;
     ApplyK K;
     apply_consts(sh.M, sh.maxC, M_tgt, maxC_tgt, lam, K);
+    int t, c0, c1;
+    fused_geometry<NT>(nch, tid, t, c0, c1);
+    if (c0 >= c1) return;                                        // (a half without pixels: wave-uniform)
     if (stream) {
-        if (K.fast) apply_sweep<ALIGNED, true, TabReaderB, true>(src, dst, P, 0, nch, tid, NT, TB, K);
-        else apply_sweep<ALIGNED, false, TabReaderB, true>(src, dst, P, 0, nch, tid, NT, TB, K);
+        if (K.fast) apply_sweep<ALIGNED, true, TabReaderB, true>(src, dst, P, c0, c1, t, kFusedThreads, TB, K);
+        else apply_sweep<ALIGNED, false, TabReaderB, true>(src, dst, P, c0, c1, t, kFusedThreads, TB, K);
     } else {
-        if (K.fast) apply_sweep<ALIGNED, true, TabReaderB, false>(src, dst, P, 0, nch, tid, NT, TB, K);
-        else apply_sweep<ALIGNED, false, TabReaderB, false>(src, dst, P, 0, nch, tid, NT, TB, K);
+        if (K.fast) apply_sweep<ALIGNED, true, TabReaderB, false>(src, dst, P, c0, c1, t, kFusedThreads, TB, K);
+        else apply_sweep<ALIGNED, false, TabReaderB, false>(src, dst, P, c0, c1, t, kFusedThreads, TB, K);
     }
 }
 
@@ -306,8 +331,11 @@ __device__ SL_SWEEP_ATTR void fused_sweep2_cube(FusedShared<NT>* shp, const uint
     static_assert(offsetof(FusedShared<NT>, S) % 4096 == 0 && offsetof(SelScratch, hist) == 0, "the cube mask must be 4 KB aligned");
     const uint32_t bits_lds = lds_address(sh.S.hist);
     const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(&sh.stage[wave][0]));
-    if (stream) select_sweep_cube<ALIGNED, kFusedTrip, true>(src, P, 0, nch, tid, NT, TB, ylimf, K, bits_lds, ring_lds, direct);
-    else select_sweep_cube<ALIGNED, kFusedTrip, false>(src, P, 0, nch, tid, NT, TB, ylimf, K, bits_lds, ring_lds, direct);
+    int t, c0, c1;
+    fused_geometry<NT>(nch, tid, t, c0, c1);
+    if (c0 >= c1) return;                                        // (a half without pixels: wave-uniform)
+    if (stream) select_sweep_cube<ALIGNED, kFusedTrip, true>(src, P, c0, c1, t, kFusedThreads, TB, ylimf, K, bits_lds, ring_lds, direct);
+    else select_sweep_cube<ALIGNED, kFusedTrip, false>(src, P, c0, c1, t, kFusedThreads, TB, ylimf, K, bits_lds, ring_lds, direct);
 }
 
 // Finish 2 of the merged schedule for the tile whose state sits in *shp: returns the number of slow exact fallbacks.
@@ -531,8 +559,9 @@ static __global__ __launch_bounds__(kMFinishThreads) void k_finish2m(StatsArgs a
 
 enum { kMethodMacenko = 0, kMethodVahadane = 1 };
 
-// NT = 512: two workgroups per CU (the throughput configuration).  NT = 1024: one workgroup per CU, used when the batch
-// has no more tiles than CUs -- the tile's latency halves (Vahadane below 257 tiles; Macenko runs per phase there).
+// NT = 512: two workgroups per CU (the throughput configuration).  NT = 1024 (Macenko, round 4): one workgroup per CU for batches of
+// no more tiles than CUs -- the sweeps run as fast as two half-size workgroups would, the finish steps with twice the threads and
+// nothing to hide behind; between ~190 and 256 tiles of 1024^2 that beats one launch per phase (fused_geometry keeps the sums identical).
 template <int METHOD, bool TRANSFORM, bool ALIGNED, int NT>
 static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
     __shared__ FusedShared<NT> sh;
@@ -600,7 +629,7 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
         if (tile == (int)blockIdx.x) sh.tab.fill_b();       // the row table: written once, before the workgroup's first tile
         __syncthreads();
 
-        if (METHOD == kMethodMacenko) {
+        if constexpr (METHOD == kMethodMacenko) {
             // ---------------- sweep 1: moments + sample
             prio_sweep(0);
             fused_sweep1<NT, ALIGNED>(&sh, src, samp, a.P, a.ylimf, a.stride_log2, stream ? 1 : 0);

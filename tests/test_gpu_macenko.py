@@ -577,3 +577,22 @@ def test_prefilter_at_full_size_on_structured_and_real_tissue_tiles():
     out = runs[0][0].cpu().numpy()
     for i in (0, 4):
         u8_parity(out[i], n.transform(tiles[i]), label=f"prefilter auto, 1024^2 tile {i}")
+
+
+def test_the_1024_thread_fused_kernel_agrees_with_both_other_schedules():
+    """schedule 3 (round 4): one 1024-thread workgroup per CU for batches of no more tiles than CUs; its two halves sweep the two halves
+    of a tile with the 512-thread trip geometry, so the binary32 bursts -- and with them every byte -- equal the other schedules'.
+    Ragged sizes (a half without pixels), failed tiles, with and without the pre-filter."""
+    from stainlib_amd import engine
+    tgt = so.synth_tile(128, 128, 1001, so.M_TRUE_TGT)
+    Mt, mct = _fit_oracle(tgt)
+    for h, w in ((256, 320), (96, 130), (33, 47), (1, 517), (24, 40)):
+        tiles = _fused_batch(h, w, n=20)
+        dev = to_dev(tiles)
+        ref = engine.macenko_transform(dev, Mt, mct, params=engine.make_params(schedule=1))
+        for sched, pf in ((3, 0), (3, 1), (2, 0)):
+            got = engine.macenko_transform(dev, Mt, mct, params=engine.make_params(schedule=sched, prefilter=pf))
+            assert torch.equal(ref[0], got[0]) and torch.equal(ref[3], got[3]), (h, w, sched, pf)
+            ok = (ref[3] == 0)
+            np.testing.assert_allclose(got[1][ok].cpu().numpy(), ref[1][ok].cpu().numpy(), rtol=0, atol=1e-12)
+            np.testing.assert_allclose(got[2][ok].cpu().numpy(), ref[2][ok].cpu().numpy(), rtol=1e-12)

@@ -11,11 +11,12 @@ sizes = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1024
 for method in methods:
     fn = engine.macenko_transform if method == "macenko" else engine.vahadane_transform
     for size in sizes:
-        for n in (16, 32, 64, 128, 256, 320, 384, 448, 512, 640, 768, 1024):
+        for n in (16, 32, 64, 96, 128, 160, 192, 224, 256, 320, 384, 448, 512, 640, 768, 1024):
             rgb = synth_tiles(n, size, size, seed=3)
             out = torch.empty_like(rgb)
             r = []
-            for sched in (1, 2, 0):
+            scheds = (1, 2, 0) + ((3,) if method == "macenko" and n <= 256 else ())
+            for sched in scheds:
                 p = engine.make_params(schedule=sched, dl_tol=1e-6, dl_max_sweeps=100)
                 for _ in range(3):
                     fn(rgb, Mt[0], mct[0], params=p, out=out)
@@ -23,5 +24,6 @@ for method in methods:
                 for _ in range(10):
                     fn(rgb, Mt[0], mct[0], params=p, out=out)
                 torch.cuda.synchronize(); r.append((time.perf_counter() - t0) / 10 * 1e3)
-            print(f"{method} size {size} n {n:4d}: per-phase {r[0]:.3f} ms  fused {r[1]:.3f} ms  automatic {r[2]:.3f} ms -> {n / r[2]:.1f} k tiles/s")
+            wide = f"  fused-1024 {r[3]:.3f} ms" if len(r) > 3 else ""
+            print(f"{method} size {size} n {n:4d}: per-phase {r[0]:.3f} ms  fused {r[1]:.3f} ms{wide}  automatic {r[2]:.3f} ms -> {n / r[2]:.1f} k tiles/s")
             del rgb, out

@@ -92,6 +92,14 @@ KERNEL(k_mix_f64_fma, double, "v", "v_fma_f64 %0, %0, %1, %0\n v_fmac_f32 v100, 
 KERNEL(k_mfma4, float, "v", "v_mfma_f32_4x4x1_16b_f32 v[100:103], %0, %1, v[100:103]\n v_mfma_f32_4x4x1_16b_f32 v[104:107], %1, %2, v[104:107]\n v_mfma_f32_4x4x1_16b_f32 v[108:111], %2, %3, v[108:111]\n v_mfma_f32_4x4x1_16b_f32 v[112:115], %3, %0, v[112:115]\n v_mfma_f32_4x4x1_16b_f32 v[100:103], %0, %1, v[100:103]\n v_mfma_f32_4x4x1_16b_f32 v[104:107], %1, %2, v[104:107]\n v_mfma_f32_4x4x1_16b_f32 v[108:111], %2, %3, v[108:111]\n v_mfma_f32_4x4x1_16b_f32 v[112:115], %3, %0, v[112:115]\n")
 KERNEL(k_mfma4_perm, uint32_t, "v", "v_mfma_f32_4x4x1_16b_f32 v[100:103], %0, %1, v[100:103]\n v_perm_b32 v116, %1, %2, %3\n v_perm_b32 v117, %1, %2, %3\n v_perm_b32 v118, %1, %2, %3\n v_mfma_f32_4x4x1_16b_f32 v[104:107], %1, %2, v[104:107]\n v_perm_b32 v116, %1, %2, %3\n v_perm_b32 v117, %1, %2, %3\n v_perm_b32 v118, %1, %2, %3\n")
 KERNEL(k_mfma4_fma, float, "v", "v_mfma_f32_4x4x1_16b_f32 v[100:103], %0, %1, v[100:103]\n v_fmac_f32 v116, %1, %2\n v_fmac_f32 v117, %1, %2\n v_fmac_f32 v118, %1, %2\n v_mfma_f32_4x4x1_16b_f32 v[104:107], %1, %2, v[104:107]\n v_fmac_f32 v116, %1, %2\n v_fmac_f32 v117, %1, %2\n v_fmac_f32 v118, %1, %2\n")
+// ---- round 4: the matrix pipe once more, in the shape the north star has in mind for the pixel x 3 products (bf16 16x16x16, 4 passes
+// of 4 cycles): alone, and interleaved 1:3 with VALU work from the SAME wave (does the MFMA issue hide behind the VALU instructions
+// of its own wave?).  With 2..8 waves per SIMD the other waves' VALU work can overlap too -- that is the w/SIMD sweep.
+KERNEL(k_mfma16bf, float, "v", "v_mfma_f32_16x16x16_bf16 v[100:103], v[116:117], v[104:105], v[100:103]\n v_mfma_f32_16x16x16_bf16 v[106:109], v[116:117], v[104:105], v[106:109]\n v_mfma_f32_16x16x16_bf16 v[110:113], v[116:117], v[104:105], v[110:113]\n v_mfma_f32_16x16x16_bf16 v[100:103], v[116:117], v[104:105], v[100:103]\n v_mfma_f32_16x16x16_bf16 v[106:109], v[116:117], v[104:105], v[106:109]\n v_mfma_f32_16x16x16_bf16 v[110:113], v[116:117], v[104:105], v[110:113]\n v_mfma_f32_16x16x16_bf16 v[100:103], v[116:117], v[104:105], v[100:103]\n v_mfma_f32_16x16x16_bf16 v[106:109], v[116:117], v[104:105], v[106:109]\n")
+KERNEL(k_mfma16bf_3fma, float, "v", "v_mfma_f32_16x16x16_bf16 v[100:103], v[116:117], v[104:105], v[100:103]\n v_fmac_f32 %0, %1, %2\n v_fmac_f32 %1, %2, %3\n v_fmac_f32 %2, %3, %0\n v_mfma_f32_16x16x16_bf16 v[106:109], v[116:117], v[104:105], v[106:109]\n v_fmac_f32 %3, %0, %1\n v_fmac_f32 %0, %1, %2\n v_fmac_f32 %1, %2, %3\n")
+KERNEL(k_mfma16bf_3perm, uint32_t, "v", "v_mfma_f32_16x16x16_bf16 v[100:103], v[116:117], v[104:105], v[100:103]\n v_perm_b32 %0, %1, %2, %3\n v_perm_b32 %1, %2, %3, %0\n v_perm_b32 %2, %3, %0, %1\n v_mfma_f32_16x16x16_bf16 v[106:109], v[116:117], v[104:105], v[106:109]\n v_perm_b32 %3, %0, %1, %2\n v_perm_b32 %0, %1, %2, %3\n v_perm_b32 %1, %2, %3, %0\n")
+KERNEL(k_only_6fma, float, "v", "v_fmac_f32 %0, %1, %2\n v_fmac_f32 %1, %2, %3\n v_fmac_f32 %2, %3, %0\n v_fmac_f32 %3, %0, %1\n v_fmac_f32 %0, %1, %2\n v_fmac_f32 %1, %2, %3\n")
+KERNEL(k_mfma16bf_7fma, float, "v", "v_mfma_f32_16x16x16_bf16 v[100:103], v[116:117], v[104:105], v[100:103]\n v_fmac_f32 %0, %1, %2\n v_fmac_f32 %1, %2, %3\n v_fmac_f32 %2, %3, %0\n v_fmac_f32 %3, %0, %1\n v_fmac_f32 %0, %1, %2\n v_fmac_f32 %1, %2, %3\n v_fmac_f32 %2, %3, %0\n")
 typedef void (*kern_t)(float*, int, float);
 static void run(const char* name, kern_t kf, int instr_per_rep, float* d_out) {
     const int iters = 2048;
@@ -116,6 +124,7 @@ int main() {
     setvbuf(stdout, nullptr, _IONBF, 0);
     float* d_out; hipMalloc(&d_out, 1024);
 #define RUN(k, n) run(#k, k, n, d_out)
+    RUN(k_mfma16bf,8);RUN(k_mfma16bf_3fma,8);RUN(k_mfma16bf_3perm,8);RUN(k_only_6fma,6);RUN(k_mfma16bf_7fma,8);
     RUN(k_mfma4,8);RUN(k_mfma4_perm,8);RUN(k_mfma4_fma,8);
     RUN(k_perm_ssel,8);RUN(k_fmac_lit,8);RUN(k_mul_lit,8);RUN(k_and_lit,8);RUN(k_cmp_sgpr,8);RUN(k_cmp_zero,8);RUN(k_alignbit,8);RUN(k_mbcnt,8);RUN(k_addc,8);RUN(k_readlane,8);RUN(k_mix_f64_perm,8);RUN(k_mix_exp_perm,8);RUN(k_mix_exp_2fma,8);RUN(k_mix_f64_fma,8);
     RUN(k_fmac_sgpr,8);RUN(k_mul_sgpr,8);RUN(k_fma_lit,8);RUN(k_fma_neg,8);RUN(k_add_abs,8);RUN(k_mul_u24,8);RUN(k_or_b32,8);RUN(k_xor_b32,8);RUN(k_sub_u32,8);RUN(k_lshl_add,8);RUN(k_and_or,8);RUN(k_add3,8);RUN(k_cnd_indep,8);RUN(k_cnd_sgpr,8);RUN(k_max_u32,8);RUN(k_ldexp,8);RUN(k_mix_fma_cmp,8);RUN(k_mix_fma_bfe,8);RUN(k_mix_3fma_perm,8);RUN(k_mix_fma_exp,8);RUN(k_exp,8);
