@@ -30,7 +30,7 @@ namespace sl {
 constexpr int kCubeFn = 10;            // functionals per channel and cell index (see cube_tables)
 constexpr int kCubeTabFloats = kCubeFn * 3 * 32;
 constexpr int kCubeWords = 1024;       // 32 x 32 words (g5, b5), bit = r5
-constexpr int kCubeMaxSharePct = 30;   // above this share of sample pixels in ambiguous cells the per-pixel sweep is cheaper
+constexpr int kCubeMaxSharePct = 40;   // above this share of sample pixels in ambiguous cells the per-pixel sweep is cheaper
 constexpr int kCubeShareStep = 16;     // the share is estimated on every 16th row of the sample (1 024 pixels of 16 Ki: +-1 %)
 constexpr int kCubeRing = kStageWave;  // per-wave staging of ambiguous pixels = the wave's whole 1 KB: up to 127 left over + 2 pixel rows of 64
 
