@@ -34,7 +34,9 @@ def pick(table, needle, counter):
 f, w = dump(f"{d}/{tag}_pmc_f.txt"), dump(f"{d}/{tag}_pmc_w.txt")
 tiles, px = 512, 1048576
 kernels = {}
-for name, needle, alg_bpp in (("k_fused<macenko,transform>", "k_fused<0, true, true", 12), ("k_apply", "k_apply<", 6)):
+# algorithmic bytes = SURVEY 8(d)'s compulsory traffic, 3 B/px read + 3 B/px written, for both kernels; the fused kernel's own schedule
+# (3 read sweeps + 1 write = 12 B/px) is reported beside it
+for name, needle, alg_bpp, sched_bpp in (("k_fused<macenko,transform>", "k_fused<0, true, true", 6, 12), ("k_apply", "k_apply<", 6, 6)):
     fr, wr = pick(f, needle, "FETCH_SIZE"), pick(w, needle, "WRITE_SIZE")
     if fr is None or wr is None:
         continue
@@ -42,7 +44,10 @@ for name, needle, alg_bpp in (("k_fused<macenko,transform>", "k_fused<0, true, t
     alg = alg_bpp * tiles * px
     kernels[name] = {"FETCH_SIZE_KiB_raw": fr, "WRITE_SIZE_KiB": wr, "hbm_bytes_per_launch": hbm,
                      "bytes_per_pixel": round(hbm / (tiles * px), 2), "algorithmic_bytes_per_launch": alg,
-                     "traffic_over_algorithmic": round(hbm / alg, 4)}
+                     "traffic_over_algorithmic": round(hbm / alg, 4), "schedule_bytes_per_pixel": sched_bpp,
+                     "traffic_over_schedule_bytes": round(hbm / (sched_bpp * tiles * px), 4),
+                     "read_over_tile_reads": round(2.0 * fr * 1024 / ((sched_bpp - 3) * tiles * px), 4),
+                     "write_over_output": round(wr * 1024 / (3 * tiles * px), 4)}
 phase = {}
 for n in (64, 512):
     try:
