@@ -35,6 +35,8 @@ constexpr int kCubeShareStep = 16;     // the share is estimated on every 16th r
 constexpr int kCubeRing = kStageWave;  // per-wave staging of ambiguous pixels = the wave's whole 1 KB: up to 127 left over + 2 pixel rows of 64
 
 // word address (bytes) of a pixel's cell inside the mask and its bit: pixel = r | g << 8 | b << 16
+// (The LDS bank of a mask read is g5.  Measured: an XOR swizzle of the word index with b5 -- banks spread even where the green bytes
+// crowd into few values, one instruction more per pixel -- changes nothing: 1.62-1.65 ms either way, real tissue 1.72 vs 1.75.)
 __device__ __forceinline__ uint32_t cube_word_offset(uint32_t p) { return ((p >> 9) & 0x7Cu) | ((p >> 12) & 0xF80u); }
 __device__ __forceinline__ uint32_t cube_bit(uint32_t p) { return (p >> 3) & 31u; }
 
