@@ -53,9 +53,9 @@ def test_random_small_tiles_against_the_oracle():
         mco = np.percentile(Co, 99, axis=0)
         if not (mco > 1e-3).all():
             continue
-        p = engine.make_params(luminosity_threshold=thr, angular_percentile=pct, schedule=int(rng.choice([1, 2])))
+        p = engine.make_params(luminosity_threshold=thr, angular_percentile=pct, schedule=int(rng.choice([1, 2, 3])), prefilter=int(rng.choice([0, 2, 2, 1])))
         out, M, mc, st = engine.macenko_transform(to_dev([I]), torch.as_tensor(Mt, device="cuda"), torch.as_tensor(mct, device="cuda"), params=p)
-        label = f"{kind} {h}x{w} seed {seed} thr {thr} pct {pct} schedule {p.schedule}"
+        label = f"{kind} {h}x{w} seed {seed} thr {thr} pct {pct} schedule {p.schedule} prefilter {p.prefilter}"
         assert int(st[0]) == 0, label
         np.testing.assert_allclose(M.cpu().numpy()[0], Mo, rtol=0, atol=5e-6, err_msg=label)
         np.testing.assert_allclose(mc.cpu().numpy()[0], mco, rtol=5e-6, err_msg=label)
@@ -110,21 +110,22 @@ def test_random_mid_size_tiles_against_the_oracle():
         mco = np.percentile(Co, 99, axis=0)
         want = so.truncate_u8(255 * np.exp(-(Co * (mct / mco)) @ Mt)).reshape(I.shape)
         outs = []
-        for sched in (1, 2):
-            p = engine.make_params(luminosity_threshold=thr, angular_percentile=pct, schedule=sched)
+        # (round 4) schedule 3 = the 1024-thread fused kernel; prefilter 2 = the colour-cube mask forced wherever it can be built
+        for sched, pf in ((1, 0), (2, 0), (3, 0), (2, 2), (2, 1)):
+            p = engine.make_params(luminosity_threshold=thr, angular_percentile=pct, schedule=sched, prefilter=pf)
             rs = torch.full((1,), -1, dtype=torch.int32, device="cuda")
             p.resweeps_out = rs.data_ptr()
             out, M, mc, st = engine.macenko_transform(to_dev([I]), torch.as_tensor(Mt, device="cuda"), torch.as_tensor(mct, device="cuda"), params=p)
-            label = f"{kind} {h}x{w} seed {seed} background {frac} thr {thr} pct {pct} schedule {sched}"
+            label = f"{kind} {h}x{w} seed {seed} background {frac} thr {thr} pct {pct} schedule {sched} prefilter {pf}"
             assert int(st[0]) == 0, label
             np.testing.assert_allclose(M.cpu().numpy()[0], Mo, rtol=0, atol=5e-6, err_msg=label)
             np.testing.assert_allclose(mc.cpu().numpy()[0], mco, rtol=5e-6, err_msg=label)
             outs.append(out)
-            if sched == 2:
+            if sched == 2 and pf == 0:
                 routes[int(rs[0])] = routes.get(int(rs[0]), 0) + 1
                 if int(rs[0]):
                     print("  separate sweep, reason", int(rs[0]), ":", label)
-        assert torch.equal(outs[0], outs[1])
+        assert all(torch.equal(outs[0], o) for o in outs[1:]), label
         u8_parity(outs[0].cpu().numpy()[0], want, label=label, src=I)
     print("resweep reasons over the cases (0 = merged sweep settled the tile):", routes)
     assert routes.get(0, 0) >= 7          # the merged route is the normal one at these sizes
