@@ -372,11 +372,7 @@ struct RawSinkT {
         n += cnt;
     }
 };
-#ifdef SL_EXP_FLUSH_INLINE
-using RawSink = RawSinkT<true>;
-#else
 using RawSink = RawSinkT<false>;
-#endif
 using RawSinkFinish = RawSinkT<true>;
 
 

@@ -199,14 +199,9 @@ __device__ __forceinline__ void fused_geometry(int nch, int tid, int& t, int& c0
     c0 = __builtin_amdgcn_readfirstlane(c0); c1 = __builtin_amdgcn_readfirstlane(c1);
 }
 
-#ifdef SL_EXP_INLINE_SWEEPS
-#define SL_SWEEP_ATTR __forceinline__
-#else
-#define SL_SWEEP_ATTR __noinline__
-#endif
 // Sweep 1: tissue test, moments, sample; leaves the ten wave sums in sh.red (the caller adds them up after a barrier).
 template <int NT, bool ALIGNED>
-__device__ SL_SWEEP_ATTR void fused_sweep1(FusedShared<NT>* shp, const uint8_t* src_, uint32_t* samp_, int P_, float ylimf_, int stride_log2_, int stream_) {
+__device__ __noinline__ void fused_sweep1(FusedShared<NT>* shp, const uint8_t* src_, uint32_t* samp_, int P_, float ylimf_, int stride_log2_, int stream_) {
     FusedShared<NT>& sh = *shp;
     const uint8_t* src = uni_ptr(src_);
     uint32_t* samp = uni_ptr(samp_);
@@ -233,7 +228,7 @@ __device__ SL_SWEEP_ATTR void fused_sweep1(FusedShared<NT>* shp, const uint8_t* 
 // Sweeps 2 (merged stage, per-pixel test) and 3 (concentration stage): classify against sh.lo / sh.hi, raw candidates to the tile's
 // list through the wave's staging in sh.stage.  merged: constants from sh.Vf / sh.mk / sh.xmin; otherwise from sh.L.
 template <int NT, bool ALIGNED>
-__device__ SL_SWEEP_ATTR void fused_select(FusedShared<NT>* shp, const uint8_t* src_, uint32_t* rawl_, int P_, int cap_raw_, float ylimf_, int stream_, int merged_) {
+__device__ __noinline__ void fused_select(FusedShared<NT>* shp, const uint8_t* src_, uint32_t* rawl_, int P_, int cap_raw_, float ylimf_, int stream_, int merged_) {
     FusedShared<NT>& sh = *shp;
     const uint8_t* src = uni_ptr(src_);
     uint32_t* rawl = uni_ptr(rawl_);
@@ -279,7 +274,7 @@ __device__ SL_SWEEP_ATTR void fused_select(FusedShared<NT>* shp, const uint8_t* 
 
 // Sweep 4: the apply pass with the tile's (sh.M, sh.maxC).
 template <int NT, bool ALIGNED>
-__device__ SL_SWEEP_ATTR void fused_apply(FusedShared<NT>* shp, const uint8_t* src_, uint8_t* dst_, int P_, const double* M_tgt_, const double* maxC_tgt_,
+__device__ __noinline__ void fused_apply(FusedShared<NT>* shp, const uint8_t* src_, uint8_t* dst_, int P_, const double* M_tgt_, const double* maxC_tgt_,
                                          double lam_, int stream_) {
     FusedShared<NT>& sh = *shp;
     const uint8_t* src = uni_ptr(src_);
@@ -308,7 +303,7 @@ __device__ SL_SWEEP_ATTR void fused_apply(FusedShared<NT>* shp, const uint8_t* s
 // Sweep 2 behind the colour-cube mask, out of line like the finish steps: its registers are allocated apart from the other sweeps'
 // (the fused kernel sits at its 128-register limit; inlined, this sweep made the others spill).  Constants come from *shp.
 template <int NT, bool ALIGNED>
-__device__ SL_SWEEP_ATTR void fused_sweep2_cube(FusedShared<NT>* shp, const uint8_t* src_, uint32_t* rawl_, int P_, int cap_raw_, float ylimf_, int stream_) {
+__device__ __noinline__ void fused_sweep2_cube(FusedShared<NT>* shp, const uint8_t* src_, uint32_t* rawl_, int P_, int cap_raw_, float ylimf_, int stream_) {
     FusedShared<NT>& sh = *shp;
     const uint8_t* src = uni_ptr(src_);
     uint32_t* rawl = uni_ptr(rawl_);
