@@ -89,6 +89,22 @@ __device__ __forceinline__ CubeConsts cube_tables(const TabView& tab, const floa
     return cc;
 }
 
+// one cell's verdict from the per-channel tables (what cube_mask evaluates for every cell, here for the cell of ONE pixel)
+__device__ __forceinline__ bool cube_cell_plain(const float* ctab, const CubeConsts& cc, float ylimf, uint32_t p) {
+    const int r5 = (int)((p >> 3) & 31u), g5 = (int)((p >> 11) & 31u), b5 = (int)((p >> 19) & 31u);
+    float v[kCubeFn];
+#pragma unroll
+    for (int f = 0; f < kCubeFn; ++f)
+        v[f] = ctab[(f * 3 + 1) * 32 + g5] + ctab[(f * 3 + 2) * 32 + b5] + (f >= 6 ? cc.kt[(f - 6) >> 1] : 0.0f) + ctab[(f * 3) * 32 + r5];
+    const bool no_tissue = v[0] >= ylimf;
+    const float t0lb = cc.hi0m >= 0.0f ? fminf(v[2], v[3]) : fmaxf(v[2], v[3]);
+    const float t1ub = cc.lo1m >= 0.0f ? fminf(v[4], v[5]) : fmaxf(v[4], v[5]);
+    const bool cone = fminf(fminf(v[1], t0lb), -t1ub) > cc.s_ang;
+    const float sa = fmaxf(fabsf(v[6]), fabsf(v[7])) + fmaxf(fabsf(v[8]), fabsf(v[9]));
+    const bool conc1 = fmaf(cc.eps[0], sa, v[7]) < cc.thr[0], conc2 = fmaf(cc.eps[1], sa, v[9]) < cc.thr[1];
+    return (no_tissue || cone) && conc1 && conc2;
+}
+
 // The mask: thread t fills words t, t + NT, ... (word = g5 | b5 << 5, bit = r5).  Call after a barrier behind cube_tables.
 // (Fully unrolled by the compiler, ~45 us per tile next to a sweeping partner; a rolled inner loop waits for its ten LDS reads in
 // every iteration: 310 us.)
@@ -118,17 +134,18 @@ __device__ __forceinline__ void cube_mask(const float* ctab, const CubeConsts& c
     }
 }
 
-// Share of the sample in ambiguous cells (all threads; two barriers): true when the cube sweep should run.
+// Share of the sample in ambiguous cells (all threads; two barriers): true when the cube sweep should run.  Evaluated from the
+// per-channel tables for the cells of every kCubeShareStep-th row of the sample, BEFORE the mask is built: a tile that declines (the
+// spatially smooth synthetic ones: 55 %) pays for 1 024 cells instead of 32 768.
 template <int NT>
-__device__ __forceinline__ bool cube_worthwhile(const uint32_t* samp, int n_sample, int cps_log2, int P, const uint32_t* bits, unsigned int* counter, int tid,
-                                                int& share_pct) {
+__device__ __forceinline__ bool cube_worthwhile(const uint32_t* samp, int n_sample, int cps_log2, int P, const float* ctab, const CubeConsts& cc, float ylimf,
+                                                unsigned int* counter, int tid, int& share_pct) {
     if (tid == 0) *counter = 0;
     __syncthreads();
     uint32_t amb = 0, seen = 0;
     for (int b = tid; b < n_sample; b += kCubeShareStep * NT) {        // every kCubeShareStep-th row of the sample is plenty
         if (sample_absent(b, cps_log2, P)) continue;
-        const uint32_t p = samp[b] & 0xffffffu;
-        amb += (bits[cube_word_offset(p) >> 2] >> cube_bit(p)) & 1u;
+        amb += cube_cell_plain(ctab, cc, ylimf, samp[b] & 0xffffffu) ? 0u : 1u;
         ++seen;
     }
     uint32_t both = amb | (seen << 16);                                 // (at most 16 Ki / 16 entries in all: the halves cannot overflow)

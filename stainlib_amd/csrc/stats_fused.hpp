@@ -82,6 +82,29 @@ __device__ __forceinline__ double uni_d(double x) {
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// The colour-cube mask of the merged sweep (stats_cube.hpp) for the tile in *shp, after finish 1 has left brackets and thresholds there:
+// per-channel tables in the sweeps' staging space, the mask where the finish steps' histogram lives (neither is in use between finish
+// 1 and finish 2); sh.use_cube says whether sweep 2 runs behind it (bit 0) and carries the sampled share of ambiguous cells (bits 8..).
+template <int NT>
+__device__ __noinline__ void fused_cube_build(FusedShared<NT>* shp, uint32_t* samp_, int n_sample_, int stride_log2_, int P_, float ylimf_, int want_cube_) {
+    FusedShared<NT>& sh = *shp;
+    uint32_t* samp = uni_ptr(samp_);
+    const int n_sample = __builtin_amdgcn_readfirstlane(n_sample_), stride_log2 = __builtin_amdgcn_readfirstlane(stride_log2_), P = __builtin_amdgcn_readfirstlane(P_);
+    const int want_cube = __builtin_amdgcn_readfirstlane(want_cube_);
+    const float ylimf = uni(ylimf_);
+    const int tid = threadIdx.x;
+    float* ctab = reinterpret_cast<float*>(&sh.stage[0][0]);
+    static_assert(sizeof(sh.stage) >= sizeof(float) * kCubeTabFloats && sizeof(sh.S.hist) >= 4 * kCubeWords, "");
+    const CubeConsts cc = cube_tables(view_of_b(sh.tab), sh.Vf, sh.hi[0], sh.lo[1], sh.mk, ctab, tid);
+    __syncthreads();
+    int share_pct;
+    const bool pays = cube_worthwhile<NT>(samp, n_sample, stride_log2 - 2, P, ctab, cc, ylimf, &sh.S.misc[33], tid, share_pct);
+    const bool go = pays || want_cube == 2;                                                   // block-uniform
+    if (tid == 0) sh.use_cube = (go ? 1 : 0) | (share_pct << 8);                              // (the share rides along for prefilter_out)
+    if (go) cube_mask<NT>(ctab, cc, ylimf, sh.S.hist, tid);
+    __syncthreads();
+}
+
 // Finish 1 of the merged schedule after the eigenvectors: brackets and thresholds into sh.lo / sh.hi / sh.mk.
 template <int NT>
 __device__ __noinline__ void fused_finish1(FusedShared<NT>* shp, uint32_t* samp_, int n_sample_, int stride_log2_, int P_, float ylimf_, double pct_, double lam_,
@@ -132,21 +155,11 @@ __device__ __noinline__ void fused_finish1(FusedShared<NT>* shp, uint32_t* samp_
     }
     __syncthreads();
     SL_SUB(4);
-    // ---------------- the colour-cube mask of the merged sweep (stats_cube.hpp): per-channel tables in the sweeps' staging space,
-    // the mask where the finish steps' histogram lives (neither is in use between finish 1 and finish 2)
+    // ---------------- the colour-cube mask of the merged sweep (out of line: inlined here, its unrolled mask loop pushed the bracket
+    // code's register-resident sample keys into scratch -- both bracket steps took twice as long)
     const float hi0 = sh.hi[0], lo1 = sh.lo[1];
-    if (want_cube && hi0 > -INFINITY && hi0 < INFINITY && lo1 > -INFINITY && lo1 < INFINITY) {       // block-uniform
-        float* ctab = reinterpret_cast<float*>(&sh.stage[0][0]);
-        static_assert(sizeof(sh.stage) >= sizeof(float) * kCubeTabFloats && sizeof(sh.S.hist) >= 4 * kCubeWords, "");
-        const CubeConsts cc = cube_tables(key.tab, sh.Vf, hi0, lo1, sh.mk, ctab, tid);
-        __syncthreads();
-        cube_mask<NT>(ctab, cc, ylimf, sh.S.hist, tid);
-        __syncthreads();
-        int share_pct;
-        const bool pays = cube_worthwhile<NT>(samp, n_sample, stride_log2 - 2, P, sh.S.hist, &sh.S.misc[33], tid, share_pct);
-        if (tid == 0) sh.use_cube = ((pays || want_cube == 2) ? 1 : 0) | (share_pct << 8);       // (the share rides along for prefilter_out)
-        __syncthreads();
-    }
+    if (want_cube && hi0 > -INFINITY && hi0 < INFINITY && lo1 > -INFINITY && lo1 < INFINITY)       // block-uniform
+        fused_cube_build<NT>(&sh, samp, n_sample, stride_log2, P, ylimf, want_cube);
     SL_SUB(7);      // (slot 7 is otherwise written on the resweep path only)
     // ---------------- the per-pixel sweep: does the projection bound stand in for its tissue test?
     // The bound makes the sweep collect NON-tissue pixels too when they pass it and lie outside the cone.  On most
