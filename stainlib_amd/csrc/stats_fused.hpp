@@ -123,10 +123,10 @@ __device__ __noinline__ void fused_finish1(FusedShared<NT>* shp, uint32_t* samp_
 #define SL_SUB(j)
 #endif
     (void)subclk;
-    SampleAngleKey key;
-    key.sample = samp; key.tab = view_of_b(sh.tab); key.cps_log2 = stride_log2 - 2; key.P = P; key.ylimf = ylimf;
-    for (int i = 0; i < 6; ++i) key.V[i] = sh.Vf[i];
     {
+        SampleAngleKey key;                                           // (scoped: kept alive across the function it cost the bracket code registers)
+        key.sample = samp; key.tab = view_of_b(sh.tab); key.cps_log2 = stride_log2 - 2; key.P = P; key.ylimf = ylimf;
+        for (int i = 0; i < 6; ++i) key.V[i] = sh.Vf[i];
         float lo[2], hi[2];
         float box[4];
         angle_brackets<NT>(key, n_sample, pct, lo, hi, sh.S, box);
@@ -170,6 +170,9 @@ __device__ __noinline__ void fused_finish1(FusedShared<NT>* shp, uint32_t* samp_
     // of a cell exactly.)
     const float xm = sh.xmin;
     if (!(sh.use_cube & 1) && xm > -INFINITY && xm < INFINITY) {  // block-uniform
+        SampleAngleKey key;
+        key.sample = samp; key.tab = view_of_b(sh.tab); key.cps_log2 = stride_log2 - 2; key.P = P; key.ylimf = ylimf;
+        for (int i = 0; i < 6; ++i) key.V[i] = sh.Vf[i];
         if (tid == 0) sh.S.misc[32] = 0;
         __syncthreads();
         uint32_t extra = 0;
