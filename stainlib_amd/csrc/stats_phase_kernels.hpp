@@ -98,7 +98,7 @@ static __global__ __launch_bounds__(kSweepThreads, 4) void k_select(StatsArgs a)
         const uint8_t* src = a.rgb + (size_t)tile * a.P * 3;
         int c0, c1;
         part_range((a.P + 3) >> 2, a.parts, part, c0, c1);
-        RawSinkFinish sink{(uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(s_stage[wave])), 0u, a.raw + (size_t)tile * a.cap_raw, &st.n_raw, &st.overflow, (uint32_t)a.cap_raw, (uint32_t)kStageWave};
+        RawSink sink{(uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(s_stage[wave])), 0u, a.raw + (size_t)tile * a.cap_raw, &st.n_raw, &st.overflow, (uint32_t)a.cap_raw, (uint32_t)kStageWave};
         const bool stream = (size_t)a.P * 3 >= kStreamBytes;
         if (STAGE == kStageMerged && K.xmin > -INFINITY) {                   // block-uniform: the projection bound stands in for the tissue test
             if (stream) select_sweep<kStageMerged, ALIGNED, kPhaseTrip, true, true>(src, a.P, c0, c1, tid, kSweepThreads, T, a.ylimf, K, sink);
