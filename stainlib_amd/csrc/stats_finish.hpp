@@ -307,14 +307,13 @@ __device__ __forceinline__ void stage_pick2(const float* cand0, const float* can
 // Raw candidates are staged per wave in LDS and written out in dense bursts; the tile's list head is
 // touched once per burst.  Positions come from v_mbcnt on the row's lane mask: no atomics, no LDS round
 // trip, the fill level stays in an SGPR.
-
-
+// burst of a wave's staged candidates to the tile's list (cold: once per ~130 pixel rows; kept out of line so
+// that the eight call sites of a trip stay small).  Round 4 tried it INLINED: -0.7 % with the sweeps inlined in the kernel (and
+// spills in their loops as soon as anything else changed); with every phase out of line nothing, neither in the sweeps nor in the
+// finish steps' refine passes -- and one instantiation of the select sweep hung with it (hazard 3).  It stays a call.
 // buf_lds: LDS byte address of the wave's staging buffer (a flat pointer to LDS kept live across the sweep drives this
 // hipcc into an illegal post-RA copy of src_shared_base)
-// burst of a wave's staged candidates to the tile's list (cold: once per ~130 pixel rows; kept out of line so
-// that the eight call sites of a trip stay small.  Round 4 measured it inlined: -0.7 % on its own, but together with any other
-// change of the kernel the sweep loops started to spill -- the fused kernel sits at its 128-register limit)
-__device__ __forceinline__ void raw_flush_body(uint32_t buf_lds, uint32_t n, uint32_t* dst, unsigned int* head, uint32_t cap) {
+__device__ __noinline__ void raw_flush(uint32_t buf_lds, uint32_t n, uint32_t* dst, unsigned int* head, uint32_t cap) {
 #if defined(__HIP_DEVICE_COMPILE__)
     SL_LDS const uint32_t* buf = (SL_LDS const uint32_t*)buf_lds;
 #else
@@ -328,13 +327,7 @@ __device__ __forceinline__ void raw_flush_body(uint32_t buf_lds, uint32_t n, uin
         if (base + i < cap) dst[base + i] = buf[i];
 }
 
-__device__ __noinline__ void raw_flush(uint32_t buf_lds, uint32_t n, uint32_t* dst, unsigned int* head, uint32_t cap) { raw_flush_body(buf_lds, n, dst, head, cap); }
-
-// INLINE_FLUSH: the finish steps' refine passes (out-of-line functions with registers to spare) inline the burst: out of line,
-// every call reloaded spilled arguments and waited for all outstanding vector memory operations first (round 4: -3 % of the fused
-// kernel's time through shorter finish steps).  The sweeps keep the call.
-template <bool INLINE_FLUSH>
-struct RawSinkT {
+struct RawSink {
     uint32_t buf;               // LDS byte address of this wave's kStageWave entries
     uint32_t n;                 // wave-uniform fill
     uint32_t* dst;              // global raw list of the tile
@@ -343,7 +336,7 @@ struct RawSinkT {
     uint32_t cap;               // capacity of dst
     uint32_t stage_cap;         // entries of the staging buffer (>= 64)
     __device__ __forceinline__ void flush(int) {
-        if (n != 0) { if constexpr (INLINE_FLUSH) raw_flush_body(buf, n, dst, head, cap); else raw_flush(buf, n, dst, head, cap); }
+        if (n != 0) raw_flush(buf, n, dst, head, cap);
         n = 0;
     }
     // One pixel row of the wave: m = lane mask of the flagged lanes (a wave-uniform value).  Branch-free on the hot
@@ -372,8 +365,6 @@ struct RawSinkT {
         n += cnt;
     }
 };
-using RawSink = RawSinkT<false>;
-using RawSinkFinish = RawSinkT<true>;
 
 
 // ------------------------------------------------------------------------------------------
@@ -480,8 +471,8 @@ __device__ __forceinline__ RefineOut wg_refine_s(const uint32_t* raw, int n_raw,
     r.ps.sc[1] = (hi1 > lo1 && lo1 > -INFINITY && hi1 < INFINITY) ? 512.0f * 0.999999f / (hi1 - lo1) : 0.0f;
     __syncthreads();
     stage_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)stage_lds);
-    RawSinkFinish s0{stage_lds, 0u, reinterpret_cast<uint32_t*>(cand0), &S.misc[11], nullptr, cap_list, stage_entries};
-    RawSinkFinish s1{stage_lds + 4u * stage_entries, 0u, reinterpret_cast<uint32_t*>(cand1), &S.misc[12], nullptr, cap_list, stage_entries};
+    RawSink s0{stage_lds, 0u, reinterpret_cast<uint32_t*>(cand0), &S.misc[11], nullptr, cap_list, stage_entries};
+    RawSink s1{stage_lds + 4u * stage_entries, 0u, reinterpret_cast<uint32_t*>(cand1), &S.misc[12], nullptr, cap_list, stage_entries};
     const float vlo0 = in_vgpr(lo0), vhi0 = in_vgpr(hi0), vlo1 = in_vgpr(lo1), vhi1 = in_vgpr(hi1);
     const float psl0 = in_vgpr(r.ps.lo[0]), psc0 = in_vgpr(r.ps.sc[0]), psl1 = in_vgpr(r.ps.lo[1]), psc1 = in_vgpr(r.ps.sc[1]);
     const uint32_t hist_lds = lds_address(S.hist);

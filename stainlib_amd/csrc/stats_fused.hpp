@@ -258,9 +258,6 @@ __device__ __noinline__ void fused_select(FusedShared<NT>* shp, const uint8_t* s
     fused_geometry<NT>(nch, tid, t, c0, c1);
     SelConsts K;
     K.lo0 = uni(sh.lo[0]); K.hi0 = uni(sh.hi[0]); K.lo1 = uni(sh.lo[1]); K.hi1 = uni(sh.hi[1]);
-    // (the burst stays out of line HERE: inlined -- RawSinkFinish -- this sweep hung on tiles whose pixel count is not a multiple of four
-    //  (503 x 527, every percentile; found by the round-4 soak), in the instantiation with the ragged tail trip; the refine passes of
-    //  the finish steps, which gain from the inlined burst, walk lists, not tiles)
     RawSink sink{(uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(sh.stage[wave])), 0u, rawl, &sh.n_raw, &sh.overflow, (uint32_t)cap_raw,
                  (uint32_t)kStageWave};
     if (merged) {
