@@ -348,7 +348,11 @@ def test_random_slides_through_the_pooled_statistics_against_the_oracle():
             np.testing.assert_allclose(M2, M1, rtol=0, atol=1e-12, err_msg=label)
             np.testing.assert_allclose(c2, c1, rtol=1e-12, err_msg=label)
             out, M_s, mc_s, status = SlideNormalizer(n, mode="pooled").transform_shard(dev)
-            u8_parity(out.cpu().numpy().reshape(tall.shape), on.transform(tall), label=label, src=tall)
+            # bytes: the pooled statistics are held to 2e-6 above (they are exact order statistics of binary32 keys over a slide that the
+            # reference evaluates in binary64: measured up to 1e-6 on slides of a few 10^4 pixels), and an error e of maxC moves a fraction
+            # ~200 e of the bytes across an integer: 5e-4 N here instead of the per-tile paths' 1e-4 N
+            want_bytes = on.transform(tall)
+            u8_parity(out.cpu().numpy().reshape(tall.shape), want_bytes, label=label, max_flips=max(8, int(5e-4 * want_bytes.size)))
         except AssertionError as e:
             failures.append((label, s1.last_path, s2.last_path, str(e)[:400]))
         done += 1
