@@ -172,27 +172,42 @@ __device__ __forceinline__ void lds_append_masked(uint32_t buf, uint32_t n, unsi
 #endif
 }
 
-// Where the exact test's candidates go: straight to the tile's raw list (no second staging level: a drain flags ~50 pixels of 128
-// and pays ONE allocation on the list head for them).
+// Where the exact test's candidates go: straight to the tile's lists (no second staging level: a drain flags ~50 pixels of 128 and
+// pays ONE allocation for them).  TWO lists: the angular candidates (tissue outside the plain cone) and the concentration candidates
+// (either stain's conservative test).  Each refine pass of finish 2 then reads the ~45 % / ~65 % of the candidates that concern it
+// instead of all of them; a pixel that is both is stored twice.  The two heads share one 64-bit word: one atomic per drain.
 struct RawDirect {
-    uint32_t* dst;              // global raw list of the tile
-    unsigned int* head;         // list head (LDS)
-    uint32_t cap;               // capacity of dst; a head beyond it marks the list incomplete, as with RawSink
-    __device__ __forceinline__ uint32_t alloc(uint32_t n, int lane) const {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(head, n);
-        return (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    uint32_t* dst_c;            // concentration candidates of the tile (the list the per-pixel sweeps fill with everything)
+    uint32_t* dst_a;            // angular candidates of the tile
+    unsigned long long* heads;  // LDS: low word = head of dst_c, high word = head of dst_a
+    uint32_t cap_c, cap_a;      // capacities; a head beyond its capacity marks that list incomplete, as with RawSink
+    __device__ __forceinline__ void alloc(uint32_t n_c, uint32_t n_a, int lane, uint32_t& base_c, uint32_t& base_a) const {
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(heads, (unsigned long long)n_c | ((unsigned long long)n_a << 32));
+        base_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+        base_a = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));
     }
-    __device__ __forceinline__ void store(unsigned long long m, uint32_t q, uint32_t base, int lane) const {
+    __device__ __forceinline__ static void store(uint32_t* dst, uint32_t cap, unsigned long long m, uint32_t q, uint32_t base, int lane) {
         const uint32_t at = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
         if (((m >> lane) & 1ull) && at < cap) dst[at] = q;
+    }
+    // two pixel rows at once: masks {angle, conc} of each
+    __device__ __forceinline__ void put2(unsigned long long a0, unsigned long long c0, uint32_t q0, unsigned long long a1, unsigned long long c1,
+                                         uint32_t q1, int lane) const {
+        const uint32_t nc0 = (uint32_t)__popcll(c0), nc1 = (uint32_t)__popcll(c1), na0 = (uint32_t)__popcll(a0), na1 = (uint32_t)__popcll(a1);
+        uint32_t bc, ba;
+        alloc(nc0 + nc1, na0 + na1, lane, bc, ba);
+        store(dst_c, cap_c, c0, q0, bc, lane);
+        store(dst_c, cap_c, c1, q1, bc + nc0, lane);
+        store(dst_a, cap_a, a0, q0, ba, lane);
+        store(dst_a, cap_a, a1, q1, ba + na0, lane);
     }
 };
 
 // The merged selection sweep behind the cube mask.  bits_lds: LDS byte address of the 4 KB mask; ring_lds: LDS byte address of this
 // wave's kCubeRing staging entries (wave-uniform).  Pixels of ambiguous cells are appended to the ring; whenever it holds two full
 // rows (checked every second pixel row) they are re-tested exactly, two rows side by side, by the test of select_sweep<kStageMerged>
-// (the variant with the per-pixel tissue test), and what that flags goes to the raw list.  c0 must be a multiple of 64.
+// (the variant with the per-pixel tissue test), and what that flags goes to the tile's two candidate lists (RawDirect).  c0 must be a multiple of 64.
 template <bool ALIGNED, int kTrip, bool STREAM, class TR>
 __device__ __forceinline__ void select_sweep_cube(const uint8_t* src, int P, int c0, int c1, int t, int nthreads, const TR& T, float ylimf,
                                                   const SelConsts& K, uint32_t bits_lds, uint32_t ring_lds, const RawDirect& out) {
@@ -204,7 +219,8 @@ __device__ __forceinline__ void select_sweep_cube(const uint8_t* src, int P, int
     uint32_t rn = 0;                                             // ring fill, wave-uniform
     struct G3 { float2 r, g, b; };
     auto gather = [&](uint32_t q) { return G3{T.gam_odf(T.addr(q, 0)), T.gam_odf(T.addr(q, 1)), T.gam_odf(T.addr(q, 2))}; };
-    auto flags = [&](const G3& e) -> unsigned long long {
+    struct M2 { unsigned long long a, c; };                      // lane masks: angular candidate, concentration candidate
+    auto flags = [&](const G3& e) -> M2 {
         const bool tc = is_tissue_f(e.r.x, e.g.x, e.b.x, ylimf);
         const float x = fmaf(K.V[4], e.b.y, fmaf(K.V[2], e.g.y, K.V[0] * e.r.y));
         const float y = fmaf(K.V[5], e.b.y, fmaf(K.V[3], e.g.y, K.V[1] * e.r.y));
@@ -215,7 +231,7 @@ __device__ __forceinline__ void select_sweep_cube(const uint8_t* src, int P, int
         const float a2 = fmaf(K.u[1][1], y, fmaf(K.u[1][0], x, K.kt[1]));
         const float sa = fabsf(a1) + fabsf(a2);
         const bool g1 = fmaf(K.eps[0], sa, a1) >= K.thr[0], g2 = fmaf(K.eps[1], sa, a2) >= K.thr[1];
-        return (__builtin_amdgcn_ballot_w64(tc) & ~__builtin_amdgcn_ballot_w64(pp)) | __builtin_amdgcn_ballot_w64(g1) | __builtin_amdgcn_ballot_w64(g2);
+        return M2{__builtin_amdgcn_ballot_w64(tc) & ~__builtin_amdgcn_ballot_w64(pp), __builtin_amdgcn_ballot_w64(g1) | __builtin_amdgcn_ballot_w64(g2)};
     };
     auto ring_read = [&](uint32_t i) -> uint32_t {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -229,11 +245,8 @@ __device__ __forceinline__ void select_sweep_cube(const uint8_t* src, int P, int
             rn -= 128u;
             const uint32_t q0 = ring_read(rn + (uint32_t)lane), q1 = ring_read(rn + 64u + (uint32_t)lane);
             const G3 e0 = gather(q0), e1 = gather(q1);
-            const unsigned long long m0 = flags(e0), m1 = flags(e1);
-            const uint32_t n0 = (uint32_t)__popcll(m0), n1 = (uint32_t)__popcll(m1);
-            const uint32_t base = out.alloc(n0 + n1, lane);
-            out.store(m0, q0, base, lane);
-            out.store(m1, q1, base + n0, lane);
+            const M2 f0 = flags(e0), f1 = flags(e1);
+            out.put2(f0.a, f0.c, q0, f1.a, f1.c, q1, lane);
         }
     };
     auto pixel_mask = [&](uint32_t p) -> bool {
@@ -290,11 +303,8 @@ __device__ __forceinline__ void select_sweep_cube(const uint8_t* src, int P, int
         const uint32_t q0 = ring_read((uint32_t)lane), q1 = ring_read(64u + (uint32_t)lane);
         const G3 e0 = gather(q0 & 0xffffffu), e1 = gather(q1 & 0xffffffu);
         const unsigned long long l0 = __builtin_amdgcn_ballot_w64((uint32_t)lane < rn), l1 = __builtin_amdgcn_ballot_w64(64u + (uint32_t)lane < rn);
-        const unsigned long long m0 = flags(e0) & l0, m1 = flags(e1) & l1;
-        const uint32_t n0 = (uint32_t)__popcll(m0), n1 = (uint32_t)__popcll(m1);
-        const uint32_t base = out.alloc(n0 + n1, lane);
-        out.store(m0, q0, base, lane);
-        out.store(m1, q1, base + n0, lane);
+        const M2 f0 = flags(e0), f1 = flags(e1);
+        out.put2(f0.a & l0, f0.c & l0, q0, f1.a & l1, f1.c & l1, q1, lane);
         rn = 0;
     }
 }

@@ -23,6 +23,8 @@ struct FusedArgs {
     const double* maxC_tgt;  // transform only
     int cap_raw, cap_list;
     uint32_t* raw;           // [gridDim.x][cap_raw]
+    int cap_ang;             // Macenko: capacity of the angular candidate list the cube sweep fills beside `raw` (RawDirect)
+    uint32_t* raw_ang;       // [gridDim.x][cap_ang]
     float* cand;             // [gridDim.x][2][cap_list]
     uint32_t* sample;        // [gridDim.x][n_sample]
     double* M_out;           // [n_tiles][6]
@@ -49,7 +51,9 @@ struct FusedShared {
     uint32_t stage[NT / 64][kStageWave];     // 1 KB per wave
     SelScratch S;            // 4 KB aligned (LDS offset 72 KB): between the finish steps S.hist holds the colour-cube mask, whose base the
                              // cube sweep ORs into its addresses
-    unsigned int n_raw, overflow;
+    alignas(8) unsigned int n_raw;     // head of the tile's raw list ...
+    unsigned int n_ang;                // ... and, right behind it, of the angular list of the cube sweep: RawDirect advances both with one 64-bit atomic
+    unsigned int overflow;
     double red[NT / 64][32];
     double sum[32];
     DictIter it;
@@ -319,11 +323,14 @@ __device__ __noinline__ void fused_apply(FusedShared<NT>* shp, const uint8_t* sr
 // Sweep 2 behind the colour-cube mask, out of line like the finish steps: its registers are allocated apart from the other sweeps'
 // (the fused kernel sits at its 128-register limit; inlined, this sweep made the others spill).  Constants come from *shp.
 template <int NT, bool ALIGNED>
-__device__ __noinline__ void fused_sweep2_cube(FusedShared<NT>* shp, const uint8_t* src_, uint32_t* rawl_, int P_, int cap_raw_, float ylimf_, int stream_) {
+__device__ __noinline__ void fused_sweep2_cube(FusedShared<NT>* shp, const uint8_t* src_, uint32_t* rawl_, uint32_t* rawa_, int P_, int cap_raw_, int cap_ang_,
+                                               float ylimf_, int stream_) {
     FusedShared<NT>& sh = *shp;
     const uint8_t* src = uni_ptr(src_);
     uint32_t* rawl = uni_ptr(rawl_);
+    uint32_t* rawa = uni_ptr(rawa_);
     const int P = __builtin_amdgcn_readfirstlane(P_), cap_raw = __builtin_amdgcn_readfirstlane(cap_raw_), stream = __builtin_amdgcn_readfirstlane(stream_);
+    const int cap_ang = __builtin_amdgcn_readfirstlane(cap_ang_);
     const float ylimf = uni(ylimf_);
     const int tid = threadIdx.x, wave = tid >> 6;
     const TabReaderB TB = TabReaderB::make(sh.tab);
@@ -338,7 +345,8 @@ __device__ __noinline__ void fused_sweep2_cube(FusedShared<NT>* shp, const uint8
         K.eps[i] = in_vgpr(sh.mk.eps[i]); K.thr[i] = in_vgpr(sh.mk.thr[i]);
     }
     K.lo0 = uni(sh.lo[0]); K.hi0 = uni(sh.hi[0]); K.lo1 = uni(sh.lo[1]); K.hi1 = uni(sh.hi[1]);
-    const RawDirect direct{rawl, &sh.n_raw, (uint32_t)cap_raw};
+    static_assert(offsetof(FusedShared<NT>, n_ang) == offsetof(FusedShared<NT>, n_raw) + 4 && offsetof(FusedShared<NT>, n_raw) % 8 == 0, "");
+    const RawDirect direct{rawl, rawa, reinterpret_cast<unsigned long long*>(&sh.n_raw), (uint32_t)cap_raw, (uint32_t)cap_ang};
     static_assert(offsetof(FusedShared<NT>, S) % 4096 == 0 && offsetof(SelScratch, hist) == 0, "the cube mask must be 4 KB aligned");
     const uint32_t bits_lds = lds_address(sh.S.hist);
     const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(&sh.stage[wave][0]));
@@ -352,11 +360,13 @@ __device__ __noinline__ void fused_sweep2_cube(FusedShared<NT>* shp, const uint8
 // Finish 2 of the merged schedule for the tile whose state sits in *shp: returns the number of slow exact fallbacks.
 // Leaves sh.M, sh.status, sh.conc_done (and sh.maxC, sh.L when conc_done) behind and the row table rebuilt.
 template <int NT>
-__device__ __noinline__ int fused_finish2(FusedShared<NT>* shp, const uint8_t* src_, uint32_t* rawl_, float* cand0_, float* cand1_, int P_, int cap_raw_,
-                                          int cap_list_, float ylimf_, double pct_, double lam_, long long* subclk_) {
+__device__ __noinline__ int fused_finish2(FusedShared<NT>* shp, const uint8_t* src_, uint32_t* rawl_, uint32_t* rawa_, float* cand0_, float* cand1_, int P_,
+                                          int cap_raw_, int cap_ang_, int cap_list_, float ylimf_, double pct_, double lam_, long long* subclk_) {
     FusedShared<NT>& sh = *shp;
     const uint8_t* src = uni_ptr(src_);
     uint32_t* rawl = uni_ptr(rawl_);
+    uint32_t* rawa = uni_ptr(rawa_);                              // null: one mixed list (the per-pixel sweeps); else the cube sweep's angular list
+    const int cap_ang = __builtin_amdgcn_readfirstlane(cap_ang_);
     float* cand0 = uni_ptr(cand0_);
     float* cand1 = uni_ptr(cand1_);
     const int P = __builtin_amdgcn_readfirstlane(P_), cap_raw = __builtin_amdgcn_readfirstlane(cap_raw_), cap_list = __builtin_amdgcn_readfirstlane(cap_list_);
@@ -388,17 +398,22 @@ __device__ __noinline__ int fused_finish2(FusedShared<NT>* shp, const uint8_t* s
     for (int i = 0; i < 6; ++i) { tkey.V[i] = sh.Vf[i]; rkey.V[i] = sh.Vf[i]; }
     const bool complete = sh.n_raw <= (uint32_t)cap_raw && sh.overflow == 0;
     const uint32_t n_raw = sh.n_raw < (uint32_t)cap_raw ? sh.n_raw : (uint32_t)cap_raw;
+    // the list the angular pass reads: the cube sweep's own (every tissue pixel outside the plain cone), else the mixed one
+    const bool split = rawa != nullptr;                            // block-uniform
+    const bool complete_a = split ? sh.n_ang <= (uint32_t)cap_ang : complete;
+    const uint32_t n_a = split ? (sh.n_ang < (uint32_t)cap_ang ? sh.n_ang : (uint32_t)cap_ang) : n_raw;
+    const uint32_t* lista = split ? rawa : rawl;
     const float los[2] = {sh.lo[0], sh.lo[1]}, his[2] = {sh.hi[0], sh.hi[1]};
     SL_SUB(2);
-    const RefineOut ra = wg_refine_s(rawl, (int)n_raw, rkey, los[0], his[0], los[1], his[1], cand0, cand1, (uint32_t)cap_list, stage_lds,
+    const RefineOut ra = wg_refine_s(lista, (int)n_a, rkey, los[0], his[0], los[1], his[1], cand0, cand1, (uint32_t)cap_list, stage_lds,
                                      stage_entries, sh.S);
     SL_SUB(3);
     {
-        // plain = tissue pixels the sweep did not collect: they sit between the two brackets (the list also holds
-        // pixels collected for their concentrations; those with an angle key count like any other candidate)
+        // plain = tissue pixels the sweep did not collect as angular candidates: they sit between the two brackets (a mixed list
+        // also holds pixels collected for their concentrations; those with an angle key count like any other candidate)
         const long long lt[2] = {(long long)ra.n_lt[0], (long long)T - (long long)ra.n_valid + (long long)ra.n_lt[1]};
         float res[4];
-        stage_pick2<false>(cand0, cand1, ra.n_in, (uint32_t)cap_list, complete, los, his, lt, P, tkey, T, k, ra.ps, res, fallbacks, sh.S);
+        stage_pick2<false>(cand0, cand1, ra.n_in, (uint32_t)cap_list, complete_a, los, his, lt, P, tkey, T, k, ra.ps, res, fallbacks, sh.S);
         if (tid == 0) { sh.res[0] = res[0]; sh.res[1] = res[1]; sh.res[2] = res[2]; sh.res[3] = res[3]; }
         __syncthreads();
     }
@@ -433,7 +448,7 @@ __device__ __noinline__ int fused_finish2(FusedShared<NT>* shp, const uint8_t* s
 #ifdef SL_DEBUG_SUBCLK
         if (subclk && tid == 0) {             // list sizes beside the clocks, x 100: the tools scale by 0.01 (slots 8..11 are clocks only on the resweep path)
             long long* q = subclk;
-            q[8] = 100ll * ra.n_valid; q[9] = 100ll * n_raw; q[10] = 100ll * (ra.n_in[0] + ra.n_in[1]); q[11] = 100ll * (rc.n_in[0] + rc.n_in[1]);
+            q[8] = 100ll * n_a; q[9] = 100ll * n_raw; q[10] = 100ll * (ra.n_in[0] + ra.n_in[1]); q[11] = 100ll * (rc.n_in[0] + rc.n_in[1]);
         }
 #endif
         const long long n_plain = (long long)P - (long long)sh.n_raw;       // proven below both brackets
@@ -528,9 +543,9 @@ static __global__ __launch_bounds__(kMFinishThreads) void k_finish2m(StatsArgs a
             sh.maxC[0] = sh.maxC[1] = nan_d();
         }
         __syncthreads();
-        fallbacks = fused_finish2<kMFinishThreads>(&sh, a.rgb + (size_t)tile * a.P * 3, a.raw + (size_t)tile * a.cap_raw,
+        fallbacks = fused_finish2<kMFinishThreads>(&sh, a.rgb + (size_t)tile * a.P * 3, a.raw + (size_t)tile * a.cap_raw, nullptr,
                                                    a.cand + ((size_t)tile * 2 + 0) * a.cap_list, a.cand + ((size_t)tile * 2 + 1) * a.cap_list, a.P,
-                                                   a.cap_raw, a.cap_list, a.ylimf, a.pct, a.lam, nullptr);
+                                                   a.cap_raw, 0, a.cap_list, a.ylimf, a.pct, a.lam, nullptr);
         __syncthreads();
         const bool singular = sh.status == SL_TILE_DEGENERATE_COV;             // block-uniform
         const bool settled = sh.conc_done != 0 || singular;                    // nothing left for the concentration stage to do
@@ -581,13 +596,14 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
     const int nch = (a.P + 3) >> 2;
     uint32_t* samp = a.sample + (size_t)blockIdx.x * a.n_sample;
     uint32_t* rawl = a.raw + (size_t)blockIdx.x * a.cap_raw;
+    uint32_t* rawa = a.raw_ang + (size_t)blockIdx.x * a.cap_ang;
     float* cand0 = a.cand + ((size_t)blockIdx.x * 2 + 0) * a.cap_list;
     float* cand1 = a.cand + ((size_t)blockIdx.x * 2 + 1) * a.cap_list;
 
     const bool stream = (size_t)a.P * 3 >= kStreamBytes;       // non-temporal tile accesses (uniform; see kStreamBytes)
     // sweeps 2/3: out of line (fused_select / fused_sweep2_cube); plain count and raw candidates into sh.*
     auto run_select = [&](bool merged, const uint8_t* src) {
-        if (merged && (sh.use_cube & 1)) fused_sweep2_cube<NT, ALIGNED>(&sh, src, rawl, a.P, a.cap_raw, a.ylimf, stream ? 1 : 0);   // block-uniform
+        if (merged && (sh.use_cube & 1)) fused_sweep2_cube<NT, ALIGNED>(&sh, src, rawl, rawa, a.P, a.cap_raw, a.cap_ang, a.ylimf, stream ? 1 : 0);   // block-uniform
         else fused_select<NT, ALIGNED>(&sh, src, rawl, a.P, a.cap_raw, a.ylimf, stream ? 1 : 0, merged ? 1 : 0);
         __threadfence_block();
         __syncthreads();
@@ -660,7 +676,7 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
                 float Vf[6];
                 sh.status = eigvecs_from_moments(sh.sum, Vd, Vf);
                 for (int i = 0; i < 6; ++i) { sh.Vd[i] = Vd[i]; sh.Vf[i] = Vf[i]; }
-                sh.n_raw = 0; sh.overflow = 0;
+                sh.n_raw = 0; sh.n_ang = 0; sh.overflow = 0;
                 sh.conc_done = 0;
                 sh.use_cube = 0;
             }
@@ -684,7 +700,8 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
                 SL_PHASE(3);
                 // ---------------- finish 2 (out of line: its registers are allocated apart from the sweeps'): exact angular percentiles
                 // -> M, then the concentration percentiles -> maxC from the same raw list
-                fallbacks += fused_finish2<NT>(&sh, src, rawl, cand0, cand1, a.P, a.cap_raw, a.cap_list, a.ylimf, a.pct, a.lam,
+                fallbacks += fused_finish2<NT>(&sh, src, rawl, (sh.use_cube & 1) ? rawa : nullptr, cand0, cand1, a.P, a.cap_raw, a.cap_ang, a.cap_list, a.ylimf,
+                                               a.pct, a.lam,
 #ifdef SL_DEBUG_SUBCLK
                                                a.phase_clock ? a.phase_clock + (size_t)a.n_tiles * 8 + (size_t)tile * 16 : nullptr
 #else

@@ -513,6 +513,20 @@ def _prefilter_run(dev, Mt, mct, prefilter, **kw):
     return out, M, mc, st, fb, rsw, cub
 
 
+def _assert_prefilter_run_equal(ref, r, pf):
+    """Bytes, M, maxC and status identical.  Exact fallbacks and resweep reasons too, with one allowance: behind the mask the angular
+    candidates have a list of their own (RawDirect), so a tile whose MIXED list overflows -- both selections then take the slow exact
+    path, reason SL_RESWEEP_LIST_FULL -- may keep the fast paths.  Never the reverse."""
+    for k in range(6):
+        a, b = ref[k], r[k]
+        if k == 4:
+            assert bool((b <= a).all()), (pf, k, a.tolist(), b.tolist())
+        elif k == 5:
+            assert bool(((a == b) | (a == 4)).all()), (pf, k, a.tolist(), b.tolist())
+        else:
+            assert torch.equal(torch.nan_to_num(a.double(), nan=-7.0), torch.nan_to_num(b.double(), nan=-7.0)), (pf, k)
+
+
 # (503, 527): a pixel count that is not a multiple of four on a tile large enough for the streaming (non-temporal) instantiation of the
 # sweeps -- the combination on which an inlined candidate burst made the per-pixel sweep hang (round-4 soak)
 @pytest.mark.parametrize("h,w", [(128, 128), (96, 130), (33, 47), (256, 320), (1, 517), (503, 527)])
@@ -532,9 +546,7 @@ def test_prefilter_never_changes_a_result(h, w):
     assert (ref[6].cpu().numpy() == 0).all()                                        # prefilter off: no mask anywhere
     for pf in (2, 0):
         r = runs[pf]
-        for k in range(6):
-            a, b = ref[k], r[k]
-            assert torch.equal(torch.nan_to_num(a.double(), nan=-7.0), torch.nan_to_num(b.double(), nan=-7.0)), (pf, k)
+        _assert_prefilter_run_equal(ref, r, pf)
     used = runs[2][6].cpu().numpy()
     st = ref[3].cpu().numpy()
     assert (used[st == 1] == 0).all()                                               # an empty mask builds nothing
@@ -566,8 +578,7 @@ def test_prefilter_at_full_size_on_structured_and_real_tissue_tiles():
     dev = to_dev(tiles)
     runs = {pf: _prefilter_run(dev, Mt, mct, pf) for pf in (1, 2, 0)}
     for pf in (2, 0):
-        for k in range(6):
-            assert torch.equal(torch.nan_to_num(runs[1][k].double(), nan=-7.0), torch.nan_to_num(runs[pf][k].double(), nan=-7.0)), (pf, k)
+        _assert_prefilter_run_equal(runs[1], runs[pf], pf)
     auto, forced = runs[0][6].cpu().numpy(), runs[2][6].cpu().numpy()
     print("share of sample pixels in ambiguous cells (%):", (forced >> 8).tolist(), " automatic mode used the mask:", (auto & 1).tolist())
     assert (forced[:6] & 1).all()
