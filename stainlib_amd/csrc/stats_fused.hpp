@@ -73,6 +73,24 @@ struct FusedShared {
     MergedConc mk;
 };
 
+// Every kernel that owns a FusedShared block declares it as its ONLY __shared__ object, so the block starts at LDS address 0
+// (fused_lds_origin traps otherwise, once per workgroup).  The out-of-line phases receive the block as a generic pointer, from which
+// the compiler cannot know any member's LDS address: every table gather then pays a v_add for base + offset -- 3 per pixel in sweep 1
+// and in the apply sweep, measured in the ISA after the phases went out of line.  They use the constants below instead.
+template <int NT>
+struct FusedLds {
+    static constexpr uint32_t tab = 0u;
+    static constexpr uint32_t stage = (uint32_t)sizeof(RowTab);
+    static constexpr uint32_t stage_wave = 4u * (uint32_t)kStageWave;
+    static constexpr uint32_t hist = (uint32_t)(sizeof(RowTab) + sizeof(uint32_t) * (NT / 64) * kStageWave);
+};
+template <int NT>
+__device__ __forceinline__ void fused_lds_origin(const FusedShared<NT>& sh) {
+    static_assert(offsetof(FusedShared<NT>, tab) == FusedLds<NT>::tab && offsetof(FusedShared<NT>, stage) == FusedLds<NT>::stage &&
+                  offsetof(FusedShared<NT>, S) == FusedLds<NT>::hist && offsetof(SelScratch, hist) == 0, "");
+    if (lds_address(&sh) != 0u) __builtin_trap();
+}
+
 // wave-uniform values arrive in VGPRs at an out-of-line function: back to SGPRs
 template <class T>
 __device__ __forceinline__ T* uni_ptr(T* p) {
@@ -228,7 +246,7 @@ __device__ __noinline__ void fused_sweep1(FusedShared<NT>* shp, const uint8_t* s
     const int P = __builtin_amdgcn_readfirstlane(P_), stride_log2 = __builtin_amdgcn_readfirstlane(stride_log2_), stream = __builtin_amdgcn_readfirstlane(stream_);
     const float ylimf = uni(ylimf_);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const TabReaderB TB = TabReaderB::make(sh.tab);
+    const TabReaderB TB = TabReaderB::make_at(FusedLds<NT>::tab);
     const int nch = (P + 3) >> 2;
     Moments mo;
     uint32_t n_tissue = 0;
@@ -256,13 +274,13 @@ __device__ __noinline__ void fused_select(FusedShared<NT>* shp, const uint8_t* s
     const int merged = __builtin_amdgcn_readfirstlane(merged_);
     const float ylimf = uni(ylimf_);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const TabReaderB TB = TabReaderB::make(sh.tab);
+    const TabReaderB TB = TabReaderB::make_at(FusedLds<NT>::tab);
     const int nch = (P + 3) >> 2;
     int t, c0, c1;
     fused_geometry<NT>(nch, tid, t, c0, c1);
     SelConsts K;
     K.lo0 = uni(sh.lo[0]); K.hi0 = uni(sh.hi[0]); K.lo1 = uni(sh.lo[1]); K.hi1 = uni(sh.hi[1]);
-    RawSink sink{(uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(sh.stage[wave])), 0u, rawl, &sh.n_raw, &sh.overflow, (uint32_t)cap_raw,
+    RawSink sink{(uint32_t)__builtin_amdgcn_readfirstlane((int)(FusedLds<NT>::stage + (uint32_t)wave * FusedLds<NT>::stage_wave)), 0u, rawl, &sh.n_raw, &sh.overflow, (uint32_t)cap_raw,
                  (uint32_t)kStageWave};
     if (merged) {
         for (int i = 0; i < 6; ++i) K.V[i] = in_vgpr(sh.Vf[i]);
@@ -304,7 +322,7 @@ __device__ __noinline__ void fused_apply(FusedShared<NT>* shp, const uint8_t* sr
     const int P = __builtin_amdgcn_readfirstlane(P_), stream = __builtin_amdgcn_readfirstlane(stream_);
     const double lam = uni_d(lam_);
     const int tid = threadIdx.x;
-    const TabReaderB TB = TabReaderB::make(sh.tab);
+    const TabReaderB TB = TabReaderB::make_at(FusedLds<NT>::tab);
     const int nch = (P + 3) >> 2;
     ApplyK K;
     apply_consts(sh.M, sh.maxC, M_tgt, maxC_tgt, lam, K);
@@ -333,7 +351,7 @@ __device__ __noinline__ void fused_sweep2_cube(FusedShared<NT>* shp, const uint8
     const int cap_ang = __builtin_amdgcn_readfirstlane(cap_ang_);
     const float ylimf = uni(ylimf_);
     const int tid = threadIdx.x, wave = tid >> 6;
-    const TabReaderB TB = TabReaderB::make(sh.tab);
+    const TabReaderB TB = TabReaderB::make_at(FusedLds<NT>::tab);
     const int nch = (P + 3) >> 2;
     SelConsts K;
     for (int i = 0; i < 6; ++i) K.V[i] = in_vgpr(sh.Vf[i]);
@@ -348,8 +366,8 @@ __device__ __noinline__ void fused_sweep2_cube(FusedShared<NT>* shp, const uint8
     static_assert(offsetof(FusedShared<NT>, n_ang) == offsetof(FusedShared<NT>, n_raw) + 4 && offsetof(FusedShared<NT>, n_raw) % 8 == 0, "");
     const RawDirect direct{rawl, rawa, reinterpret_cast<unsigned long long*>(&sh.n_raw), (uint32_t)cap_raw, (uint32_t)cap_ang};
     static_assert(offsetof(FusedShared<NT>, S) % 4096 == 0 && offsetof(SelScratch, hist) == 0, "the cube mask must be 4 KB aligned");
-    const uint32_t bits_lds = lds_address(sh.S.hist);
-    const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(&sh.stage[wave][0]));
+    const uint32_t bits_lds = FusedLds<NT>::hist;
+    const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(FusedLds<NT>::stage + (uint32_t)wave * FusedLds<NT>::stage_wave));
     int t, c0, c1;
     fused_geometry<NT>(nch, tid, t, c0, c1);
     if (c0 >= c1) return;                                        // (a half without pixels: wave-uniform)
@@ -388,8 +406,8 @@ __device__ __noinline__ int fused_finish2(FusedShared<NT>* shp, const uint8_t* s
     percentile_pos((double)T, 100.0 - pct, k[0], gfrac[0]);
     percentile_pos((double)T, pct, k[1], gfrac[1]);
     fin_tab_build(sh.tab);                                        // the row table's space: one-copy table + member staging
-    const FinTab FT{lds_address(&sh.tab)};
-    const uint32_t stage_lds = lds_address(&sh.tab) + kFinTabBytes + (uint32_t)wave * fin_stage_bytes(NT);
+    const FinTab FT{FusedLds<NT>::tab};
+    const uint32_t stage_lds = FusedLds<NT>::tab + kFinTabBytes + (uint32_t)wave * fin_stage_bytes(NT);
     const uint32_t stage_entries = fin_stage_bytes(NT) / 8u;      // two lists per wave
     AngleTileKey tkey;
     tkey.src = src; tkey.tab = FT.view(); tkey.ylimf = ylimf;
@@ -487,6 +505,7 @@ __device__ __noinline__ int fused_finish2(FusedShared<NT>* shp, const uint8_t* s
 constexpr int kMFinishThreads = 1024;
 static __global__ __launch_bounds__(kMFinishThreads) void k_finish1m(StatsArgs a) {
     __shared__ FusedShared<kMFinishThreads> sh;
+    fused_lds_origin(sh);
     const int tile = blockIdx.x, tid = threadIdx.x;
     TileState& st = a.state[tile];
     sh.tab.fill_b();
@@ -525,6 +544,7 @@ static __global__ __launch_bounds__(kMFinishThreads) void k_finish1m(StatsArgs a
 static __global__ __launch_bounds__(kMFinishThreads) void k_finish2m(StatsArgs a, double* M_out, double* maxC_out, int32_t* status_out,
                                                                     int32_t* fallbacks_out, int tile0) {
     __shared__ FusedShared<kMFinishThreads> sh;
+    fused_lds_origin(sh);
     const int tile = blockIdx.x, tid = threadIdx.x;
     TileState& st = a.state[tile];
     TileMerged& tm = a.mstate[tile];
@@ -591,6 +611,7 @@ enum { kMethodMacenko = 0, kMethodVahadane = 1 };
 template <int METHOD, bool TRANSFORM, bool ALIGNED, int NT>
 static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
     __shared__ FusedShared<NT> sh;
+    fused_lds_origin(sh);
     const int tid = threadIdx.x;
     const TabReaderB TB = TabReaderB::make(sh.tab);       // the 8-byte {gamma, od32} rows serve every sweep
     const int nch = (a.P + 3) >> 2;

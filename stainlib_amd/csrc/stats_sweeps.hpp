@@ -44,16 +44,34 @@ struct BurstMoments {
 
 
 // Sample bookkeeping of one chunk row (64 chunks starting at the wave-uniform, 64-aligned chunk `row0`): the lane
-// whose chunk the draw selects stores pixel 0 or 3 of it.  Scalar hash, ~6 vector instructions per chunk.
-template <bool ALIGNED>
-__device__ __forceinline__ void sample_row(const Chunk& ch, int row0, int cc, int c1, int P, int cps_log2, uint32_t* samp) {
+// whose chunk the draw selects stores pixel 0 or 3 of it.  Everything that depends on the row alone is scalar (hash, draw, the
+// row's slot in the sample); a lane contributes its two constants (SampleLane), so a chunk costs one compare, one v_perm and the
+// predicated store -- 2 vector instructions where the per-lane form of rounds 1-3 (chunk index, mask, two compares, select, two
+// shifts, address) cost 9, i.e. 1.75 of sweep 1's 22 per pixel (ISA count, round 4).  The stored words are the same.
+struct SampleLane {
+    uint32_t lm;        // lane & (cmask & 63): compared with the draw's low bits
+    uint32_t idx;       // lane >> cps_log2 (0 when a sampling block spans whole rows): the lane's slot relative to the row's
+    __device__ __forceinline__ static SampleLane make(int lane, int cps_log2) {
+        const uint32_t cmask = (1u << cps_log2) - 1u;
+        return SampleLane{(uint32_t)lane & cmask & 63u, cps_log2 <= 6 ? (uint32_t)lane >> cps_log2 : 0u};
+    }
+};
+template <bool ALIGNED, bool TAIL>
+__device__ __forceinline__ void sample_row(const Chunk& ch, int row0, int lane, const SampleLane& sl, int c1, int P, int cps_log2, uint32_t* samp) {
     const uint32_t h = sample_hash((uint32_t)row0 >> sample_group_shift(cps_log2));
     const uint32_t cmask = (1u << cps_log2) - 1u;
     const uint32_t sel = (h >> 8) & cmask;
     const bool last = (h >> 31) != 0;                                  // uniform: pixel 3 instead of pixel 0
-    if (samp && ((cc < c1) & (((uint32_t)cc & cmask) == sel))) {
-        const uint32_t v = (last ? ch.w2 : ch.w0) >> (last ? 8 : 0);   // stray top byte for pixel 0: readers ignore it
-        if (ALIGNED || (size_t)cc * 4 + (last ? 3 : 0) < (size_t)P) samp[(uint32_t)cc >> cps_log2] = v;
+    const bool row_hit = ((((uint32_t)row0 ^ sel) & cmask) >> 6) == 0u;   // uniform: the draw falls into this row (always, up to 64 chunks per block)
+    if (samp && row_hit && sl.lm == (sel & 63u)) {
+        // pixel 0: w0 as it is (stray top byte: readers ignore it); pixel 3: w2 >> 8 -- one v_perm with a uniform selector
+        const uint32_t v = __builtin_amdgcn_perm(ch.w2, ch.w0, last ? 0x0c070605u : 0x03020100u);
+        bool ok = true;
+        if (TAIL) {
+            const int cc = row0 + lane;
+            ok = (cc < c1) & (ALIGNED | ((size_t)cc * 4 + (last ? 3 : 0) < (size_t)P));
+        }
+        if (ok) samp[((uint32_t)row0 >> cps_log2) + sl.idx] = v;
     }
 }
 
@@ -67,6 +85,7 @@ __device__ __forceinline__ void moments_sweep_b(const uint8_t* src, int P, int c
     const size_t nbytes = (size_t)P * 3;
     const int lane = t & 63;
     const int cps_log2 = stride_log2 - 2;          // chunks per sampling block
+    const SampleLane slane = SampleLane::make(lane, cps_log2);
     const int w0 = __builtin_amdgcn_readfirstlane(c0 + (t & ~63));
     struct G { float2 v[12]; };
     auto fetch = [&](int cc) { return load_chunk_clamped<ALIGNED, STREAM>(src, nbytes, cc, c1); };
@@ -101,7 +120,7 @@ __device__ __forceinline__ void moments_sweep_b(const uint8_t* src, int P, int c
     g[0] = gather(cur[0]);
     auto trip = [&](auto tail_tag, int cb) {
 #pragma unroll
-        for (int k = 0; k < kTrip; ++k) sample_row<ALIGNED>(cur[k], cb + k * nthreads, cb + k * nthreads + lane, c1, P, cps_log2, samp);
+        for (int k = 0; k < kTrip; ++k) sample_row<ALIGNED, decltype(tail_tag)::value>(cur[k], cb + k * nthreads, lane, slane, c1, P, cps_log2, samp);
 #pragma unroll
         for (int k = 0; k < kTrip; ++k) {
             if (k + 1 < kTrip) {
