@@ -251,11 +251,15 @@ def test_random_tiles_through_the_vahadane_fit_against_the_converged_oracle():
         assert (M >= 0).all() and M[0, 0] >= M[1, 0], label
         err = float(np.abs(M - Mo).max())
         # flat optima (two stains nearly collinear in a small window) move the minimiser far for a 1e-9 change of the objective:
-        # the distance bar applies where the two atoms are separated
-        if obj(M) > obj(Mo) + 1e-9 or (float(Mo[0] @ Mo[1]) < 0.98 and err >= 1e-5):
+        # the distance bar applies where the two atoms are separated -- and where both descents ended in the same basin: the
+        # problem is not convex, and on a window of ~1 000 pixels the kernel's path (sample stage first) now and then ends in a
+        # DIFFERENT stationary point with a clearly lower objective than the oracle's (seed 23, case 184: 0.2021 against 0.2048 on a
+        # 37 x 33 window).  That passes the certificate; its distance from the oracle's point says nothing.
+        better_basin = obj(M) < obj(Mo) - 1e-6
+        if obj(M) > obj(Mo) + 1e-9 or (float(Mo[0] @ Mo[1]) < 0.98 and err >= 1e-5 and not better_basin):
             failures.append((label, obj(M), obj(Mo), err, int(sweeps[0])))
             continue
-        worst = max(worst, err)
+        worst = worst if better_basin else max(worst, err)
         out, M2, mc2, st2 = engine.vahadane_transform(dev, Mt, mct, params=p)
         assert int(st2[0]) == 0, label
         np.testing.assert_array_equal(M2.cpu().numpy()[0], M, err_msg=label)
