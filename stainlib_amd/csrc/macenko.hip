@@ -403,7 +403,9 @@ extern "C" int sl_macenko_fit(const uint8_t* rgb, int n, int h, int w, const SlP
                               void* stream) {
     const long P = (long)h * w;
     const MacenkoPlan pl = (n > 0 && h > 0 && w > 0) ? plan_macenko(n, P, params ? params->schedule : 0, params ? params->fused_min_tiles : 0) : MacenkoPlan{};
-    int rc = check_common(rgb, n, h, w, workspace, workspace_bytes, pl.total);
+    // the documented requirement, not this plan's own need (a schedule may need less: the per-phase one has no angular list): a workspace
+    // smaller than sl_workspace_bytes() is refused whatever SlParams selects
+    int rc = check_common(rgb, n, h, w, workspace, workspace_bytes, (n > 0 && h > 0 && w > 0) ? sl_workspace_bytes(SL_OP_MACENKO_TRANSFORM, n, h, w) : 0);
     if (rc) return rc;
     SlParams p;
     sl_default_params(&p);
@@ -421,7 +423,9 @@ extern "C" int sl_macenko_transform(const uint8_t* rgb, uint8_t* out, int n, int
                                     void* stream) {
     const long P = (long)h * w;
     const MacenkoPlan pl = (n > 0 && h > 0 && w > 0) ? plan_macenko(n, P, params ? params->schedule : 0, params ? params->fused_min_tiles : 0) : MacenkoPlan{};
-    int rc = check_common(rgb, n, h, w, workspace, workspace_bytes, pl.total);
+    // the documented requirement, not this plan's own need (a schedule may need less: the per-phase one has no angular list): a workspace
+    // smaller than sl_workspace_bytes() is refused whatever SlParams selects
+    int rc = check_common(rgb, n, h, w, workspace, workspace_bytes, (n > 0 && h > 0 && w > 0) ? sl_workspace_bytes(SL_OP_MACENKO_TRANSFORM, n, h, w) : 0);
     if (rc) return rc;
     if (!out || !M_tgt || !maxC_tgt) return SL_ERR_BADARG;
     SlParams p;
