@@ -545,7 +545,7 @@ def hed2rgb(hed: np.ndarray, mode: str = "0.18") -> np.ndarray:
     return np.clip(np.exp(log_rgb), 0, 1)
 
 
-def hed_transform(patch: np.ndarray, sigmas, biases, cutoff=(0.05, 0.95), mode="0.18"):
+def hed_transform(patch: np.ndarray, sigmas, biases, cutoff=(0.05, 0.95), mode="0.18", details=None):
     """HedColorAugmenter.transform, augmenter.py:276-331 (uint8 and float inputs)."""
     if patch.dtype.kind == "f":
         patch_mean = np.mean(patch)                                              # :289
@@ -561,6 +561,8 @@ def hed_transform(patch: np.ndarray, sigmas, biases, cutoff=(0.05, 0.95), mode="
             hed[:, :, c] += biases[c]
     rgb = np.clip(hed2rgb(hed, mode), 0.0, 1.0)                                  # :319-320
     if patch.dtype.kind != "f":
+        if details is not None:
+            details.update(prequant=rgb * 255.0)                                 # (tests: the values the cast truncates)
         rgb = (rgb * 255.0).astype(np.uint8)                                     # :324-325
     return rgb
 
@@ -589,7 +591,7 @@ class StainAugmentor:
         self.n_stains = 2
         self.tissue_mask = tissue_mask(I).ravel()                                # :426
 
-    def pop_with(self, alphas, betas):
+    def pop_with(self, alphas, betas, details=None):
         C = self.source_concentrations.copy()                                    # :433
         for i in range(2):
             if self.augment_background:
@@ -598,6 +600,8 @@ class StainAugmentor:
                 C[self.tissue_mask, i] = C[self.tissue_mask, i] * alphas[i] + betas[i]  # :442-443
         out = 255 * np.exp(-1 * np.dot(C, self.stain_matrix))                    # :445
         out = out.reshape(self.image_shape)
+        if details is not None:
+            details.update(prequant=np.clip(out, 0, 255))                        # (tests: the values the cast truncates)
         return np.clip(out, 0, 255).astype(np.uint8)                             # :447
 
     def pop(self):
