@@ -131,10 +131,10 @@ typedef struct SlParams {
                                    Written by the fused schedule of sl_macenko_*; left untouched otherwise. */
     int32_t fused_min_tiles;    /* schedule == 0 only: batches of at least this many tiles run the persistent fused kernel, smaller ones
                                    one launch per phase.  0 (default) = the library's measured crossovers on an MI355X at its 1400 W
-                                   power state (tools/crossover.py, profiles/r03_crossover*.txt): Macenko 416 tiles (352 for tiles below 512 Ki
+                                   power state (tools/crossover.py, profiles/r04_crossover*.txt): Macenko 352 tiles (320 for tiles below 512 Ki
                                    pixels, 288 up to 256 Ki), Vahadane 640 (192 below 512 Ki pixels; 704 when the batch exceeds one resident grid).  A Macenko batch larger than the fused
                                    kernel's resident grid (2 x compute units) is split: whole fused rounds, and a remainder below this
-                                   number of tiles one launch per phase (default: 416 / 224 / 192 tiles by the same tile sizes, never for
+                                   number of tiles one launch per phase (default: 208 / 224 / 192 tiles by the same tile sizes, never for
                                    tiles up to 64 Ki pixels).  Results do not depend on the schedule. */
     int32_t prefilter;          /* the colour-cube pre-filter of the fused Macenko kernel's selection sweep (a 32^3-cell mask of colours that are
                                    provably "plain", built per tile by finish 1; pixels of the other cells are re-tested exactly):

@@ -20,18 +20,20 @@ constexpr size_t kGroupBytes = (size_t)2 << 30;   // uint8 bytes of one tile gro
 // launch per phase wins.  1024^2 tiles: 1.11 vs 1.14 ms at 256, 1.64 vs 1.52 at 384.  Smaller tiles cross earlier (the per-phase launches
 // of more than 256 tiles split into two groups' worth of finish launches): 512^2 0.42 vs 0.47 ms at 256 tiles, 0.58 vs 0.56 at 320, 0.64 vs
 // 0.57 at 384; 256^2 0.235 vs 0.232 at 256, 0.35 vs 0.28 at 320; 700^2 0.78 vs 0.83 at 320, 0.87 vs 0.83 at 384.
-constexpr int kFusedMinTiles = 416;         // tiles of 512 Ki pixels and more
-constexpr int kFusedMinTilesMid = 352;      // 256 Ki < pixels < 512 Ki
+// Round 4 (the fused kernel 10 % faster, the per-phase kernels as they were; profiles/r04_crossover*.txt): 1024^2 1.330 vs 1.371 ms at 320 tiles,
+// 1.500 vs 1.401 at 384 -> 352; 700^2 0.815 vs 0.783 at 320 -> 320; 512^2 unchanged (0.386 vs 0.391 at 256, 0.548 vs 0.496 at 320).
+constexpr int kFusedMinTiles = 352;         // tiles of 512 Ki pixels and more (round 3: 416)
+constexpr int kFusedMinTilesMid = 320;      // 256 Ki < pixels < 512 Ki (round 3: 352)
 constexpr int kFusedMinTilesSmall = 288;    // up to 256 Ki pixels
 // The automatic split of a batch beyond the resident grid (plan_macenko): the remainder goes per phase when it is below these.  For small
 // tiles a second, partly empty fused round overlaps the first one's tail and the split pays only for short remainders (512^2, 640 tiles:
 // 0.91 split vs 0.97 fused, 768 tiles: 1.03 vs 0.98; 256^2: never).
-constexpr int kSplitMaxRest = 416, kSplitMaxRestMid = 224, kSplitMaxRestSmall = 192, kSplitMaxRestTiny = 0;   // tiny: up to 64 Ki pixels
+constexpr int kSplitMaxRest = 208 /* round 4: 1024^2, 768 tiles 2.58 split vs 2.49 fused (remainder 256), 640 tiles 2.20 vs 2.37 (remainder 128); was 416 */, kSplitMaxRestMid = 224, kSplitMaxRestSmall = 192, kSplitMaxRestTiny = 0;   // tiny: up to 64 Ki pixels
 inline int fused_min_default(long P) { return P >= (1L << 19) ? kFusedMinTiles : P > (1L << 18) ? kFusedMinTilesMid : kFusedMinTilesSmall; }
 inline int split_max_rest(long P) {
     return P >= (1L << 19) ? kSplitMaxRest : P > (1L << 18) ? kSplitMaxRestMid : P > (1L << 16) ? kSplitMaxRestSmall : kSplitMaxRestTiny;
 }
-constexpr int kWideMinTiles = 208;          // Macenko, tiles of 256 Ki pixels and more: from here to #CU tiles the 1024-thread fused kernel (1024^2: 192 tiles 0.818 vs 0.798 ms per phase, 224: 0.858 vs 0.881, 256: 0.915 vs 0.974)
+constexpr int kWideMinTiles = 192;          // (round 4, final tree: 192 tiles 0.788 vs 0.815 ms per phase, 160: 0.761 vs 0.709; was 208) Macenko, tiles of 256 Ki pixels and more: from here to #CU tiles the 1024-thread fused kernel (1024^2: 192 tiles 0.818 vs 0.798 ms per phase, 224: 0.858 vs 0.881, 256: 0.915 vs 0.974)
 constexpr int kDictFusedMinTiles = 640;     // Vahadane: below it the dictionary sweeps run one launch per phase too (measured: 1024^2 tiles 3.70 vs
                                             // 3.85 ms at 512, 6.24 vs 5.76 at 768; in a fused launch of one tile per workgroup the few tiles
                                             // that need a third full sweep hold the whole launch, per phase they cost a short extra launch)

@@ -1,5 +1,5 @@
 """Fused vs one-launch-per-phase schedule by batch and tile size, Macenko and Vahadane, with the automatic schedule beside them (where the
-switch and the split of a batch beyond the resident grid should sit).  python tools/crossover.py [methods] [sizes]"""
+switch and the split of a batch beyond the resident grid should sit).  python tools/crossover.py [methods] [sizes] [batch sizes]"""
 import sys, time, torch
 sys.path.insert(0, ".")
 from stainlib_amd import engine
@@ -11,7 +11,8 @@ sizes = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1024
 for method in methods:
     fn = engine.macenko_transform if method == "macenko" else engine.vahadane_transform
     for size in sizes:
-        for n in (16, 32, 64, 96, 128, 160, 192, 224, 256, 320, 384, 448, 512, 640, 768, 1024):
+        counts = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else (16, 32, 64, 96, 128, 160, 192, 224, 256, 320, 384, 448, 512, 640, 768, 1024)
+        for n in counts:
             rgb = synth_tiles(n, size, size, seed=3)
             out = torch.empty_like(rgb)
             r = []
