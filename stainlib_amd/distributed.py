@@ -357,6 +357,14 @@ class SlideNormalizer:
         self.group = group
         self.mode = mode
 
+    def _targets(self, device):
+        """The normalizer's 8 target doubles for the apply pass: its cached device tensors where it has them (uploaded once per fit; as
+        numpy arguments they are two small pageable copies per call), else the public attributes as they are."""
+        cached = getattr(self.normalizer, "_target_on", None)
+        if cached is not None:
+            return cached(device)
+        return self.normalizer.stain_matrix_target, self.normalizer.maxC_target.reshape(2)
+
     def transform_shard(self, tiles_local: torch.Tensor, out: Optional[torch.Tensor] = None, n_tiles_total: Optional[int] = None):
         """tiles_local: this rank's (n_local,H,W,3) uint8 device tensor.  Returns (out, M_slide, maxC_slide, status_local).
         n_tiles_total (pooled mode, optional): the slide's tile count over all ranks; saves the one tiny all-reduce that otherwise
@@ -376,7 +384,7 @@ class SlideNormalizer:
             state = stats.enqueue(tiles_local, n_tiles_total=n_tiles_total)
             M_s = state[_ffi.POOL_M:_ffi.POOL_M + 6].reshape(2, 3)
             maxC_s = state[_ffi.POOL_MAXC:_ffi.POOL_MAXC + 2]
-            Mt, mct = self.normalizer.stain_matrix_target, self.normalizer.maxC_target.reshape(2)
+            Mt, mct = self._targets(dev)
             out = engine.normalize_apply(tiles_local, M_s.expand(n, 2, 3).contiguous(), maxC_s.expand(n, 2).contiguous(), Mt, mct, out=out)
             got = stats.finish(state)
             if got is None:
@@ -392,6 +400,6 @@ class SlideNormalizer:
         M_all, maxC_all, st_all = gather_tile_stats(M, maxC, status, self.group)
         M_s, maxC_s = slide_statistics(M_all, maxC_all, st_all)
         n = tiles_local.shape[0]
-        out = engine.normalize_apply(tiles_local, M_s.expand(n, 2, 3).contiguous(), maxC_s.expand(n, 2).contiguous(),
-                                     self.normalizer.stain_matrix_target, self.normalizer.maxC_target.reshape(2), out=out)
+        Mt, mct = self._targets(tiles_local.device)
+        out = engine.normalize_apply(tiles_local, M_s.expand(n, 2, 3).contiguous(), maxC_s.expand(n, 2).contiguous(), Mt, mct, out=out)
         return out, M_s, maxC_s, status
