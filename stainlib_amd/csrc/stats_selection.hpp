@@ -173,6 +173,8 @@ __device__ unsigned long long g_bclk[16];      // development aid: wall-clock ti
 #else
 #define SL_BCLK(j)
 #endif
+__device__ __forceinline__ void wave_locate(const uint32_t* hist, int nb, uint32_t k, uint32_t* out, int lane);   // (below)
+constexpr int kLocateOut = 40;          // S.misc[kLocateOut + 3 i]: {bin, below, in bin} of rank i (wg_brackets_regs; slots 40..51)
 template <int NSETS, int KPT, int NBR>
 __device__ __forceinline__ void wg_brackets_regs(const uint32_t (&ord)[NSETS][KPT], const int (&set_of)[NBR],
                                                  const double (&pct)[NBR], float* lo, float* hi, SelScratch& S, float z = kBracketZ) {
@@ -228,7 +230,8 @@ __device__ __forceinline__ void wg_brackets_regs(const uint32_t (&ord)[NSETS][KP
         s1[s] = (nv[s] == 0 || R < 1024u) ? 0 : (32 - __clz(R) - 10);
         if (nv[s] == 0) continue;                            // block-uniform
         const int nb1 = (int)(R >> s1[s]) + 1;
-        for (int i = threadIdx.x; i < nb1; i += blockDim.x) S.hist[i] = 0;
+        const int nb1r = (nb1 + 63) & ~63;                   // wave_locate reads whole multiples of 64 bins
+        for (int i = threadIdx.x; i < nb1r; i += blockDim.x) S.hist[i] = 0;
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < KPT; ++j) {
@@ -237,14 +240,21 @@ __device__ __forceinline__ void wg_brackets_regs(const uint32_t (&ord)[NSETS][KP
         }
         __syncthreads();
         SL_BCLK(1);
+        // the set's ranks located side by side, one wave each (round 4: were four whole-workgroup rounds of wave 0 + barrier)
+        {
+            const int wave = (int)(threadIdx.x >> 6), nwaves = (int)(blockDim.x >> 6), lane = (int)(threadIdx.x & 63);
 #pragma unroll
-        for (int i = 0; i < 2 * NBR; ++i) {
-            if (set_of[i >> 1] != s) continue;
-            wg_locate(S.hist, nb1, rank[i], S.misc);
-            wlo[i] = omin[s] + (S.misc[0] << s1[s]);
-            const uint32_t span = s1[s] ? ((1u << s1[s]) - 1u) : 0u;
-            whi[i] = (omax[s] - wlo[i]) < span ? omax[s] : wlo[i] + span;
-            below[i] = S.misc[1];
+            for (int i = 0; i < 2 * NBR; ++i)
+                if (set_of[i >> 1] == s && (i % nwaves) == wave) wave_locate(S.hist, nb1r, rank[i], S.misc + kLocateOut + 3 * i, lane);
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 2 * NBR; ++i) {
+                if (set_of[i >> 1] != s) continue;
+                wlo[i] = omin[s] + (S.misc[kLocateOut + 3 * i] << s1[s]);
+                const uint32_t span = s1[s] ? ((1u << s1[s]) - 1u) : 0u;
+                whi[i] = (omax[s] - wlo[i]) < span ? omax[s] : wlo[i] + span;
+                below[i] = S.misc[kLocateOut + 3 * i + 1];
+            }
             __syncthreads();
         }
     }
@@ -270,16 +280,24 @@ __device__ __forceinline__ void wg_brackets_regs(const uint32_t (&ord)[NSETS][KP
         }
         __syncthreads();
         SL_BCLK(3);
+        {
+            const int wave = (int)(threadIdx.x >> 6), nwaves = (int)(blockDim.x >> 6), lane = (int)(threadIdx.x & 63);
 #pragma unroll
-        for (int i = 0; i < 2 * NBR; ++i) {
-            const int s = set_of[i >> 1];
-            if (!(nv[s] > 0 && s1[s] > 0)) continue;
-            const int s2 = s1[s] > 8 ? s1[s] - 8 : 0;
-            wg_locate(S.hist + i * 256, 256, rank[i] - below[i], S.misc);
-            const uint32_t nlo = wlo[i] + (S.misc[0] << s2);
-            const uint32_t span = s2 ? ((1u << s2) - 1u) : 0u;
-            whi[i] = (whi[i] - nlo) < span ? whi[i] : nlo + span;
-            wlo[i] = nlo;
+            for (int i = 0; i < 2 * NBR; ++i) {
+                const int s = set_of[i >> 1];
+                if (nv[s] > 0 && s1[s] > 0 && (i % nwaves) == wave) wave_locate(S.hist + i * 256, 256, rank[i] - below[i], S.misc + kLocateOut + 3 * i, lane);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 2 * NBR; ++i) {
+                const int s = set_of[i >> 1];
+                if (!(nv[s] > 0 && s1[s] > 0)) continue;
+                const int s2 = s1[s] > 8 ? s1[s] - 8 : 0;
+                const uint32_t nlo = wlo[i] + (S.misc[kLocateOut + 3 * i] << s2);
+                const uint32_t span = s2 ? ((1u << s2) - 1u) : 0u;
+                whi[i] = (whi[i] - nlo) < span ? whi[i] : nlo + span;
+                wlo[i] = nlo;
+            }
             __syncthreads();
         }
     }
