@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SL_VERSION 400 /* 0.4.0: SlParams.reserved_ became prefilter, SlParams grew (prefilter_out); 0.3.0: fused_min_tiles, sl_pool_*, resweeps_out carries reasons */
+#define SL_VERSION 500 /* 0.5.0: SlParams starts with struct_size (checked by every entry point), two_sweep / twosweep_out; 0.4.0: prefilter, prefilter_out; 0.3.0: fused_min_tiles, sl_pool_*, resweeps_out carries reasons */
 
 /* The library is built with -fvisibility=hidden: exactly the functions declared here are exported. */
 #if defined(__GNUC__)
@@ -107,7 +107,18 @@ typedef struct SlProfile {
 #define SL_RESWEEP_OUTSIDE_BOX 2    /* the exact stain matrix fell outside the box the sweep assumed */
 #define SL_RESWEEP_BRACKET_MISSED 3 /* a concentration bracket did not hold the wanted rank */
 #define SL_RESWEEP_LIST_FULL 4      /* the candidate list overflowed */
+/* what became of a tile's two-sweep attempt (SlParams.twosweep_out) */
+#define SL_TWOSWEEP_DIRECT 1        /* the tile's stain matrix came out of two read sweeps (moments + candidates in one, then the apply pass) */
+#define SL_TWOSWEEP_OFF 0           /* not attempted (SlParams.two_sweep == 1, or a schedule without it) */
+#define SL_TWOSWEEP_NO_ESTIMATE (-1) /* the cluster sample gave no usable estimate (few tissue entries, an ill-defined plane, open brackets) */
+#define SL_TWOSWEEP_SHARE (-2)      /* too many of the sample's pixels in colour-cube cells the mask could not prove plain: not worth it */
+#define SL_TWOSWEEP_PLANE (-3)      /* the exact eigenvector plane left the tilt the sweep allowed for: three-sweep route from the exact moments */
+#define SL_TWOSWEEP_BRACKET (-4)    /* an angular bracket carried over from the estimate missed its rank (or a list overflowed): likewise */
 typedef struct SlParams {
+    uint32_t struct_size;        /* sizeof(SlParams) of the header the CALLER was compiled against: set by sl_default_params, checked by every
+                                    entry point that takes an SlParams (SL_ERR_BADARG on a mismatch) -- a caller built against another
+                                    version of this struct is refused instead of being read past its end */
+    uint32_t reserved0;
     double luminosity_threshold; /* 0.8  (binary64 like the Python float the reference compares with) */
     double angular_percentile;   /* 99   */
     double lasso_lambda;        /* 0.01 */
@@ -144,6 +155,15 @@ typedef struct SlParams {
                                    bits 8.. the share (percent) of the tile's sample pixels that fell into cells the mask could not
                                    prove plain (0 when no mask was built; diagnostics).  Written by the fused schedule of sl_macenko_*;
                                    left untouched otherwise. */
+    int32_t two_sweep;          /* the two-read-sweep schedule of the fused Macenko kernel (the candidates of all four order statistics are
+                                   collected in the moments sweep, under eigenvectors estimated from a cluster sample gathered before it, and
+                                   the finish verifies the estimate against the exact eigenvectors; a tile that fails takes the three-sweep
+                                   route): 0 (default) = per tile, wherever the sample says it pays; 1 = never; 2 = wherever an estimate
+                                   exists (tests); 3 = as 2 with the verification forced to fail, 4 = as 2 with the sample's plane tilted
+                                   (tests of the fallback).  Results do not depend on it. */
+    int32_t reserved1;
+    int32_t* twosweep_out;      /* NULL (default) or DEVICE pointer to n ints: SL_TWOSWEEP_* per tile (diagnostics).  Written by the fused
+                                   schedule of sl_macenko_*; left untouched otherwise. */
 } SlParams;
 
 SL_API int sl_version(void);

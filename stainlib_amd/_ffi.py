@@ -33,6 +33,8 @@ PROF_NAMES = {1: "k_moments", 2: "k_select<merged>", 4: "k_select<conc>", 8: "k_
 
 class SlParams(C.Structure):
     _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("reserved0", C.c_uint32),
         ("luminosity_threshold", C.c_double),
         ("angular_percentile", C.c_double),
         ("lasso_lambda", C.c_double),
@@ -46,6 +48,9 @@ class SlParams(C.Structure):
         ("fused_min_tiles", C.c_int32),
         ("prefilter", C.c_int32),
         ("prefilter_out", C.c_void_p),
+        ("two_sweep", C.c_int32),
+        ("reserved1", C.c_int32),
+        ("twosweep_out", C.c_void_p),
     ]
 
 

@@ -29,6 +29,7 @@ extern "C" int sl_stain_augment(const uint8_t* rgb, uint8_t* out, int n, int h, 
     if (!rgb || !out || !M || !alpha_beta || n <= 0 || h <= 0 || w <= 0) return SL_ERR_BADARG;
     SlParams p;
     sl_default_params(&p);
+    if (!params_ok(params)) return SL_ERR_BADARG;
     if (params) p = *params;
     const long P = (long)h * w;
     if (P > (1L << 30)) return SL_ERR_BADARG;

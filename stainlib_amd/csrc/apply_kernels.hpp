@@ -18,6 +18,7 @@ namespace sl {
 // its store goes byte by byte.  No predicated load anywhere (see load_chunk_clamped).
 struct __attribute__((packed, aligned(1))) ChunkU { uint32_t w0, w1, w2; };
 typedef uint32_t sl_u32x3 __attribute__((ext_vector_type(3)));      // (16 bytes wide: never do pointer arithmetic on it)
+typedef uint32_t sl_u32x3u __attribute__((ext_vector_type(3), aligned(1)));   // the same at any byte address
 // STREAM = non-temporal accesses.  The fused kernel turns them on for tiles of kStreamBytes or more: every sweep streams
 // the tile once and nothing is re-read before 3 MB x 512 workgroups have passed through the caches (measured at 1024^2:
 // +2.5 %, the stores alone +0.5 %); smaller tiles stay cacheable -- a 256^2 tile (192 KB) is re-read by the next sweep
@@ -28,10 +29,11 @@ template <bool ALIGNED, bool STREAM = false>
 __device__ __forceinline__ Chunk load_chunk(const uint8_t* tile, size_t nbytes, int c) {
     if (ALIGNED) {
         if (STREAM) {
-            const sl_u32x3 t = __builtin_nontemporal_load(reinterpret_cast<const sl_u32x3*>(tile + (size_t)c * 12));
+            const sl_u32x3 t = __builtin_nontemporal_load((SL_GLOBAL const sl_u32x3*)(as_global(tile) + (size_t)c * 12));
             return Chunk{t.x, t.y, t.z};
         }
-        return reinterpret_cast<const Chunk*>(tile)[c];
+        const sl_u32x3 t = *(SL_GLOBAL const sl_u32x3*)(as_global(tile) + (size_t)c * 12);
+        return Chunk{t.x, t.y, t.z};
     } else {
         const size_t base = (size_t)c * 12;
         if (nbytes < 12) {                                   // a tile of fewer than 4 pixels (uniform)
@@ -39,14 +41,15 @@ __device__ __forceinline__ Chunk load_chunk(const uint8_t* tile, size_t nbytes, 
 #pragma unroll
             for (int i = 0; i < 12; ++i) {
                 const size_t at = base + i < nbytes - 1 ? base + i : nbytes - 1;
-                const uint32_t b = tile[at];
+                const uint32_t b = as_global(tile)[at];
                 w[i >> 2] |= (base + i < nbytes ? b : 0u) << (8 * (i & 3));
             }
             return Chunk{w[0], w[1], w[2]};
         }
         const size_t lim = nbytes - 12;
         const size_t at = base < lim ? base : lim;
-        const ChunkU u = *reinterpret_cast<const ChunkU*>(tile + at);
+        const sl_u32x3u uv = *(SL_GLOBAL const sl_u32x3u*)(as_global(tile) + at);
+        const ChunkU u{uv.x, uv.y, uv.z};
         const uint32_t d = (uint32_t)(base - at);            // 0 except for a ragged last chunk (1..11 bytes too early)
         const uint32_t step = d >> 2, sh = 8u * (d & 3u);
         const uint32_t a0 = step == 0 ? u.w0 : (step == 1 ? u.w1 : u.w2);
@@ -73,18 +76,19 @@ __device__ __forceinline__ void store_chunk(uint8_t* tile, size_t nbytes, int c,
     if (ALIGNED) {
         if (STREAM) {
             sl_u32x3 t; t.x = v.w0; t.y = v.w1; t.z = v.w2;
-            __builtin_nontemporal_store(t, reinterpret_cast<sl_u32x3*>(tile + (size_t)c * 12));
+            __builtin_nontemporal_store(t, (SL_GLOBAL sl_u32x3*)(as_global(tile) + (size_t)c * 12));
         } else {
-            reinterpret_cast<Chunk*>(tile)[c] = v;
+            sl_u32x3 t; t.x = v.w0; t.y = v.w1; t.z = v.w2;
+            *(SL_GLOBAL sl_u32x3*)(as_global(tile) + (size_t)c * 12) = t;
         }
     } else {
         const size_t base = (size_t)c * 12;
         if (base + 12 <= nbytes) {
-            ChunkU u; u.w0 = v.w0; u.w1 = v.w1; u.w2 = v.w2;
-            *reinterpret_cast<ChunkU*>(tile + base) = u;
+            sl_u32x3u u; u.x = v.w0; u.y = v.w1; u.z = v.w2;
+            *(SL_GLOBAL sl_u32x3u*)(as_global(tile) + base) = u;
         } else {
             for (int i = 0; i < 12; ++i)
-                if (base + i < nbytes) tile[base + i] = (uint8_t)chunk_byte(v, i);
+                if (base + i < nbytes) as_global(tile)[base + i] = (uint8_t)chunk_byte(v, i);
         }
     }
 }

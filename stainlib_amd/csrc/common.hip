@@ -45,6 +45,7 @@ extern "C" int sl_version(void) { return SL_VERSION; }
 extern "C" void sl_default_params(SlParams* p) {
     if (!p) return;
     std::memset(p, 0, sizeof(*p));
+    p->struct_size = (uint32_t)sizeof(SlParams);
     p->luminosity_threshold = 0.8;
     p->angular_percentile = 99.0;
     p->lasso_lambda = 0.01;

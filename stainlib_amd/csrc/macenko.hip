@@ -50,7 +50,7 @@ int g_debug_stop = 0;
 #endif
 
 struct Layout {
-    int parts, stride_log2, n_sample, G, cap_raw, cap_list, cap_ang;
+    int parts, stride_log2, n_sample, sample_cap, G, cap_raw, cap_list, cap_ang;
     bool fused;
     bool wide;                              // fused with 1024-thread workgroups, one per CU (Macenko, batches of up to #CU tiles)
     int grid;                               // fused: workgroups launched
@@ -77,6 +77,10 @@ Layout make_layout(int n, long P, int method = kMethodMacenko, int schedule = 0,
     while (((P + (1L << L.stride_log2) - 1) >> L.stride_log2) > kMaxSample) ++L.stride_log2;
     L.n_sample = (int)((P + (1L << L.stride_log2) - 1) >> L.stride_log2);
     assert(L.stride_log2 >= 4 && L.n_sample <= kMaxSample);     // sample_row / sample_pixel: cps_log2 = stride_log2 - 2 >= 2
+    // the fused Macenko kernel's two-sweep schedule gathers a cluster sample into the same buffer (stats_twosweep.hpp)
+    L.sample_cap = L.n_sample;
+    if (method == kMethodMacenko && cluster_samples(P) > L.sample_cap) L.sample_cap = cluster_samples(P);
+    assert(L.sample_cap <= kMaxSample);
     long g = (long)(kGroupBytes / (size_t)(3 * P));
     const long min_g = (1024 + L.parts - 1) / L.parts;      // keep >= ~1024 workgroups per sweep launch
     if (g < min_g) g = min_g;
@@ -105,7 +109,7 @@ Layout make_layout(int n, long P, int method = kMethodMacenko, int schedule = 0,
     L.off_status = o;   o = align_up(o + sizeof(int32_t) * (size_t)n);
     L.off_diag = o;     o = align_up(o + sizeof(int32_t) * (size_t)n);
     L.off_partials = o; o = align_up(o + sizeof(double) * 32 * (size_t)L.parts * L.G);     // 10 (Macenko) / 32 (Vahadane) per item
-    L.off_sample = o;   o = align_up(o + sizeof(uint32_t) * (size_t)L.n_sample * slots);
+    L.off_sample = o;   o = align_up(o + sizeof(uint32_t) * (size_t)L.sample_cap * slots);
     // list capacities scale with the tile.  i.i.d. tiles: ~6 % of the pixels are raw candidates of the merged selection sweep (angle
     // ~2.5 %, concentrations ~4 %) and ~4.5 % end up in a bracket.  Real tissue fills them further -- the concentration brackets the
     // merged sweep widens by the box of stain matrices hold up to 8 % of the pixels of a stained-tissue tile with background, the raw
@@ -269,26 +273,20 @@ int run_fused(int method, const uint8_t* rgb, uint8_t* out, int n, long P, const
     a.sweeps_out = sweeps_out;
     a.use_cube = p.prefilter == 1 ? 0 : (p.prefilter == 2 ? 2 : 1);
     a.cube_out = p.prefilter_out;
+    a.sample_cap = L.sample_cap;
+    // (tiles below 16 Ki pixels keep the three-sweep schedule: their sample would be a fifth of the tile)
+    a.two_sweep = (method != kMethodMacenko || p.two_sweep == 1 || P < (1L << 14)) ? 0 : (p.two_sweep >= 2 && p.two_sweep <= 4 ? p.two_sweep : 1);
+    a.cl_lines = cluster_lines(P);
+    a.cl_scale_log2 = 1;
+    while (((long)a.cl_lines * kClusterPx << a.cl_scale_log2) < P && a.cl_scale_log2 < 30) ++a.cl_scale_log2;
+    a.ts_out = p.twosweep_out;
     const bool al = aligned4(rgb, P) && (!out || aligned4(out, P));
-    const dim3 g((unsigned)L.grid), b(kFusedThreads);
     ProfScope ps(p.profile, out ? SL_PROF_FUSED_TRANSFORM : SL_PROF_FUSED_FIT, n, s);
-    if (method == kMethodMacenko && L.wide) {
-        const dim3 bw(2 * kFusedThreads);
-#define SL_GOW(T, A) hipLaunchKernelGGL((k_fused<kMethodMacenko, T, A, 2 * kFusedThreads>), g, bw, 0, s, a)
-        if (out) { if (al) SL_GOW(true, true); else SL_GOW(true, false); }
-        else     { if (al) SL_GOW(false, true); else SL_GOW(false, false); }
-#undef SL_GOW
-        return launch_status();
-    }
-#define SL_GO(M, T, A) hipLaunchKernelGGL((k_fused<M, T, A, kFusedThreads>), g, b, 0, s, a)
-    if (method == kMethodMacenko) {
-        if (out) { if (al) SL_GO(kMethodMacenko, true, true); else SL_GO(kMethodMacenko, true, false); }
-        else     { if (al) SL_GO(kMethodMacenko, false, true); else SL_GO(kMethodMacenko, false, false); }
-    } else {
-        if (out) { if (al) SL_GO(kMethodVahadane, true, true); else SL_GO(kMethodVahadane, true, false); }
-        else     { if (al) SL_GO(kMethodVahadane, false, true); else SL_GO(kMethodVahadane, false, false); }
-    }
-#undef SL_GO
+    // (the twelve instantiations of k_fused live in three translation units of their own -- fused_macenko.hip, fused_macenko_wide.hip,
+    //  fused_vahadane.hip -- so that they compile side by side)
+    if (method == kMethodMacenko && L.wide) launch_fused_macenko_wide(a, out != nullptr, al, (unsigned)L.grid, s);
+    else if (method == kMethodMacenko) launch_fused_macenko(a, out != nullptr, al, (unsigned)L.grid, s);
+    else launch_fused_vahadane(a, out != nullptr, al, (unsigned)L.grid, s);
     return launch_status();
 }
 
@@ -403,6 +401,7 @@ extern "C" size_t sl_workspace_bytes(int op, int n_tiles, int h, int w) {
 extern "C" int sl_macenko_fit(const uint8_t* rgb, int n, int h, int w, const SlParams* params, double* M_out,
                               double* maxC_out, int32_t* status, void* workspace, size_t workspace_bytes,
                               void* stream) {
+    if (!params_ok(params)) return SL_ERR_BADARG;
     const long P = (long)h * w;
     const MacenkoPlan pl = (n > 0 && h > 0 && w > 0) ? plan_macenko(n, P, params ? params->schedule : 0, params ? params->fused_min_tiles : 0) : MacenkoPlan{};
     // the documented requirement, not this plan's own need (a schedule may need less: the per-phase one has no angular list): a workspace
@@ -423,6 +422,7 @@ extern "C" int sl_macenko_transform(const uint8_t* rgb, uint8_t* out, int n, int
                                     const double* M_tgt, const double* maxC_tgt, double* M_src_out,
                                     double* maxC_src_out, int32_t* status, void* workspace, size_t workspace_bytes,
                                     void* stream) {
+    if (!params_ok(params)) return SL_ERR_BADARG;
     const long P = (long)h * w;
     const MacenkoPlan pl = (n > 0 && h > 0 && w > 0) ? plan_macenko(n, P, params ? params->schedule : 0, params ? params->fused_min_tiles : 0) : MacenkoPlan{};
     // the documented requirement, not this plan's own need (a schedule may need less: the per-phase one has no angular list): a workspace
@@ -444,6 +444,7 @@ extern "C" int sl_macenko_transform(const uint8_t* rgb, uint8_t* out, int n, int
 extern "C" int sl_vahadane_fit(const uint8_t* rgb, int n, int h, int w, const SlParams* params, double* M_out,
                                double* maxC_out, int32_t* status, int32_t* sweeps_out, void* workspace,
                                size_t workspace_bytes, void* stream) {
+    if (!params_ok(params)) return SL_ERR_BADARG;
     const long P = (long)h * w;
     const Layout L = (n > 0 && h > 0 && w > 0) ? make_layout(n, P, kMethodVahadane, params ? params->schedule : 0, params ? params->fused_min_tiles : 0) : Layout{};
     int rc = check_common(rgb, n, h, w, workspace, workspace_bytes, L.total);
@@ -470,6 +471,7 @@ extern "C" int sl_vahadane_transform(const uint8_t* rgb, uint8_t* out, int n, in
                                      const double* M_tgt, const double* maxC_tgt, double* M_src_out,
                                      double* maxC_src_out, int32_t* status, void* workspace, size_t workspace_bytes,
                                      void* stream) {
+    if (!params_ok(params)) return SL_ERR_BADARG;
     const long P = (long)h * w;
     const Layout L = (n > 0 && h > 0 && w > 0) ? make_layout(n, P, kMethodVahadane, params ? params->schedule : 0, params ? params->fused_min_tiles : 0) : Layout{};
     int rc = check_common(rgb, n, h, w, workspace, workspace_bytes, L.total);

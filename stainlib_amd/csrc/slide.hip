@@ -458,6 +458,7 @@ int fill_args(SlideArgs& a, const uint8_t* rgb, int n, int h, int w, const SlPar
     if (keyset != SL_KEYSET_ANGLE && keyset != SL_KEYSET_CONC) return SL_ERR_BADARG;
     SlParams p;
     sl_default_params(&p);
+    if (!params_ok(params)) return SL_ERR_BADARG;
     if (params) p = *params;
     a.rgb = rgb;
     a.P = h * w;
@@ -657,6 +658,7 @@ extern "C" int sl_tile_moments(const uint8_t* rgb, int n, int h, int w, const Sl
     const long items = (long)n * parts;
     SlParams p;
     sl_default_params(&p);
+    if (!params_ok(params)) return SL_ERR_BADARG;
     if (params) p = *params;
     const float ylimf = (float)y_limit_for_threshold(p.luminosity_threshold) - 2048.0f;
     hipStream_t s = (hipStream_t)stream;
@@ -762,6 +764,7 @@ extern "C" int sl_pool_begin(const double* moments11, const SlParams* params, do
     if (!moments11 || !state) return SL_ERR_BADARG;
     SlParams p;
     sl_default_params(&p);
+    if (!params_ok(params)) return SL_ERR_BADARG;
     if (params) p = *params;
     hipLaunchKernelGGL(k_pool_begin, dim3(1), dim3(64), 0, (hipStream_t)stream, moments11, state, p.angular_percentile);
     return launch_status();
@@ -813,6 +816,7 @@ extern "C" int sl_pool_resolve(double* state, int keyset, const unsigned long lo
     if (!state || !window_reduced || (keyset != SL_KEYSET_ANGLE && keyset != SL_KEYSET_CONC)) return SL_ERR_BADARG;
     SlParams p;
     sl_default_params(&p);
+    if (!params_ok(params)) return SL_ERR_BADARG;
     if (params) p = *params;
     hipLaunchKernelGGL(k_pool_resolve, dim3(1), dim3(1024), 0, (hipStream_t)stream, state, window_reduced, keyset, p.lasso_lambda);
     return launch_status();

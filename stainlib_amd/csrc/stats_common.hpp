@@ -130,8 +130,34 @@ __device__ __forceinline__ long long sample_pixel(uint32_t b, int cps_log2) {
     return (long long)chunk * 4 + ((h >> 31) ? 3 : 0);
 }
 // only the LAST block of a tile can hold its draw beyond the tile: every other entry is present without looking
+// (cps_log2 == kDenseCps: a DENSE sample -- the cluster sample of the two-sweep schedule, stats_twosweep.hpp -- whose n_sample entries all exist)
+constexpr int kDenseCps = 64;
 __device__ __forceinline__ bool sample_absent(int b, int cps_log2, int P) {
+    if (cps_log2 >= kDenseCps) return false;
     return b >= ((P - 1) >> (cps_log2 + 2)) && sample_pixel((uint32_t)b, cps_log2) >= P;
+}
+
+// ---- cluster sample (round 5, the two-sweep Macenko schedule): a sample that must exist BEFORE the tile's first sweep cannot ride in
+// a sweep, and 16 Ki scattered 4-byte reads fetch 16 Ki x 128 bytes = two thirds of a sweep.  So: n_lines blocks of 128 bytes (the
+// fetch unit of the L2) spread evenly over the tile, the block of each sample line drawn by hash inside its stratum, and
+// kClusterPx pixels of each (every kClusterStep-th: they span 36 of the block's 42): 2 048 lines x 8 pixels = 16 Ki entries for 256 KB
+// of fetches (0.25 B/px of a 1024^2 tile).  Neighbouring pixels of real tissue are correlated: the brackets made of this sample are
+// widened by a design effect (kClusterDeff) -- the sample steers, results never depend on it.
+constexpr int kClusterLines = 2048, kClusterPx = 8, kClusterStep = 5;
+__host__ __device__ inline int cluster_lines(long P) {
+    const long nl = (3 * P) >> 7;
+    return (int)(nl < 1 ? 1 : (nl < kClusterLines ? nl : kClusterLines));
+}
+__host__ __device__ inline int cluster_samples(long P) { return cluster_lines(P) * kClusterPx; }
+// pixel index of entry b (always inside the tile)
+__device__ __forceinline__ int cluster_pixel(int b, int P, int n_lines) {
+    const int i = b / kClusterPx, j = b % kClusterPx;
+    const long long nl = ((3ll * P) >> 7) < 1 ? 1 : ((3ll * P) >> 7);
+    const long long l0 = (long long)i * nl / n_lines, l1 = (long long)(i + 1) * nl / n_lines;     // the stratum of line i (l1 > l0: n_lines <= nl)
+    const uint32_t h = sample_hash((uint32_t)i);
+    const long long line = l0 + (long long)((h >> 8) % (uint32_t)(l1 - l0));
+    const long long px = (line * 128 + 2) / 3 + (long long)((h >> 28) % 3u) + kClusterStep * j;   // first whole pixel of the block + 0..2 + 5 j: <= +37, inside the block
+    return (int)(px < (long long)P ? px : (long long)P - 1);
 }
 
 // Monotone surrogate of arctan2(y, x) on (-pi, pi]: y/(|x|+|y|) in [-1,1] for x >= 0, mirrored to

@@ -145,7 +145,7 @@ __device__ __forceinline__ bool cube_worthwhile(const uint32_t* samp, int n_samp
     uint32_t amb = 0, seen = 0;
     for (int b = tid; b < n_sample; b += kCubeShareStep * NT) {        // every kCubeShareStep-th row of the sample is plenty
         if (sample_absent(b, cps_log2, P)) continue;
-        amb += cube_cell_plain(ctab, cc, ylimf, samp[b] & 0xffffffu) ? 0u : 1u;
+        amb += cube_cell_plain(ctab, cc, ylimf, as_global(samp)[b] & 0xffffffu) ? 0u : 1u;
         ++seen;
     }
     uint32_t both = amb | (seen << 16);                                 // (at most 16 Ki / 16 entries in all: the halves cannot overflow)
@@ -189,7 +189,7 @@ struct RawDirect {
     }
     __device__ __forceinline__ static void store(uint32_t* dst, uint32_t cap, unsigned long long m, uint32_t q, uint32_t base, int lane) {
         const uint32_t at = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (((m >> lane) & 1ull) && at < cap) dst[at] = q;
+        if (((m >> lane) & 1ull) && at < cap) as_global(dst)[at] = q;
     }
     // two pixel rows at once: masks {angle, conc} of each
     __device__ __forceinline__ void put2(unsigned long long a0, unsigned long long c0, uint32_t q0, unsigned long long a1, unsigned long long c1,

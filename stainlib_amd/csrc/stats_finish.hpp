@@ -223,14 +223,14 @@ __device__ __forceinline__ void wg_pick2(const float* cand0, const float* cand1,
         uint32_t best = 0xffffffffu;
         float kn[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) { const int i = tid + u * bd; kn[u] = cand[i < n ? i : 0]; }
+        for (int u = 0; u < U; ++u) { const int i = tid + u * bd; kn[u] = as_global(cand)[i < n ? i : 0]; }
         for (int i0 = tid; i0 < n; i0 += U * bd) {
             float k[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 k[u] = kn[u];
                 const int i = i0 + (U + u) * bd;
-                kn[u] = cand[i < n ? i : 0];
+                kn[u] = as_global(cand)[i < n ? i : 0];
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -324,7 +324,7 @@ __device__ __noinline__ void raw_flush(uint32_t buf_lds, uint32_t n, uint32_t* d
     if (lane == 0) base = atomicAdd(head, n);
     base = __builtin_amdgcn_readfirstlane(base);
     for (uint32_t i = lane; i < n; i += 64)
-        if (base + i < cap) dst[base + i] = buf[i];
+        if (base + i < cap) as_global(dst)[base + i] = buf[i];
 }
 
 struct RawSink {
@@ -485,13 +485,13 @@ __device__ __forceinline__ RefineOut wg_refine_s(const uint32_t* raw, int n_raw,
     int i0 = (tid - lane) * U;                                       // wave-uniform trip count
     uint32_t wn[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) wn[u] = raw[min(i0 + u * 64 + lane, last)];
+    for (int u = 0; u < U; ++u) wn[u] = as_global(raw)[min(i0 + u * 64 + lane, last)];
     for (; i0 < n_raw; i0 += step) {
         uint32_t w[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             w[u] = wn[u];
-            wn[u] = raw[min(i0 + step + u * 64 + lane, last)];       // next trip (clamped, never predicated)
+            wn[u] = as_global(raw)[min(i0 + step + u * 64 + lane, last)];       // next trip (clamped, never predicated)
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -527,8 +527,9 @@ __device__ __forceinline__ RefineOut wg_refine_s(const uint32_t* raw, int n_raw,
 // leaves it) a second pair at kBoxZ sigma is located in the same register-resident keys -- costs a histogram pass only then.
 constexpr float kBoxZ = 3.6f;
 template <int THREADS>
+// zs: scale of the bracket half-widths (a clustered sample's ranks scatter by sqrt(design effect) more than an independent one's)
 __device__ __forceinline__ void angle_brackets(const SampleAngleKey& key, int n_sample, double pct, float* lo, float* hi,
-                                               SelScratch& S, float* box = nullptr) {
+                                               SelScratch& S, float* box = nullptr, float zs = 1.0f) {
     constexpr int KPT = kMaxSample / THREADS;
     uint32_t ord[1][KPT];
 #ifdef SL_DEBUG_SUBCLK
@@ -543,7 +544,7 @@ __device__ __forceinline__ void angle_brackets(const SampleAngleKey& key, int n_
 #pragma unroll
         for (int g = 0; g < kBrkBatch; ++g) {
             const int b = (j0 + g) * THREADS + (int)threadIdx.x;
-            w[g] = b < n_sample ? key.sample[b] : 0u;
+            w[g] = b < n_sample ? as_global(key.sample)[b] : 0u;
         }
 #pragma unroll
         for (int g = 0; g < kBrkBatch; ++g) {
@@ -555,7 +556,7 @@ __device__ __forceinline__ void angle_brackets(const SampleAngleKey& key, int n_
     SL_BCLK(5);
     const int set_of[2] = {0, 0};
     const double p2[2] = {100.0 - pct, pct};          // minPhi, maxPhi (macenko_stain_extractor.py:33-34)
-    wg_brackets_regs<1, KPT, 2>(ord, set_of, p2, lo, hi, S);
+    wg_brackets_regs<1, KPT, 2>(ord, set_of, p2, lo, hi, S, kBracketZ * zs);
     if (box) {
         const bool closed = (lo[0] > -INFINITY) & (hi[0] < INFINITY) & (lo[1] > -INFINITY) & (hi[1] < INFINITY);     // block-uniform
         if (closed) {
@@ -567,17 +568,17 @@ __device__ __forceinline__ void angle_brackets(const SampleAngleKey& key, int n_
         } else {
             // worth a second pass only if the kBoxZ-sigma ranks stay inside the sample (S.misc[6]: its valid keys, left by the first pass)
             const double n = (double)S.misc[6], q = p2[0] / 100.0;
-            const bool inside = n > 0.0 && floor(q * (n - 1.0) - (double)kBoxZ * sqrt(fmax(q * (1.0 - q) * n, 0.0))) - 1.0 >= 0.0;   // block-uniform
+            const bool inside = n > 0.0 && floor(q * (n - 1.0) - (double)(kBoxZ * zs) * sqrt(fmax(q * (1.0 - q) * n, 0.0))) - 1.0 >= 0.0;   // block-uniform
             float blo[2] = {-INFINITY, -INFINITY}, bhi[2] = {INFINITY, INFINITY};
             __syncthreads();
-            if (inside) wg_brackets_regs<1, KPT, 2>(ord, set_of, p2, blo, bhi, S, kBoxZ);
+            if (inside) wg_brackets_regs<1, KPT, 2>(ord, set_of, p2, blo, bhi, S, kBoxZ * zs);
             box[0] = blo[0]; box[1] = bhi[0]; box[2] = blo[1]; box[3] = bhi[1];
         }
     }
 }
 // brackets of the 99th percentile of both concentration columns from the sample (normalizer.py:36,47)
 template <int THREADS>
-__device__ __forceinline__ void conc_brackets(const SampleConcKey& key, int n_sample, float* lo, float* hi, SelScratch& S) {
+__device__ __forceinline__ void conc_brackets(const SampleConcKey& key, int n_sample, float* lo, float* hi, SelScratch& S, float zs = 1.0f) {
     constexpr int KPT = kMaxSample / THREADS;
     uint32_t ord[2][KPT];
 #ifdef SL_DEBUG_SUBCLK
@@ -590,7 +591,7 @@ __device__ __forceinline__ void conc_brackets(const SampleConcKey& key, int n_sa
 #pragma unroll
         for (int g = 0; g < kBrkBatch; ++g) {
             const int b = (j0 + g) * THREADS + (int)threadIdx.x;
-            w[g] = b < n_sample ? key.sample[b] : 0u;
+            w[g] = b < n_sample ? as_global(key.sample)[b] : 0u;
         }
 #pragma unroll
         for (int g = 0; g < kBrkBatch; ++g) {
@@ -605,7 +606,7 @@ __device__ __forceinline__ void conc_brackets(const SampleConcKey& key, int n_sa
     SL_BCLK(6);
     const int set_of[2] = {0, 1};
     const double p2[2] = {99.0, 99.0};
-    wg_brackets_regs<2, KPT, 2>(ord, set_of, p2, lo, hi, S);
+    wg_brackets_regs<2, KPT, 2>(ord, set_of, p2, lo, hi, S, kBracketZ * zs);
 }
 
 }  // namespace sl

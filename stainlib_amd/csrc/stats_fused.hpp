@@ -3,6 +3,7 @@
 #pragma once
 #include "stats_phase_kernels.hpp"
 #include "stats_cube.hpp"
+#include "stats_twosweep.hpp"
 
 namespace sl {
 
@@ -43,6 +44,14 @@ struct FusedArgs {
     int32_t* sweeps_out;     // [n_tiles] (may be NULL)
     int use_cube;            // Macenko: let finish 1 build the colour-cube mask for sweep 2 (stats_cube.hpp); 0 = always the per-pixel sweep
     int32_t* cube_out;       // [n_tiles] 1 where sweep 2 ran behind the cube mask (diagnostics, may be NULL)
+    // Macenko, two-sweep schedule (stats_twosweep.hpp)
+    int two_sweep;           // 0 = off (three sweeps, the sample rides in sweep 1); 1 = on where phase 0 says it pays; 2 = on wherever an estimate
+                             // exists (tests); 3 = as 2, and the plane check is made to fail (tests: drives the fallback); 4 = as 2 with the
+                             // sample's plane tilted by 0.05 before use (tests: a check that fails on its own)
+    int sample_cap;          // entries of a workgroup's sample buffer (>= n_sample and >= the cluster sample)
+    int cl_lines;            // lines of the cluster sample (cluster_lines(P)); its entries: cl_lines * kClusterPx <= the sample buffer
+    int cl_scale_log2;       // log2 of the pixels one entry of the cluster sample stands for (rounded up, >= 1)
+    int32_t* ts_out;         // [n_tiles] kTs* (diagnostics, may be NULL)
 };
 
 template <int NT>
@@ -71,6 +80,7 @@ struct FusedShared {
     int why;                 // why the merged sweep's concentration candidates were not used (SL_RESWEEP_*; 0 = they were)
     int use_cube;            // finish 1 built the colour-cube mask (in S.hist) and the sample says it pays: sweep 2 = select_sweep_cube
     MergedConc mk;
+    TwoSweep ts;             // two-sweep schedule: the estimate phase 0 left for sweep 1 (ts.ok) and what the finish must verify
 };
 
 // Every kernel that owns a FusedShared block declares it as its ONLY __shared__ object, so the block starts at LDS address 0
@@ -114,10 +124,10 @@ __device__ __forceinline__ double uni_d(double x) {
 // per-channel tables in the sweeps' staging space, the mask where the finish steps' histogram lives (neither is in use between finish
 // 1 and finish 2); sh.use_cube says whether sweep 2 runs behind it (bit 0) and carries the sampled share of ambiguous cells (bits 8..).
 template <int NT>
-__device__ SL_FINISH_ATTR void fused_cube_build(FusedShared<NT>* shp, uint32_t* samp_, int n_sample_, int stride_log2_, int P_, float ylimf_, int want_cube_) {
+__device__ SL_FINISH_ATTR void fused_cube_build(FusedShared<NT>* shp, uint32_t* samp_, int n_sample_, int cps_log2_, int P_, float ylimf_, int want_cube_) {
     FusedShared<NT>& sh = *shp;
     uint32_t* samp = uni_ptr(samp_);
-    const int n_sample = __builtin_amdgcn_readfirstlane(n_sample_), stride_log2 = __builtin_amdgcn_readfirstlane(stride_log2_), P = __builtin_amdgcn_readfirstlane(P_);
+    const int n_sample = __builtin_amdgcn_readfirstlane(n_sample_), cps_log2 = __builtin_amdgcn_readfirstlane(cps_log2_), P = __builtin_amdgcn_readfirstlane(P_);
     const int want_cube = __builtin_amdgcn_readfirstlane(want_cube_);
     const float ylimf = uni(ylimf_);
     const int tid = threadIdx.x;
@@ -126,7 +136,7 @@ __device__ SL_FINISH_ATTR void fused_cube_build(FusedShared<NT>* shp, uint32_t* 
     const CubeConsts cc = cube_tables(view_of_b(sh.tab), sh.Vf, sh.hi[0], sh.lo[1], sh.mk, ctab, tid);
     __syncthreads();
     int share_pct;
-    const bool pays = cube_worthwhile<NT>(samp, n_sample, stride_log2 - 2, P, ctab, cc, ylimf, &sh.S.misc[33], tid, share_pct);
+    const bool pays = cube_worthwhile<NT>(samp, n_sample, cps_log2, P, ctab, cc, ylimf, &sh.S.misc[33], tid, share_pct);
     const bool go = pays || want_cube == 2;                                                   // block-uniform
     if (tid == 0) sh.use_cube = (go ? 1 : 0) | (share_pct << 8);                              // (the share rides along for prefilter_out)
     if (go) cube_mask<NT>(ctab, cc, ylimf, sh.S.hist, tid);
@@ -134,12 +144,20 @@ __device__ SL_FINISH_ATTR void fused_cube_build(FusedShared<NT>* shp, uint32_t* 
 }
 
 // Finish 1 of the merged schedule after the eigenvectors: brackets and thresholds into sh.lo / sh.hi / sh.mk.
+// The sample: n_sample entries; stride_log2 >= 4: the stratified sample sweep 1 left (one pixel per 2^stride_log2), some entries may be
+// absent; stride_log2 < 0: the DENSE cluster sample of the two-sweep schedule (every entry present, one per 2^-stride_log2 pixels or so,
+// brackets widened by the design effect).
 template <int NT>
 __device__ SL_FINISH_ATTR void fused_finish1(FusedShared<NT>* shp, uint32_t* samp_, int n_sample_, int stride_log2_, int P_, float ylimf_, double pct_, double lam_,
                                            long long* subclk_, int want_cube_) {
     FusedShared<NT>& sh = *shp;
     uint32_t* samp = uni_ptr(samp_);
-    const int n_sample = __builtin_amdgcn_readfirstlane(n_sample_), stride_log2 = __builtin_amdgcn_readfirstlane(stride_log2_), P = __builtin_amdgcn_readfirstlane(P_);
+    const int n_sample = __builtin_amdgcn_readfirstlane(n_sample_), P = __builtin_amdgcn_readfirstlane(P_);
+    const int sl2 = __builtin_amdgcn_readfirstlane(stride_log2_);
+    const bool dense = sl2 < 0;
+    const int stride_log2 = dense ? -sl2 : sl2;                       // pixels one entry stands for (log2)
+    const int cps_log2 = dense ? kDenseCps : stride_log2 - 2;
+    const float zs = dense ? (float)sqrt(kClusterDeff) : 1.0f;
     const int want_cube = __builtin_amdgcn_readfirstlane(want_cube_);
     const float ylimf = uni(ylimf_);
     const double pct = uni_d(pct_), lam = uni_d(lam_);
@@ -153,11 +171,11 @@ __device__ SL_FINISH_ATTR void fused_finish1(FusedShared<NT>* shp, uint32_t* sam
     (void)subclk;
     {
         SampleAngleKey key;                                           // (scoped: kept alive across the function it cost the bracket code registers)
-        key.sample = samp; key.tab = view_of_b(sh.tab); key.cps_log2 = stride_log2 - 2; key.P = P; key.ylimf = ylimf;
+        key.sample = samp; key.tab = view_of_b(sh.tab); key.cps_log2 = cps_log2; key.P = P; key.ylimf = ylimf;
         for (int i = 0; i < 6; ++i) key.V[i] = sh.Vf[i];
         float lo[2], hi[2];
         float box[4];
-        angle_brackets<NT>(key, n_sample, pct, lo, hi, sh.S, box);
+        angle_brackets<NT>(key, n_sample, pct, lo, hi, sh.S, box, zs);
         if (tid == 0) {
             sh.lo[0] = lo[0]; sh.hi[0] = hi[0]; sh.lo[1] = lo[1]; sh.hi[1] = hi[1];
             for (int i = 0; i < 4; ++i) sh.box[i] = box[i];
@@ -173,10 +191,10 @@ __device__ SL_FINISH_ATTR void fused_finish1(FusedShared<NT>* shp, uint32_t* sam
     SL_SUB(13);
     if (sh.mk.ok) {                                               // block-uniform
         SampleConcKey ckey;
-        ckey.sample = samp; ckey.tab = view_of_b(sh.tab); ckey.L = sh.mk.Lc; ckey.cps_log2 = stride_log2 - 2;
+        ckey.sample = samp; ckey.tab = view_of_b(sh.tab); ckey.L = sh.mk.Lc; ckey.cps_log2 = cps_log2;
         ckey.P = P; ckey.col = 0;
         float lo[2], hi[2];
-        conc_brackets<NT>(ckey, n_sample, lo, hi, sh.S);
+        conc_brackets<NT>(ckey, n_sample, lo, hi, sh.S, zs);
         if (tid == 0) merged_thresholds(sh.mk, lo[0], lo[1], hi[0], hi[1]);
     } else if (tid == 0) {
         merged_thresholds(sh.mk, -INFINITY, -INFINITY, -INFINITY, -INFINITY);       // disarms the concentration test
@@ -187,7 +205,7 @@ __device__ SL_FINISH_ATTR void fused_finish1(FusedShared<NT>* shp, uint32_t* sam
     // code's register-resident sample keys into scratch -- both bracket steps took twice as long)
     const float hi0 = sh.hi[0], lo1 = sh.lo[1];
     if (want_cube && hi0 > -INFINITY && hi0 < INFINITY && lo1 > -INFINITY && lo1 < INFINITY)       // block-uniform
-        fused_cube_build<NT>(&sh, samp, n_sample, stride_log2, P, ylimf, want_cube);
+        fused_cube_build<NT>(&sh, samp, n_sample, cps_log2, P, ylimf, want_cube);
     SL_SUB(7);      // (slot 7 is otherwise written on the resweep path only)
     // ---------------- the per-pixel sweep: does the projection bound stand in for its tissue test?
     // The bound makes the sweep collect NON-tissue pixels too when they pass it and lie outside the cone.  On most
@@ -199,14 +217,14 @@ __device__ SL_FINISH_ATTR void fused_finish1(FusedShared<NT>* shp, uint32_t* sam
     const float xm = sh.xmin;
     if (!(sh.use_cube & 1) && xm > -INFINITY && xm < INFINITY) {  // block-uniform
         SampleAngleKey key;
-        key.sample = samp; key.tab = view_of_b(sh.tab); key.cps_log2 = stride_log2 - 2; key.P = P; key.ylimf = ylimf;
+        key.sample = samp; key.tab = view_of_b(sh.tab); key.cps_log2 = cps_log2; key.P = P; key.ylimf = ylimf;
         for (int i = 0; i < 6; ++i) key.V[i] = sh.Vf[i];
         if (tid == 0) sh.S.misc[32] = 0;
         __syncthreads();
         uint32_t extra = 0;
         for (int b = tid; b < n_sample; b += NT) {
             if (!key.present(b, n_sample)) continue;
-            const uint32_t w = samp[b];
+            const uint32_t w = as_global(samp)[b];
             const uint32_t r = w & 255u, g = (w >> 8) & 255u, bl = (w >> 16) & 255u;
             const bool tissue = is_tissue_f(key.tab.gam(r), key.tab.gam(g), key.tab.gam(bl), ylimf);
             const float ox = key.tab.odf(r), oy = key.tab.odf(g), oz = key.tab.odf(bl);
@@ -383,9 +401,12 @@ __device__ __noinline__ void fused_sweep2_cube(FusedShared<NT>* shp, const uint8
 
 // Finish 2 of the merged schedule for the tile whose state sits in *shp: returns the number of slow exact fallbacks.
 // Leaves sh.M, sh.status, sh.conc_done (and sh.maxC, sh.L when conc_done) behind and the row table rebuilt.
+// ts (two-sweep schedule): the brackets in sh.lo / sh.hi were carried over from an estimate of the eigenvectors; when they do not hold
+// the wanted ranks (or the angular list is incomplete) the function returns -1 at once -- the caller then takes the three-sweep route
+// from the exact moments -- instead of falling back to the exact selection over the whole tile.
 template <int NT>
 __device__ SL_FINISH_ATTR int fused_finish2(FusedShared<NT>* shp, const uint8_t* src_, uint32_t* rawl_, uint32_t* rawa_, float* cand0_, float* cand1_, int P_,
-                                          int cap_raw_, int cap_ang_, int cap_list_, float ylimf_, double pct_, double lam_, long long* subclk_) {
+                                          int cap_raw_, int cap_ang_, int cap_list_, float ylimf_, double pct_, double lam_, long long* subclk_, int ts_ = 0) {
     FusedShared<NT>& sh = *shp;
     const uint8_t* src = uni_ptr(src_);
     uint32_t* rawl = uni_ptr(rawl_);
@@ -397,6 +418,7 @@ __device__ SL_FINISH_ATTR int fused_finish2(FusedShared<NT>* shp, const uint8_t*
     const float ylimf = uni(ylimf_);
     const double pct = uni_d(pct_), lam = uni_d(lam_);
     long long* subclk = uni_ptr(subclk_);
+    const int ts = __builtin_amdgcn_readfirstlane(ts_);
     const int tid = threadIdx.x, wave = tid >> 6;
     int fallbacks = 0;
 #ifdef SL_DEBUG_SUBCLK
@@ -436,6 +458,18 @@ __device__ SL_FINISH_ATTR int fused_finish2(FusedShared<NT>* shp, const uint8_t*
         // plain = tissue pixels the sweep did not collect as angular candidates: they sit between the two brackets (a mixed list
         // also holds pixels collected for their concentrations; those with an angle key count like any other candidate)
         const long long lt[2] = {(long long)ra.n_lt[0], (long long)T - (long long)ra.n_valid + (long long)ra.n_lt[1]};
+        if (ts) {                                                 // block-uniform
+            bool covered = complete_a;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const long long k2 = (k[b] + 1 < (long long)T) ? k[b] + 1 : k[b];
+                covered = covered & (k[b] >= lt[b]) & (k2 < lt[b] + (long long)ra.n_in[b]) & (ra.n_in[b] <= (uint32_t)cap_list);
+            }
+            if (!covered) {
+                fin_tab_expand<NT>(sh.tab);
+                return -1;
+            }
+        }
         float res[4];
         stage_pick2<false>(cand0, cand1, ra.n_in, (uint32_t)cap_list, complete_a, los, his, lt, P, tkey, T, k, ra.ps, res, fallbacks, sh.S);
         if (tid == 0) { sh.res[0] = res[0]; sh.res[1] = res[1]; sh.res[2] = res[2]; sh.res[3] = res[3]; }
@@ -502,6 +536,360 @@ __device__ SL_FINISH_ATTR int fused_finish2(FusedShared<NT>* shp, const uint8_t*
     fin_tab_expand<NT>(sh.tab);                                   // the row table back for the sweeps to come
     return fallbacks;
 #undef SL_SUB
+}
+
+// ------------------------------------------------------------------------------------------
+// two-sweep schedule (stats_twosweep.hpp): phase 0 and the merged sweep, out of line like every other phase
+// ------------------------------------------------------------------------------------------
+// Phase 0: the cluster sample of the tile (into registers, and into samp[0 .. n_lines * kClusterPx) for the routes that fall back),
+// its eigenvectors, the angular brackets under them, the two half-spaces of the plain cone, the box of stain matrices with its tilts, the
+// concentration brackets under the box centre and the colour-cube mask of the merged sweep (S.hist).  Leaves sh.ts (ts.ok: sweep 1
+// collects candidates), sh.mk, and sh.use_cube (share).
+// Every workgroup of a launch starts here at the same moment and nothing streams meanwhile, so this phase is written for LATENCY: the
+// sample words stay in registers (thread t holds entries t, t + NT, ...), each bracket set costs one evaluation of the keys into a
+// fixed-range histogram and one wave_locate per rank (the register-resident windowed search of finish 1 needs four passes and three
+// times the barriers: 33-45 us per set where this takes ~15; its brackets are tighter by a histogram bin -- 0.002 of pseudo-angle,
+// ~1 % of a concentration -- which costs this schedule a few hundred candidates), and the fourth moments ride in the angle pass.
+constexpr int kP0Bins = 1024;            // angle keys: pseudo-angle [-1, 1) in 1024 bins; concentrations: 512 bins per stain of c / (c + 1)
+template <int NT>
+__device__ SL_FINISH_ATTR void fused_phase0(FusedShared<NT>* shp, const uint8_t* src_, uint32_t* samp_, int P_, int n_lines_, float ylimf_, double pct_, double lam_,
+                                          int mode_, long long* subclk_) {
+    FusedShared<NT>& sh = *shp;
+    const uint8_t* src = uni_ptr(src_);
+    uint32_t* samp = uni_ptr(samp_);
+    const int P = __builtin_amdgcn_readfirstlane(P_), n_lines = __builtin_amdgcn_readfirstlane(n_lines_), mode = __builtin_amdgcn_readfirstlane(mode_);
+    const float ylimf = uni(ylimf_);
+    const double pct = uni_d(pct_), lam = uni_d(lam_);
+    long long* subclk = uni_ptr(subclk_);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_sample = n_lines * kClusterPx;
+    constexpr int KPT = kMaxSample / NT;
+    static_assert(KPT % 8 == 0, "");
+#ifdef SL_DEBUG_SUBCLK
+#define SL_SUB(j) { __syncthreads(); if (subclk && tid == 0) subclk[(j)] = wall_clock64(); }
+#else
+#define SL_SUB(j)
+#endif
+    (void)subclk;
+    SL_SUB(0);
+    if (tid == 0) { sh.ts.ok = 0; sh.ts.why = kTsNoEstimate; sh.mk.ok = 0; sh.use_cube = 0; }
+    const TabView tab = view_of_b(sh.tab);
+    // ---------------- the sample: gathered into registers (8 loads in flight), written out for the fallback routes, summed on the way
+    uint32_t w[KPT];
+    Moments mo;
+    double cnt = 0.0;
+    {
+        const uint32_t nl = (uint32_t)(((3ll * P) >> 7) < 1 ? 1 : ((3ll * P) >> 7));
+        const uint32_t wl = nl / (uint32_t)n_lines;                // lines per stratum (>= 1)
+#pragma unroll
+        for (int j0 = 0; j0 < KPT; j0 += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int b = min((j0 + u) * NT + tid, n_sample - 1);      // (clamped, never predicated)
+                w[j0 + u] = cluster_word(src, P, wl, (uint32_t)b);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int b = (j0 + u) * NT + tid;
+                if (b < n_sample) {
+                    as_global(samp)[b] = w[j0 + u];
+                    const uint32_t r = w[j0 + u] & 255u, g = (w[j0 + u] >> 8) & 255u, bl = (w[j0 + u] >> 16) & 255u;
+                    if (is_tissue_f(tab.gam(r), tab.gam(g), tab.gam(bl), ylimf)) {
+                        mo.add((double)tab.odf(r), (double)tab.odf(g), (double)tab.odf(bl));
+                        cnt += 1.0;
+                    }
+                }
+            }
+        }
+    }
+    {
+        double v[10];
+        mo.to_array(v, 0u, lane);
+        v[0] = cnt;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) v[i] = wave_sum(v[i]);
+        if (lane == 0)
+            for (int i = 0; i < 10; ++i) sh.red[wave][i] = v[i];
+    }
+    for (int i = tid; i < kP0Bins; i += NT) sh.S.hist[i] = 0;
+    __syncthreads();
+    SL_SUB(1);
+    if (tid < 10) {
+        double t = 0;
+        for (int wv = 0; wv < NT / 64; ++wv) t += sh.red[wv][tid];
+        sh.sum[tid] = t;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double Vd[6], wv[3];
+        float Vf[6];
+        const int st = eigvecs_from_moments(sh.sum, Vd, Vf, wv);
+        const double ns = sh.sum[0];
+        // the tilt a Gaussian cloud of this size would show: v_j^T dC v_3 / (l_j - l_3), sd sqrt(l_j l_3 / n)
+        const double l1 = wv[0], l2 = wv[1], l3 = wv[2] > 0.0 ? wv[2] : 0.0;
+        bool ok = st == SL_TILE_OK && ns >= (double)kTsMinTissue && l2 > 1e-9 * l1 && l2 - l3 > 0.05 * l2;
+        double tau = 0.0;
+        if (ok) {
+            tau = kTiltZ * sqrt(kClusterDeff / ns) * fmax(sqrt(l3 * l2) / (l2 - l3), sqrt(l3 * l1) / (l1 - l3));
+            tau = fmax(tau, kTsMinTau);
+            ok = tau <= kTsMaxTau;
+        }
+        double nd[3] = {Vd[2] * Vd[5] - Vd[4] * Vd[3], Vd[4] * Vd[1] - Vd[0] * Vd[5], Vd[0] * Vd[3] - Vd[2] * Vd[1]};
+        const double nn = 1.0 / sqrt(nd[0] * nd[0] + nd[1] * nd[1] + nd[2] * nd[2]);
+        if (mode == 4 && ok) {                                    // tests: the sample's plane tilted by 0.05 (second column towards the normal)
+            double b[3];
+            for (int c = 0; c < 3; ++c) b[c] = Vd[2 * c + 1] + 0.05 * nd[c] * nn;
+            const double nb = 1.0 / sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
+            for (int c = 0; c < 3; ++c) { Vd[2 * c + 1] = b[c] * nb; Vf[2 * c + 1] = (float)Vd[2 * c + 1]; }
+            nd[0] = Vd[2] * Vd[5] - Vd[4] * Vd[3]; nd[1] = Vd[4] * Vd[1] - Vd[0] * Vd[5]; nd[2] = Vd[0] * Vd[3] - Vd[2] * Vd[1];
+        }
+        const double nn2 = 1.0 / sqrt(nd[0] * nd[0] + nd[1] * nd[1] + nd[2] * nd[2]);
+        for (int i = 0; i < 6; ++i) { sh.ts.Vd[i] = Vd[i]; sh.Vd[i] = Vd[i]; sh.Vf[i] = Vf[i]; }
+        for (int c = 0; c < 3; ++c) { sh.ts.nd[c] = nd[c] * nn2; sh.ts.fn[c] = (float)(nd[c] * nn2); }
+        sh.ts.tau = tau;
+        sh.ts.gH[0] = l1 - l3; sh.ts.gH[1] = l2 - l3;             // (scratch: the eigenvalue gaps for the fourth moments below)
+        sh.res[0] = (float)(4.0 * sqrt(l3));                      // zref of ts_thresholds
+        sh.res[1] = (float)(sh.sum[1] / ns); sh.res[2] = (float)(sh.sum[2] / ns); sh.res[3] = (float)(sh.sum[3] / ns);     // the sample's mean
+        sh.status = ok ? SL_TILE_OK : SL_TILE_DEGENERATE_COV;     // (scratch here: sweep 1 sets the tile's real status)
+    }
+    __syncthreads();
+    SL_SUB(2);
+    if (sh.status != SL_TILE_OK) return;                          // block-uniform: no estimate
+    // ---------------- ONE pass over the sample: the angle keys under V~ into a fixed-range histogram, and the fourth moments that give the
+    // tilt's standard error: the eigenvector perturbation is v_j^T dC n / (l_j - l_3) with dC the sampling error of the covariance, whose
+    // (j, 3) entry has variance sum (a_j a_3)^2 / n^2 (a = the centred pixel in the eigenbasis).  The Gaussian figure above misses what a
+    // few saturated pixels in the sample do to it (measured on the i.i.d. bench batch: the exact plane 2-8 % outside a 7-sigma Gaussian
+    // bound in one tile of 750).
+    {
+        float V[6], nf[3];
+        for (int i = 0; i < 6; ++i) V[i] = sh.Vf[i];
+        for (int c = 0; c < 3; ++c) nf[c] = sh.ts.fn[c];
+        const float mx = sh.res[1], my = sh.res[2], mz = sh.res[3];
+        float q1 = 0.0f, q2 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const int b = j * NT + tid;
+            const uint32_t r = w[j] & 255u, g = (w[j] >> 8) & 255u, bl = (w[j] >> 16) & 255u;
+            const float ox = tab.odf(r), oy = tab.odf(g), oz = tab.odf(bl);
+            const bool tissue = (b < n_sample) & is_tissue_f(tab.gam(r), tab.gam(g), tab.gam(bl), ylimf);
+            if (tissue) {
+                const float key = angle_key(V, ox, oy, oz);
+                const int bin = min(kP0Bins - 1, max(0, (int)((key + 1.0f) * (0.5f * kP0Bins))));
+                atomicAdd(&sh.S.hist[bin], 1u);
+                const float dx = ox - mx, dy = oy - my, dz = oz - mz;
+                const float a1 = fmaf(V[4], dz, fmaf(V[2], dy, V[0] * dx)), a2 = fmaf(V[5], dz, fmaf(V[3], dy, V[1] * dx));
+                const float a3 = fmaf(nf[2], dz, fmaf(nf[1], dy, nf[0] * dx));
+                q1 = fmaf(a1 * a3, a1 * a3, q1);
+                q2 = fmaf(a2 * a3, a2 * a3, q2);
+            }
+        }
+        double d1 = wave_sum((double)q1), d2 = wave_sum((double)q2);
+        if (lane == 0) { sh.red[wave][0] = d1; sh.red[wave][1] = d2; }
+    }
+    __syncthreads();
+    {
+        // ranks of the two percentiles -/+ z sigma (z widened by the design effect), as wg_brackets_regs takes them; waves 0..3 locate the
+        // 6-sigma ranks, waves 4..7 the kBoxZ ones (the box when a 6-sigma end is open)
+        const double n = sh.sum[0];
+        const double zsd = sqrt(kClusterDeff);
+        if (wave < 8) {
+            const int which = wave & 3, b = which >> 1, upper = which & 1;
+            const double q = (b == 0 ? 100.0 - pct : pct) / 100.0;
+            const double z = (wave < 4 ? (double)kBracketZ : (double)kBoxZ) * zsd;
+            const double r = q * (n - 1.0), sd = sqrt(fmax(q * (1.0 - q) * n, 0.0));
+            const long long rk = upper ? (long long)ceil(r + z * sd) + 1 : (long long)floor(r - z * sd) - 1;
+            const bool open = upper ? rk > (long long)n - 1 : rk < 0;
+            uint32_t* o = &sh.S.misc[kLocateOut - 24 + 3 * wave];             // slots 16..39
+            if (!open) wave_locate(sh.S.hist, kP0Bins, (uint32_t)rk, o, lane);
+            else if (lane == 0) o[0] = 0xffffffffu;
+        }
+        if (tid == 0) {
+            double t1 = 0.0, t2 = 0.0;
+            for (int wv = 0; wv < NT / 64; ++wv) { t1 += sh.red[wv][0]; t2 += sh.red[wv][1]; }
+            const double se = fmax(sqrt(t1) / (n * sh.ts.gH[0]), sqrt(t2) / (n * sh.ts.gH[1]));
+            const double tau = fmax(sh.ts.tau, kTiltZ4 * sqrt(kClusterDeff) * se);
+            sh.ts.tau = tau;
+            sh.ts.kappa1 = tau;
+            sh.ts.kappa2 = tau * tau + 1e-7;
+            if (!(tau <= kTsMaxTau)) sh.status = SL_TILE_DEGENERATE_COV;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // bracket ends = bin edges on the safe side; a rank in the first or last bin (keys beyond [-1, 1): x < 0) counts as open
+        float e[8];
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t bin = sh.S.misc[kLocateOut - 24 + 3 * i];
+            const bool upper = i & 1;
+            const bool open = bin == 0xffffffffu || bin == 0u || bin >= (uint32_t)(kP0Bins - 1);
+            e[i] = open ? (upper ? INFINITY : -INFINITY) : -1.0f + (float)(bin + (upper ? 1u : 0u)) * (2.0f / kP0Bins);
+        }
+        sh.lo[0] = e[0]; sh.hi[0] = e[1]; sh.lo[1] = e[2]; sh.hi[1] = e[3];
+        const bool closed = (e[0] > -INFINITY) & (e[1] < INFINITY) & (e[2] > -INFINITY) & (e[3] < INFINITY);
+        if (closed) {
+            for (int b = 0; b < 2; ++b) {
+                const float m = 0.5f * (e[2 * b] + e[2 * b + 1]), r = (float)kBoxFrac * 0.5f * (e[2 * b + 1] - e[2 * b]);
+                sh.box[2 * b] = m - r; sh.box[2 * b + 1] = m + r;
+            }
+        } else {
+            for (int i = 0; i < 4; ++i) sh.box[i] = e[4 + i];
+        }
+    }
+    for (int i = tid; i < kP0Bins; i += NT) sh.S.hist[i] = 0;     // (the locates are done: the barrier above)
+    __syncthreads();
+    SL_SUB(3);
+    if (sh.status != SL_TILE_OK) return;
+    // the plain cone must be closed on its inner sides and lie within +-90 degrees of the first eigenvector
+    const float hi0 = sh.hi[0], lo1 = sh.lo[1];
+    if (!(hi0 > -0.95f && hi0 < lo1 && lo1 < 0.95f)) return;      // block-uniform (NaN / open ends fail the comparisons)
+    if (tid < 64) {
+        // half-space normals: H-type (-sin a, cos a), L-type (sin a, -cos a) in the plane, then V~ n
+        const double aH = angle_of_pseudo((double)hi0), aL = angle_of_pseudo((double)lo1);
+        double sH, cH, sL, cL;
+        sincos(aH, &sH, &cH);
+        sincos(aL, &sL, &cL);
+        if (tid == 0) {
+            const double k2 = sh.ts.kappa2 + 6e-6;                // + the sweep's own binary32 rounding and that of the finish's keys
+            for (int c = 0; c < 3; ++c) {
+                const double gH = sh.ts.Vd[2 * c] * -sH + sh.ts.Vd[2 * c + 1] * cH, gL = sh.ts.Vd[2 * c] * sL + sh.ts.Vd[2 * c + 1] * -cL;
+                sh.ts.gH[c] = gH; sh.ts.gL[c] = gL;
+                sh.ts.fgH[c] = (float)(gH - k2); sh.ts.fgL[c] = (float)(gL - k2);
+            }
+            sh.ts.fk1 = (float)(sh.ts.kappa1 * (1.0 + 1e-6));
+            sh.ts.lo0 = sh.lo[0]; sh.ts.hi1 = sh.hi[1];
+        }
+        // ---------------- the box of stain matrices (in-plane grid x tilts)
+        ts_box(sh.ts.Vd, sh.ts.nd, sh.ts.tau, sh.box, lam, tid, sh.mk);
+    }
+    __syncthreads();
+    SL_SUB(4);
+    // ---------------- concentration brackets under the box centre: both stains' keys as c / (c + 1) into 512 bins each
+    if (sh.mk.ok) {                                               // block-uniform
+        LassoK L = sh.mk.Lc;
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const int b = j * NT + tid;
+            float c1, c2;
+            lasso2(L, tab.odf(w[j] & 255u), tab.odf((w[j] >> 8) & 255u), tab.odf((w[j] >> 16) & 255u), c1, c2);
+            if (b < n_sample) {
+                const int b1 = min(511, max(0, (int)(512.0f * c1 * __builtin_amdgcn_rcpf(c1 + 1.0f))));
+                const int b2 = min(511, max(0, (int)(512.0f * c2 * __builtin_amdgcn_rcpf(c2 + 1.0f))));
+                atomicAdd(&sh.S.hist[b1], 1u);
+                atomicAdd(&sh.S.hist[512 + b2], 1u);
+            }
+        }
+        __syncthreads();
+        if (wave < 4) {                                           // ranks of the 99th percentile of ALL sample entries -/+ z sigma, per stain
+            const int col = wave >> 1, upper = wave & 1;
+            const double n = (double)n_sample, q = 0.99;
+            const double z = (double)kBracketZ * sqrt(kClusterDeff);
+            const double r = q * (n - 1.0), sd = sqrt(q * (1.0 - q) * n);
+            const long long rk = upper ? (long long)ceil(r + z * sd) + 1 : (long long)floor(r - z * sd) - 1;
+            const bool open = upper ? rk > (long long)n - 1 : rk < 0;
+            uint32_t* o = &sh.S.misc[kLocateOut - 24 + 3 * wave];
+            if (!open) wave_locate(sh.S.hist + 512 * col, 512, (uint32_t)rk, o, lane);
+            else if (lane == 0) o[0] = 0xffffffffu;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float e[4];
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t bin = sh.S.misc[kLocateOut - 24 + 3 * i];
+                const bool upper = i & 1;
+                const bool open = bin == 0xffffffffu || (upper && bin >= 511u);
+                const float edge = (float)(bin + (upper ? 1u : 0u));                     // u = c / (c + 1) = edge / 512  ->  c = edge / (512 - edge)
+                e[i] = open ? (upper ? INFINITY : -INFINITY) : (upper ? edge / (512.0f - edge) * (1.0f + 1e-5f) : edge / (512.0f - edge) * (1.0f - 1e-5f));
+            }
+            ts_thresholds(sh.mk, e[0], e[2], e[1], e[3], sh.res[0]);
+        }
+    } else if (tid == 0) {
+        ts_thresholds(sh.mk, -INFINITY, -INFINITY, -INFINITY, -INFINITY, 0.0f);       // disarms the concentration test
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int i = 0; i < 2; ++i) {
+            for (int c = 0; c < 3; ++c) sh.ts.W[i][c] = sh.mk.ok ? (float)sh.mk.C.W[i][c] : 0.0f;
+            sh.ts.kt[i] = sh.mk.kt[i]; sh.ts.eps[i] = sh.mk.eps[i]; sh.ts.zeta[i] = (float)(sh.mk.zeta[i] * (1.0 + 1e-6)); sh.ts.thr[i] = sh.mk.thr[i];
+        }
+    }
+    __syncthreads();
+    SL_SUB(5);
+    // ---------------- the colour cube of the merged sweep
+    {
+        float* ctab = reinterpret_cast<float*>(&sh.stage[0][0]);
+        static_assert(sizeof(sh.stage) >= sizeof(float) * kTsTabFloats, "");
+        const TsCubeConsts cc = ts_cube_tables(view_of_b(sh.tab), sh.ts, ctab, tid);
+        if (tid == 0) sh.S.misc[33] = 0;
+        __syncthreads();
+        // the share of the sample in ambiguous cells, from two of the register rows (1/16 of the entries)
+        uint32_t amb = 0, seen = 0;
+#pragma unroll
+        for (int j = 0; j < KPT; j += KPT / 2) {
+            if (j * NT + tid < n_sample) {
+                amb += ts_cell_plain(ctab, cc, ylimf, w[j]) ? 0u : 1u;
+                ++seen;
+            }
+        }
+        uint32_t both = amb | (seen << 16);
+        for (int o = 32; o > 0; o >>= 1) both += (uint32_t)__shfl_xor((int)both, o, 64);
+        if (lane == 0 && both) atomicAdd(&sh.S.misc[33], both);
+        __syncthreads();
+        const uint32_t tot = sh.S.misc[33];
+        const int share = (tot >> 16) ? (int)(100u * (tot & 0xffffu) / (tot >> 16)) : 100;
+        const bool go = share <= kTsMaxSharePct || mode >= 2;       // block-uniform
+        if (tid == 0) {
+            sh.use_cube = (go ? 1 : 0) | (share << 8);
+            sh.ts.ok = go ? 1 : 0;
+            sh.ts.why = go ? kTsDirect : kTsShare;
+        }
+        if (go) ts_cube_mask<NT>(ctab, cc, ylimf, sh.S.hist, tid);
+        __syncthreads();
+    }
+    SL_SUB(6);
+#undef SL_SUB
+}
+
+// Sweep 1 of the two-sweep schedule: moments into sh.red (as fused_sweep1) and the candidates of all four order statistics into the
+// tile's two lists (as fused_sweep2_cube), under the estimate in sh.ts.
+template <int NT, bool ALIGNED>
+__device__ __noinline__ void fused_sweep1c(FusedShared<NT>* shp, const uint8_t* src_, uint32_t* rawl_, uint32_t* rawa_, int P_, int cap_raw_, int cap_ang_,
+                                           float ylimf_, int stream_) {
+    FusedShared<NT>& sh = *shp;
+    const uint8_t* src = uni_ptr(src_);
+    uint32_t* rawl = uni_ptr(rawl_);
+    uint32_t* rawa = uni_ptr(rawa_);
+    const int P = __builtin_amdgcn_readfirstlane(P_), cap_raw = __builtin_amdgcn_readfirstlane(cap_raw_), stream = __builtin_amdgcn_readfirstlane(stream_);
+    const int cap_ang = __builtin_amdgcn_readfirstlane(cap_ang_);
+    const float ylimf = uni(ylimf_);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const TabReaderB TB = TabReaderB::make_at(FusedLds<NT>::tab);
+    const int nch = (P + 3) >> 2;
+    TsSweepConsts K;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { K.gH[c] = uni(sh.ts.fgH[c]); K.gL[c] = uni(sh.ts.fgL[c]); K.n[c] = uni(sh.ts.fn[c]); }
+    K.k1 = uni(sh.ts.fk1);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) K.W[i][c] = uni(sh.ts.W[i][c]);
+        K.kt[i] = uni(sh.ts.kt[i]); K.eps[i] = uni(sh.ts.eps[i]); K.zeta[i] = uni(sh.ts.zeta[i]); K.thr[i] = uni(sh.ts.thr[i]);
+    }
+    const RawDirect direct{rawl, rawa, reinterpret_cast<unsigned long long*>(&sh.n_raw), (uint32_t)cap_raw, (uint32_t)cap_ang};
+    const uint32_t bits_lds = FusedLds<NT>::hist;
+    const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(FusedLds<NT>::stage + (uint32_t)wave * FusedLds<NT>::stage_wave));
+    Moments mo;
+    uint32_t n_tissue = 0;
+    int t, c0, c1;
+    fused_geometry<NT>(nch, tid, t, c0, c1);
+    if (c0 >= c1) {                                              // (a half without pixels: wave-uniform)
+    } else if (stream) ts_sweep<ALIGNED, kFusedTrip, true>(src, P, c0, c1, t, kFusedThreads, TB, ylimf, K, bits_lds, ring_lds, direct, mo, n_tissue);
+    else ts_sweep<ALIGNED, kFusedTrip, false>(src, P, c0, c1, t, kFusedThreads, TB, ylimf, K, bits_lds, ring_lds, direct, mo, n_tissue);
+    double v[10];
+    mo.to_array(v, n_tissue, lane);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) v[i] = wave_sum(v[i]);
+    if (lane == 0)
+        for (int i = 0; i < 10; ++i) sh.red[wave][i] = v[i];
 }
 
 // ---- the merged schedule, one launch per phase: k_moments -> k_finish1m -> k_select<merged> -> k_finish2m [-> k_select<conc>,
@@ -621,7 +1009,7 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
     const int tid = threadIdx.x;
     const TabReaderB TB = TabReaderB::make(sh.tab);       // the 8-byte {gamma, od32} rows serve every sweep
     const int nch = (a.P + 3) >> 2;
-    uint32_t* samp = a.sample + (size_t)blockIdx.x * a.n_sample;
+    uint32_t* samp = a.sample + (size_t)blockIdx.x * a.sample_cap;
     uint32_t* rawl = a.raw + (size_t)blockIdx.x * a.cap_raw;
     uint32_t* rawa = a.raw_ang + (size_t)blockIdx.x * a.cap_ang;
     float* cand0 = a.cand + ((size_t)blockIdx.x * 2 + 0) * a.cap_list;
@@ -684,10 +1072,35 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
         __syncthreads();
 
         if constexpr (METHOD == kMethodMacenko) {
-            // ---------------- sweep 1: moments + sample
+            if (tid == 0) {
+                sh.n_raw = 0; sh.n_ang = 0; sh.overflow = 0;
+                sh.conc_done = 0;
+                sh.use_cube = 0;
+                sh.ts.ok = 0; sh.ts.why = kTsOff; sh.ts.dense = 0;
+            }
+            __syncthreads();
+            // ---------------- two-sweep schedule, phase 0: the cluster sample and everything the merged sweep needs (stats_twosweep.hpp)
+            if (a.two_sweep) {                                                // uniform
+                prio_finish();
+                fused_phase0<NT>(&sh, src, samp, a.P, a.cl_lines, a.ylimf, a.pct, a.lam, a.two_sweep,
+#ifdef SL_DEBUG_SUBCLK
+                                 // (development: a third region of the clock buffer, only for the tool that allocates it: sl_debug_set_stop(-7))
+                                 (a.phase_clock && a.debug_stop == -7) ? a.phase_clock + (size_t)a.n_tiles * 24 + (size_t)tile * 16 : nullptr
+#else
+                                 nullptr
+#endif
+                                 );
+                __syncthreads();
+            }
+            const bool ts_on = sh.ts.ok != 0;                                 // block-uniform
+            SL_PHASE(4);      // (slot 4 is otherwise written on the resweep path only: the end of phase 0)
+            // ---------------- sweep 1: moments (+ sample, or + the candidates of all four order statistics)
             prio_sweep(0);
-            fused_sweep1<NT, ALIGNED>(&sh, src, samp, a.P, a.ylimf, a.stride_log2, stream ? 1 : 0);
+            if (ts_on) fused_sweep1c<NT, ALIGNED>(&sh, src, rawl, rawa, a.P, a.cap_raw, a.cap_ang, a.ylimf, stream ? 1 : 0);
+            else fused_sweep1<NT, ALIGNED>(&sh, src, samp, a.P, a.ylimf, a.stride_log2, stream ? 1 : 0);   // (a declined tile: the stratified sample replaces the cluster sample)
+            if (ts_on && tid == 0) sh.ts.dense = 1;
             prio_finish();
+            __threadfence_block();
             __syncthreads();
             if (tid < 10) {
                 double t = 0;
@@ -703,16 +1116,51 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
                 float Vf[6];
                 sh.status = eigvecs_from_moments(sh.sum, Vd, Vf);
                 for (int i = 0; i < 6; ++i) { sh.Vd[i] = Vd[i]; sh.Vf[i] = Vf[i]; }
-                sh.n_raw = 0; sh.n_ang = 0; sh.overflow = 0;
                 sh.conc_done = 0;
-                sh.use_cube = 0;
             }
             __syncthreads();
             SL_SUB(1);
-            if (sh.status == SL_TILE_OK) {                                    // block-uniform
+            bool direct = false;                                              // block-uniform: the two-sweep route settled the tile's M
+            if (sh.status == SL_TILE_OK && ts_on) {                           // block-uniform
+                // ---------------- two-sweep finish: do the half-spaces the sweep tested against hold for the exact eigenvectors?
+                if (tid < 64) {
+                    float br[4];
+                    const bool okv = ts_verify(sh.ts, sh.Vd, br, tid, a.two_sweep == 3);
+                    if (tid == 0) {
+                        sh.lo[0] = br[0]; sh.hi[0] = br[1]; sh.lo[1] = br[2]; sh.hi[1] = br[3];
+                        if (!okv) { sh.ts.ok = 0; sh.ts.why = kTsPlane; }
+#ifdef SL_TS_DEBUG
+                        if (!okv) sh.ts.why = (int)sh.ts.lo0;
+#endif
+                    }
+                }
+                __syncthreads();
+                if (sh.ts.ok) {                                               // block-uniform
+                    const int fb = fused_finish2<NT>(&sh, src, rawl, rawa, cand0, cand1, a.P, a.cap_raw, a.cap_ang, a.cap_list, a.ylimf, a.pct, a.lam,
+#ifdef SL_DEBUG_SUBCLK
+                                                     a.phase_clock ? a.phase_clock + (size_t)a.n_tiles * 8 + (size_t)tile * 16 : nullptr
+#else
+                                                     nullptr
+#endif
+                                                     , 1);
+                    if (fb >= 0) { fallbacks += fb; direct = true; }
+                    else if (tid == 0) { sh.ts.ok = 0; sh.ts.why = kTsBracket; }
+                }
+                if (!direct) {                                                // the three-sweep route from the exact moments
+                    if (tid == 0) {
+                        sh.n_raw = 0; sh.n_ang = 0; sh.overflow = 0;
+                        sh.conc_done = 0;
+                        sh.use_cube = 0;
+                    }
+                    __syncthreads();
+                }
+                SL_PHASE(2);
+                SL_PHASE(3);
+            }
+            if (sh.status == SL_TILE_OK && !direct) {                         // block-uniform
                 // ---------------- finish 1, the rest of it (out of line like finish 2): angle brackets, the box of stain matrices the
                 // sample leaves possible, concentration brackets under its centre
-                fused_finish1<NT>(&sh, samp, a.n_sample, a.stride_log2, a.P, a.ylimf, a.pct, a.lam,
+                fused_finish1<NT>(&sh, samp, ts_on ? a.cl_lines * kClusterPx : a.n_sample, ts_on ? -a.cl_scale_log2 : a.stride_log2, a.P, a.ylimf, a.pct, a.lam,
 #ifdef SL_DEBUG_SUBCLK
                                   a.phase_clock ? a.phase_clock + (size_t)a.n_tiles * 8 + (size_t)tile * 16 : nullptr
 #else
@@ -774,11 +1222,12 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
             SL_SUB(7);
             // ---------------- concentration brackets from the sample
             {
+                const bool dense = METHOD == kMethodMacenko && sh.ts.dense != 0;       // block-uniform: the cluster sample of the two-sweep schedule
                 SampleConcKey ckey;
-                ckey.sample = samp; ckey.tab = view_of_b(sh.tab); ckey.L = sh.L; ckey.cps_log2 = a.stride_log2 - 2;
+                ckey.sample = samp; ckey.tab = view_of_b(sh.tab); ckey.L = sh.L; ckey.cps_log2 = dense ? kDenseCps : a.stride_log2 - 2;
                 ckey.P = a.P; ckey.col = 0;
                 float lo[2], hi[2];
-                conc_brackets<NT>(ckey, a.n_sample, lo, hi, sh.S);
+                conc_brackets<NT>(ckey, dense ? a.cl_lines * kClusterPx : a.n_sample, lo, hi, sh.S, dense ? (float)sqrt(kClusterDeff) : 1.0f);
                 if (tid == 0) { sh.lo[0] = lo[0]; sh.hi[0] = hi[0]; sh.lo[1] = lo[1]; sh.hi[1] = hi[1]; }
                 __syncthreads();
             }
@@ -833,6 +1282,7 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
         if (tid == 0 && a.diag_out) a.diag_out[tile] = fallbacks;
         if (tid == 0 && a.sweeps_out) a.sweeps_out[tile] = sweeps_used;
         if (METHOD == kMethodMacenko && tid == 0 && a.cube_out) a.cube_out[tile] = (sh.status == SL_TILE_OK || sh.status == SL_TILE_ZERO_MAXC) ? sh.use_cube : 0;
+        if (METHOD == kMethodMacenko && tid == 0 && a.ts_out) a.ts_out[tile] = sh.ts.why;
         SL_PHASE(6);
         // ---------------- sweep 4: apply
         if (TRANSFORM) {
@@ -850,5 +1300,11 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
 #undef SL_SUB
     }
 }
+
+// host-side launchers of the twelve instantiations, one translation unit per family (transform: with the apply sweep; aligned: 4-byte
+// aligned tiles of a multiple of four pixels)
+void launch_fused_macenko(const FusedArgs& a, bool transform, bool aligned, unsigned grid, hipStream_t s);
+void launch_fused_macenko_wide(const FusedArgs& a, bool transform, bool aligned, unsigned grid, hipStream_t s);
+void launch_fused_vahadane(const FusedArgs& a, bool transform, bool aligned, unsigned grid, hipStream_t s);
 
 }  // namespace sl

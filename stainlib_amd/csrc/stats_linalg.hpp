@@ -32,7 +32,8 @@ __device__ __forceinline__ void jacobi_rot(double& app, double& aqq, double& apq
 }
 
 // sums = {n, Sx, Sy, Sz, Sxx, Sxy, Sxz, Syy, Syz, Szz} -> status, V (binary64 + binary32)
-__device__ __forceinline__ int eigvecs_from_moments(const double* sum, double* Vd, float* Vf) {
+// w_out (optional, [3]): the eigenvalues, largest first (after the canonical choice of a null space: as computed)
+__device__ __forceinline__ int eigvecs_from_moments(const double* sum, double* Vd, float* Vf, double* w_out = nullptr) {
     const double n = sum[0];
     int status = SL_TILE_OK;
     double v0[3] = {1, 0, 0}, v1[3] = {0, 1, 0}, v2[3] = {0, 0, 1};
@@ -80,6 +81,7 @@ __device__ __forceinline__ int eigvecs_from_moments(const double* sum, double* V
             for (int i = 0; i < 3; ++i) v1[i] = u[i] / nu;
         }
     }
+    if (w_out) { w_out[0] = w2; w_out[1] = w1; w_out[2] = w0; }
     const double s2 = v2[0] < 0 ? -1.0 : 1.0, s1 = v1[0] < 0 ? -1.0 : 1.0;      // :26-27
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -215,6 +217,12 @@ struct MergedConc {
     double rho[2], eta[2];     // rho: bound on |r| + eta over the box; eta: rounding allowance of the binary32 evaluations
     LassoD C;                  // the box centre's map, binary64
     LassoK Lc;                 // the box centre's lasso constants (sample keys)
+    // two-sweep schedule (stats_twosweep.hpp): the box also covers a TILT of the eigenvector plane against the sample's.  The exact map
+    // then has a component E_i = (A.W_i . nrm) nrm^T off the plane of the centre's map: a_i(M; x) <= ... + zeta_i |nrm . x|
+    int tilted;                // 0: the box was built under the exact eigenvectors (three-sweep schedule): no such component
+    int pad2_;
+    double nrm[3];             // unit normal of the SAMPLE's eigenvector plane
+    double zeta[2];            // bound on |A.W_i . nrm| over the box
 };
 
 // per-tile state of the merged selection stage in the one-launch-per-phase schedule (the fused kernel keeps it in LDS)
@@ -261,6 +269,8 @@ __device__ __forceinline__ void merged_box(const double* Vd, const float* box, d
     if (lane == 0) {
         mk.ok = (finite && !any_bad) ? 1 : 0;
         mk.pad_ = 0;
+        mk.tilted = 0; mk.pad2_ = 0;
+        mk.nrm[0] = mk.nrm[1] = mk.nrm[2] = 0.0; mk.zeta[0] = mk.zeta[1] = 0.0;
         mk.C = C;
         LassoK Lc;
         lasso_consts(Mc, lam, Lc);
@@ -310,6 +320,7 @@ __device__ __forceinline__ bool merged_verify(const MergedConc& mk, const double
     for (int i = 0; i < 2; ++i) {
         const double e = fmax(fabs(T[i][i] - 1.0), fabs(T[i][1 - i]));
         ok = ok & (e <= (double)mk.eps[i]) & (fabs(r[i]) + mk.eta[i] <= mk.rho[i]);
+        if (mk.tilted) ok = ok & (fabs(A.W[i][0] * mk.nrm[0] + A.W[i][1] * mk.nrm[1] + A.W[i][2] * mk.nrm[2]) <= mk.zeta[i]);
     }
     return ok;
 }

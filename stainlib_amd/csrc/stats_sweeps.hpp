@@ -71,7 +71,7 @@ __device__ __forceinline__ void sample_row(const Chunk& ch, int row0, int lane, 
             const int cc = row0 + lane;
             ok = (cc < c1) & (ALIGNED | ((size_t)cc * 4 + (last ? 3 : 0) < (size_t)P));
         }
-        if (ok) samp[((uint32_t)row0 >> cps_log2) + sl.idx] = v;
+        if (ok) as_global(samp)[((uint32_t)row0 >> cps_log2) + sl.idx] = v;
     }
 }
 
