@@ -114,6 +114,7 @@ typedef struct SlProfile {
 #define SL_TWOSWEEP_SHARE (-2)      /* too many of the sample's pixels in colour-cube cells the mask could not prove plain: not worth it */
 #define SL_TWOSWEEP_PLANE (-3)      /* the exact eigenvector plane left the tilt the sweep allowed for: three-sweep route from the exact moments */
 #define SL_TWOSWEEP_BRACKET (-4)    /* an angular bracket carried over from the estimate missed its rank (or a list overflowed): likewise */
+#define SL_TWOSWEEP_LISTS (-5)      /* the sample predicts more bracket members than the candidate lists hold: not attempted */
 typedef struct SlParams {
     uint32_t struct_size;        /* sizeof(SlParams) of the header the CALLER was compiled against: set by sl_default_params, checked by every
                                     entry point that takes an SlParams (SL_ERR_BADARG on a mismatch) -- a caller built against another

@@ -275,7 +275,8 @@ int run_fused(int method, const uint8_t* rgb, uint8_t* out, int n, long P, const
     a.cube_out = p.prefilter_out;
     a.sample_cap = L.sample_cap;
     // (tiles below 16 Ki pixels keep the three-sweep schedule: their sample would be a fifth of the tile)
-    a.two_sweep = (method != kMethodMacenko || p.two_sweep == 1 || P < (1L << 14)) ? 0 : (p.two_sweep >= 2 && p.two_sweep <= 4 ? p.two_sweep : 1);
+    // (... and SlParams.prefilter = 1, "never behind the colour-cube mask", rules the merged sweep out: it has no per-pixel form)
+    a.two_sweep = (method != kMethodMacenko || p.two_sweep == 1 || P < (1L << 14)) ? 0 : (p.two_sweep >= 2 && p.two_sweep <= 4 ? p.two_sweep : (p.prefilter == 1 ? 0 : 1));
     a.cl_lines = cluster_lines(P);
     a.cl_scale_log2 = 1;
     while (((long)a.cl_lines * kClusterPx << a.cl_scale_log2) < P && a.cl_scale_log2 < 30) ++a.cl_scale_log2;

@@ -553,11 +553,12 @@ __device__ SL_FINISH_ATTR int fused_finish2(FusedShared<NT>* shp, const uint8_t*
 constexpr int kP0Bins = 1024;            // angle keys: pseudo-angle [-1, 1) in 1024 bins; concentrations: 512 bins per stain of c / (c + 1)
 template <int NT>
 __device__ SL_FINISH_ATTR void fused_phase0(FusedShared<NT>* shp, const uint8_t* src_, uint32_t* samp_, int P_, int n_lines_, float ylimf_, double pct_, double lam_,
-                                          int mode_, long long* subclk_) {
+                                          int mode_, int cap_raw_, int cap_ang_, int cap_list_, long long* subclk_) {
     FusedShared<NT>& sh = *shp;
     const uint8_t* src = uni_ptr(src_);
     uint32_t* samp = uni_ptr(samp_);
     const int P = __builtin_amdgcn_readfirstlane(P_), n_lines = __builtin_amdgcn_readfirstlane(n_lines_), mode = __builtin_amdgcn_readfirstlane(mode_);
+    const int cap_raw = __builtin_amdgcn_readfirstlane(cap_raw_), cap_ang = __builtin_amdgcn_readfirstlane(cap_ang_), cap_list = __builtin_amdgcn_readfirstlane(cap_list_);
     const float ylimf = uni(ylimf_);
     const double pct = uni_d(pct_), lam = uni_d(lam_);
     long long* subclk = uni_ptr(subclk_);
@@ -632,7 +633,9 @@ __device__ SL_FINISH_ATTR void fused_phase0(FusedShared<NT>* shp, const uint8_t*
         if (ok) {
             tau = kTiltZ * sqrt(kClusterDeff / ns) * fmax(sqrt(l3 * l2) / (l2 - l3), sqrt(l3 * l1) / (l1 - l3));
             tau = fmax(tau, kTsMinTau);
-            ok = tau <= kTsMaxTau;
+            // Tissue with a strong third component (the ihc fixture: 1.3e-2 here; H&E-like tiles 2-4e-3): the tilt allowance then puts a quarter
+            // of the pixels on the concentration list and the tile would decline at the END of this phase, 170 us later -- it leaves now.
+            ok = tau <= (mode >= 2 ? kTsMaxTau : kTsAutoMaxTau);
         }
         double nd[3] = {Vd[2] * Vd[5] - Vd[4] * Vd[3], Vd[4] * Vd[1] - Vd[0] * Vd[5], Vd[0] * Vd[3] - Vd[2] * Vd[1]};
         const double nn = 1.0 / sqrt(nd[0] * nd[0] + nd[1] * nd[1] + nd[2] * nd[2]);
@@ -802,17 +805,56 @@ __device__ SL_FINISH_ATTR void fused_phase0(FusedShared<NT>* shp, const uint8_t*
             }
             ts_thresholds(sh.mk, e[0], e[2], e[1], e[3], sh.res[0]);
         }
-    } else if (tid == 0) {
-        ts_thresholds(sh.mk, -INFINITY, -INFINITY, -INFINITY, -INFINITY, 0.0f);       // disarms the concentration test
     }
     __syncthreads();
+    // No box of stain matrices (a small tissue sample: the widened ranks leave it; or a box over which the map changes too much): the
+    // concentration candidates could not ride in the sweep, and the three-sweep route, whose stratified sample needs no widening, may
+    // well have its box -- declined.
+    if (!sh.mk.ok && mode < 2) return;                            // block-uniform (ts.why = kTsNoEstimate)
+    if (!sh.mk.ok && tid == 0) ts_thresholds(sh.mk, -INFINITY, -INFINITY, -INFINITY, -INFINITY, 0.0f);       // (forced: the concentration test disarmed)
     if (tid == 0) {
         for (int i = 0; i < 2; ++i) {
             for (int c = 0; c < 3; ++c) sh.ts.W[i][c] = sh.mk.ok ? (float)sh.mk.C.W[i][c] : 0.0f;
             sh.ts.kt[i] = sh.mk.kt[i]; sh.ts.eps[i] = sh.mk.eps[i]; sh.ts.zeta[i] = (float)(sh.mk.zeta[i] * (1.0 + 1e-6)); sh.ts.thr[i] = sh.mk.thr[i];
         }
+        sh.S.misc[34] = 0; sh.S.misc[35] = 0;
     }
     __syncthreads();
+    // Will the lists hold what the sweep is going to collect?  The sweep's own exact test on the sample entries says how many candidates
+    // of either kind to expect.  Real tissue with a strong second stain (the ihc fixture) puts a quarter of its pixels on the
+    // concentration list once the box has to cover a tilt as well -- the uncertainty of the weaker stain's concentration under a
+    // heavily stained pixel is real -- and a list that overflows costs the tile a separate concentration sweep on top (measured:
+    // 2.06 ms per 512 such tiles against 1.62 for three sweeps): such a tile keeps the three-sweep schedule.
+    {
+        uint32_t na = 0, nc = 0;
+        float gH[3], gL[3], nf[3], W[2][3];
+        for (int c = 0; c < 3; ++c) { gH[c] = sh.ts.fgH[c]; gL[c] = sh.ts.fgL[c]; nf[c] = sh.ts.fn[c]; W[0][c] = sh.ts.W[0][c]; W[1][c] = sh.ts.W[1][c]; }
+        const float k1 = sh.ts.fk1;
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const int b = j * NT + tid;
+            const uint32_t r = w[j] & 255u, g = (w[j] >> 8) & 255u, bl = (w[j] >> 16) & 255u;
+            const float ox = tab.odf(r), oy = tab.odf(g), oz = tab.odf(bl);
+            const bool tissue = is_tissue_f(tab.gam(r), tab.gam(g), tab.gam(bl), ylimf);
+            const float z = fabsf(fmaf(nf[2], oz, fmaf(nf[1], oy, nf[0] * ox)));
+            const float tH = fmaf(gH[2], oz, fmaf(gH[1], oy, gH[0] * ox)), tL = fmaf(gL[2], oz, fmaf(gL[1], oy, gL[0] * ox));
+            const bool pp = fmaf(-k1, z, fminf(tH, tL)) > 0.0f;
+            const float a1 = fmaf(W[0][2], oz, fmaf(W[0][1], oy, fmaf(W[0][0], ox, sh.ts.kt[0]))), a2 = fmaf(W[1][2], oz, fmaf(W[1][1], oy, fmaf(W[1][0], ox, sh.ts.kt[1])));
+            const float sa = fabsf(a1) + fabsf(a2);
+            const bool g1 = fmaf(sh.ts.zeta[0], z, fmaf(sh.ts.eps[0], sa, a1)) >= sh.ts.thr[0], g2 = fmaf(sh.ts.zeta[1], z, fmaf(sh.ts.eps[1], sa, a2)) >= sh.ts.thr[1];
+            if (b < n_sample) { na += (tissue && !pp) ? 1u : 0u; nc += (g1 || g2) ? 1u : 0u; }
+        }
+        for (int o = 32; o > 0; o >>= 1) { na += (uint32_t)__shfl_xor((int)na, o, 64); nc += (uint32_t)__shfl_xor((int)nc, o, 64); }
+        if (lane == 0) { atomicAdd(&sh.S.misc[34], na); atomicAdd(&sh.S.misc[35], nc); }
+        __syncthreads();
+        const double scale = (double)P / (double)n_sample;
+        const bool full = (double)sh.S.misc[34] * scale > 0.75 * (double)cap_ang || (double)sh.S.misc[35] * scale > 0.75 * (double)cap_raw ||
+                          (double)sh.S.misc[35] * scale > 1.5 * (double)cap_list;       // (members: most of the candidates, split over two lists)
+        if (full && mode < 2) {                                   // block-uniform
+            if (tid == 0) sh.ts.why = kTsLists;
+            return;
+        }
+    }
     SL_SUB(5);
     // ---------------- the colour cube of the merged sweep
     {
@@ -865,15 +907,19 @@ __device__ __noinline__ void fused_sweep1c(FusedShared<NT>* shp, const uint8_t* 
     const TabReaderB TB = TabReaderB::make_at(FusedLds<NT>::tab);
     const int nch = (P + 3) >> 2;
     TsSweepConsts K;
+    // (wave-uniform constants stay in SGPRs although a vector operation with an SGPR operand issues at half rate: the exact test runs for the
+    //  pixels of ambiguous cells only, and in VGPRs the 24 constants made the drains spill -- measured 1.475-1.50 ms against 1.425-1.45)
+#define SL_TSK(x) uni(x)
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { K.gH[c] = uni(sh.ts.fgH[c]); K.gL[c] = uni(sh.ts.fgL[c]); K.n[c] = uni(sh.ts.fn[c]); }
-    K.k1 = uni(sh.ts.fk1);
+    for (int c = 0; c < 3; ++c) { K.gH[c] = SL_TSK(sh.ts.fgH[c]); K.gL[c] = SL_TSK(sh.ts.fgL[c]); K.n[c] = SL_TSK(sh.ts.fn[c]); }
+    K.k1 = SL_TSK(sh.ts.fk1);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) K.W[i][c] = uni(sh.ts.W[i][c]);
-        K.kt[i] = uni(sh.ts.kt[i]); K.eps[i] = uni(sh.ts.eps[i]); K.zeta[i] = uni(sh.ts.zeta[i]); K.thr[i] = uni(sh.ts.thr[i]);
+        for (int c = 0; c < 3; ++c) K.W[i][c] = SL_TSK(sh.ts.W[i][c]);
+        K.kt[i] = SL_TSK(sh.ts.kt[i]); K.eps[i] = SL_TSK(sh.ts.eps[i]); K.zeta[i] = SL_TSK(sh.ts.zeta[i]); K.thr[i] = uni(sh.ts.thr[i]);
     }
+#undef SL_TSK
     const RawDirect direct{rawl, rawa, reinterpret_cast<unsigned long long*>(&sh.n_raw), (uint32_t)cap_raw, (uint32_t)cap_ang};
     const uint32_t bits_lds = FusedLds<NT>::hist;
     const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(FusedLds<NT>::stage + (uint32_t)wave * FusedLds<NT>::stage_wave));
@@ -1080,9 +1126,18 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
             }
             __syncthreads();
             // ---------------- two-sweep schedule, phase 0: the cluster sample and everything the merged sweep needs (stats_twosweep.hpp)
-            if (a.two_sweep) {                                                // uniform
+            // Every workgroup of a launch starts at the same moment, and phase 0 streams nothing: with both workgroups of a CU in it the chip
+            // idles for its ~170 us (measured: the whole batch two-sweep gains 0-6 %, and a tile that DECLINES in phase 0 loses 10-13 %).  So
+            // on its first tile only the workgroup that was launched second on its CU tries: its phase 0 hides behind its partner's moments
+            // sweep, and it is the one whose tile ends the launch.  Later tiles of a workgroup (batches beyond the resident grid) start while
+            // other workgroups stream.
+#ifndef SL_TS_WHO
+#define SL_TS_WHO younger
+#endif
+            const bool ts_try = a.two_sweep >= 2 || (a.two_sweep == 1 && NT == kFusedThreads && (SL_TS_WHO || tile != (int)blockIdx.x));   // block-uniform
+            if (ts_try) {
                 prio_finish();
-                fused_phase0<NT>(&sh, src, samp, a.P, a.cl_lines, a.ylimf, a.pct, a.lam, a.two_sweep,
+                fused_phase0<NT>(&sh, src, samp, a.P, a.cl_lines, a.ylimf, a.pct, a.lam, a.two_sweep, a.cap_raw, a.cap_ang, a.cap_list,
 #ifdef SL_DEBUG_SUBCLK
                                  // (development: a third region of the clock buffer, only for the tool that allocates it: sl_debug_set_stop(-7))
                                  (a.phase_clock && a.debug_stop == -7) ? a.phase_clock + (size_t)a.n_tiles * 24 + (size_t)tile * 16 : nullptr

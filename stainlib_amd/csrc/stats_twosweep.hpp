@@ -31,14 +31,15 @@ constexpr double kClusterDeff = 2.0;     // design effect assumed for the cluste
 constexpr double kTiltZ = 5.0;           // a-priori tilt bound tau = kTiltZ x the standard error a Gaussian cloud of the sample's size would give
 constexpr double kTiltZ4 = 4.0;          // ... and kTiltZ4 x the standard error the sample's own fourth moments give (whichever is larger)
 constexpr double kTsMinTau = 2e-4, kTsMaxTau = 0.05;
+constexpr double kTsAutoMaxTau = 6e-3;   // automatic mode: a Gaussian tilt bound above this leaves phase 0 right after the eigen-solve (see fused_phase0)
 constexpr int kTsMinTissue = 256;        // tissue entries the sample must hold for an estimate
-constexpr int kTsMaxSharePct = 70;       // above this share of sample pixels in ambiguous cells the two-sweep schedule is declined (measured: spatially
-                                         // smooth tiles at 58 % still run 2 % faster through the merged sweep than through moments + per-pixel selection sweep)
+constexpr int kTsMaxSharePct = 40;       // above this share of sample pixels in ambiguous cells the two-sweep schedule is declined (measured, interleaved: i.i.d. tiles at
+                                         // 13 % gain 6 %, spatially smooth synthetic tiles at 60 % lose 11 % against the three-sweep schedule)
 constexpr int kTsFn = 9;                 // functionals per channel and cell index of the two-sweep cube (ts_cube_tables)
 constexpr int kTsTabFloats = kTsFn * 3 * 32;
 
 // what became of the two-sweep attempt of a tile (SlParams.twosweep_out)
-enum { kTsDirect = 1, kTsOff = 0, kTsNoEstimate = -1, kTsShare = -2, kTsPlane = -3, kTsBracket = -4 };
+enum { kTsDirect = 1, kTsOff = 0, kTsNoEstimate = -1, kTsShare = -2, kTsPlane = -3, kTsBracket = -4, kTsLists = -5 };
 
 struct TwoSweep {
     int ok;                 // phase 0 left an estimate: sweep 1 collects candidates under it

@@ -503,6 +503,7 @@ def test_a_batch_beyond_the_resident_grid_is_split_between_the_schedules():
 def _prefilter_run(dev, Mt, mct, prefilter, **kw):
     from stainlib_amd import engine
     n = dev.shape[0]
+    kw.setdefault("two_sweep", 1)       # these runs compare the selection sweep of the THREE-sweep schedule (tests/test_gpu_twosweep.py has the other)
     p = engine.make_params(schedule=2, prefilter=prefilter, **kw)
     fb = engine.attach_fallbacks(p, n, device="cuda")
     rsw = torch.zeros((n,), dtype=torch.int32, device="cuda")

@@ -62,6 +62,12 @@ for mode, name in ((1, "three-sweep"), (0, "two-sweep")):
         sub = buf.cpu().numpy().astype(np.float64)[n * 24:].reshape(n, 16) * 0.01
         names = ["gather", "sample moments + eig", "fourth moments + angle brackets", "half-spaces + box", "conc brackets + thresholds", "cube tables, share, mask"]
         print("   phase 0: " + "  ".join(f"{nm} {(sub[:, i + 1] - sub[:, i]).mean():.1f}" for i, nm in enumerate(names[:6])) + f"  tail {(t[:, 4] - sub[:, 6]).mean():.1f}")
+    sb = buf.cpu().numpy().astype(np.float64)[n * 8: n * 24].reshape(n, 16) * 0.01
+    sel = direct if mode == 0 else np.ones(n, bool)
+    if sel.any():
+        f = [("sums+eig", sb[:, 1] - t[:, 1]), ("verify / finish 1 + sweep 2", sb[:, 2] - sb[:, 1]), ("refine angle", sb[:, 3] - sb[:, 2]), ("pick angle", sb[:, 5] - sb[:, 3]),
+             ("M + verify", sb[:, 6] - sb[:, 5]), ("refine conc", sb[:, 14] - sb[:, 6]), ("pick conc", sb[:, 15] - sb[:, 14]), ("tail -> apply", t[:, 6] - sb[:, 15])]
+        print("   finish steps (tiles on this route): " + "  ".join(f"{nm} {v[sel].mean():.1f}" for nm, v in f))
     cnt = buf.cpu().numpy().astype(np.float64)[n * 8: n * 24].reshape(n, 16)[:, 8:12] * 0.01
     print("   lists per tile (mean / max): angular candidates %.0f / %.0f, concentration candidates %.0f / %.0f, angle members %.0f / %.0f, concentration members %.0f / %.0f" % (
         cnt[:, 0].mean(), cnt[:, 0].max(), cnt[:, 1].mean(), cnt[:, 1].max(), cnt[:, 2].mean(), cnt[:, 2].max(), cnt[:, 3].mean(), cnt[:, 3].max()))
