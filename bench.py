@@ -708,6 +708,8 @@ def main():
     params.resweeps_out = resweeps.data_ptr()
     prefilter = torch.zeros((B,), dtype=torch.int32, device=dev)    # bit 0: the selection sweep ran behind the colour-cube mask; bits 8..: share (%)
     params.prefilter_out = prefilter.data_ptr()
+    twosweep = torch.zeros((B,), dtype=torch.int32, device=dev)     # SL_TWOSWEEP_* per tile: what became of the two-sweep attempt
+    params.twosweep_out = twosweep.data_ptr()
 
     def step(p):
         return engine.macenko_transform(rgb, Mt, mct, params=p, out=out, ws=ws)
@@ -850,8 +852,10 @@ def main():
         # For the per-phase schedule the dominant kernel is its k_apply launches (6 B/px)
         fused = [(t, ms) for tag, t, ms in timed_pairs if tag == _ffi.PROF_FUSED_TRANSFORM]
         if fused:
-            bpp_sched = 12.0 + 3.0 * n_resweeps / max(B, 1)
-            dom_name = "k_macenko_fused<transform> (mask+moments+sample, merged angle/concentration select, apply: 3 read sweeps + 1 write)"
+            n_direct = int((twosweep == 1).sum())
+            bpp_sched = 12.0 - 3.0 * n_direct / max(B, 1) + 3.0 * n_resweeps / max(B, 1)
+            dom_name = ("k_macenko_fused<transform> (three-sweep route: moments + sample, merged angle/concentration select, apply; "
+                        "two-sweep route: cluster sample, moments + candidates, apply)")
             dom = fused
         else:
             dom_name, bpp_sched = "k_apply (OD + reconstruction pass)", 6.0
@@ -940,6 +944,25 @@ def main():
                       "north_star_tolerance": 1e-4}
             del out_fused
 
+        # round 5: the two-read-sweep route (SlParams.two_sweep; stats_twosweep.hpp) against the three-sweep one, interleaved on this box
+        def _ab(modes, reps=5):
+            ps = [engine.make_params(two_sweep=m) for m in modes]
+            ts_ = [[] for _ in modes]
+            for _ in range(reps):
+                for i, pm in enumerate(ps):
+                    step(pm)
+                    ts_[i].append(_timed(lambda: step(pm), reps=3, warm=1))
+            return [float(np.median(t)) for t in ts_]
+        ab = _ab((1, 0, 2))
+        codes, counts = np.unique(twosweep.cpu().numpy(), return_counts=True)
+        two_sweep_ab = {"attempts_in_the_timed_run": {str(int(c)): int(k) for c, k in zip(codes, counts)},
+                        "codes": "1 direct (two read sweeps), 0 not attempted, -1 no estimate, -2 colour-cube share, -3 plane check failed, "
+                                 "-4 bracket missed, -5 lists predicted full",
+                        "interleaved_ms_per_launch": {"three_sweep (two_sweep=1)": round(ab[0], 4), "automatic (default)": round(ab[1], 4),
+                                                      "every tile tries (two_sweep=2)": round(ab[2], 4)},
+                        "note": "automatic: on its first tile only the workgroup launched second on its CU tries (phase 0 streams nothing: with both "
+                                "workgroups of a CU in it at the start of a launch the chip idles); results are identical in every mode (tests)"}
+
         line = {
             "metric": "1024x1024 H&E tiles/sec normalized (Macenko)",
             "value": round(tiles_per_s, 1),
@@ -969,8 +992,8 @@ def main():
                          "bytes_model": "SURVEY 8(d) compulsory traffic: 3 B/px read + 3 B/px written, x tiles per launch",
                          "avg_launch_ms": round(dom_ms, 5), "launches_timed": len(dom), "tiles_per_launch": dom_tiles,
                          "schedule_model": {"bytes_per_pixel": bpp_sched, "achieved": round(sched_gbs, 1), "frac": round(sched_gbs / HBM_PEAK_GBS, 4),
-                                            "note": "what the kernel's own schedule moves (3 dependent read sweeps + 1 write, + 3 B/px per "
-                                                    "tile that needed the separate concentration sweep): a description of the schedule, "
+                                            "note": "what the kernel's own schedule moves (3 dependent read sweeps + 1 write; 2 + 1 for a tile on the "
+                                                    "two-sweep route; + 3 B/px per tile that needed the separate concentration sweep): a description of the schedule, "
                                                     "not the roofline fraction -- fewer sweeps LOWER it"},
                          "traffic_over_algorithmic": (round(traffic_dom / dom_bytes, 3) if traffic_dom else None),
                          "traffic_rate": ({"GBps": round(traffic_dom / (dom_ms * 1e-3) / 1e9, 1),
@@ -997,6 +1020,7 @@ def main():
                           "mean_share_of_sample_pixels_in_ambiguous_cells_pct": round(float((prefilter >> 8).float().mean()), 1),
                           "note": "round 4: finish 1 builds a 32^3-cell mask of provably plain colours per tile; sweep 2 tests one bit per pixel and "
                                   "re-tests only the pixels of the other cells exactly (SlParams.prefilter; results do not depend on it)"},
+            "two_sweep": two_sweep_ab,
             "parity": parity,
             "distributed": {"backend": (dist.get_backend() if dist_on else None), "world_size": (dist.get_world_size() if dist_on else 1),
                             "per_rank_tiles_per_s": [round(x, 1) for x in per_rank], "ranks": ranks, "device_of_rank0": dev_index,

@@ -21,8 +21,8 @@ def test_normalizer_fit_transform_like_the_reference():
         n = cls()
         assert n.fit(tgt) is None
         assert n.stain_matrix_target.shape == (2, 3) and n.maxC_target.shape == (1, 2)
-        np.testing.assert_allclose(n.stain_matrix_target, g["M_target"], rtol=0, atol=2e-6)
-        np.testing.assert_allclose(n.maxC_target, g["maxC_target"], rtol=2e-6)
+        np.testing.assert_allclose(n.stain_matrix_target, g["M_target"], rtol=0, atol=5e-7)
+        np.testing.assert_allclose(n.maxC_target, g["maxC_target"], rtol=5e-7)
         out = n.transform(I)
         assert isinstance(out, np.ndarray) and out.dtype == np.uint8 and out.shape == I.shape
         u8_parity(out, g["out"])
@@ -42,9 +42,9 @@ def test_extractor_and_utils():
     from stainlib_amd.utils import stain_utils as su
     I = so.synth_tile(128, 128, 6)
     M = sl.MacenkoStainExtractor.get_stain_matrix(I)
-    np.testing.assert_allclose(M, so.macenko_stain_matrix(I), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(M, so.macenko_stain_matrix(I), rtol=0, atol=5e-7)
     M95 = sl.MacenkoStainExtractor.get_stain_matrix(I, luminosity_threshold=0.75, angular_percentile=95)
-    np.testing.assert_allclose(M95, so.macenko_stain_matrix(I, 0.75, 95), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(M95, so.macenko_stain_matrix(I, 0.75, 95), rtol=0, atol=5e-7)
     mask = su.LuminosityThresholdTissueLocator.get_tissue_mask(I)
     assert mask.dtype == bool and mask.shape == (128, 128)
     assert np.array_equal(mask, so.tissue_mask(I))                       # integer path: bit-exact
@@ -157,7 +157,7 @@ def test_stain_augmentor_vs_reference_golden(path):
     I = so.synth_tile(int(g["size"]), int(g["size"]), int(g["seed"]))
     a = sl.StainAugmentor("macenko", augment_background=bool(g["background"]))
     a.fit(I)
-    np.testing.assert_allclose(a.stain_matrix, g["M"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(a.stain_matrix, g["M"], rtol=0, atol=5e-7)
     assert a.image_shape == I.shape and a.n_stains == 2
     np.random.seed(int(g["npseed"]))
     o0, o1 = a.pop(), a.pop()
@@ -182,8 +182,8 @@ def test_slide_level_mode_single_rank():
     Ms = np.median(np.stack([f[0] for f in fits]), axis=0)
     Ms /= np.linalg.norm(Ms, axis=1)[:, None]
     mcs = np.median(np.stack([np.percentile(so.get_concentrations(I, f[0]), 99, axis=0) for I, f in zip(tiles[:6], fits)]), axis=0)
-    np.testing.assert_allclose(M_s.cpu().numpy(), Ms, rtol=0, atol=2e-6)
-    np.testing.assert_allclose(mc_s.cpu().numpy(), mcs, rtol=2e-6)
+    np.testing.assert_allclose(M_s.cpu().numpy(), Ms, rtol=0, atol=5e-7)
+    np.testing.assert_allclose(mc_s.cpu().numpy(), mcs, rtol=5e-7)
     on = so.ExtractiveStainNormalizer("macenko")
     on.fit(tgt)
     for i in range(6):
@@ -226,8 +226,8 @@ def test_pooled_slide_mode_matches_reference_on_concatenated_tiles():
     dev = to_dev(tiles)
     stats = PooledSlideStatistics()
     M_got, maxC_got = stats(dev)
-    np.testing.assert_allclose(M_got, M_want, rtol=0, atol=2e-6)
-    np.testing.assert_allclose(maxC_got, maxC_want, rtol=2e-6)
+    np.testing.assert_allclose(M_got, M_want, rtol=0, atol=5e-7)
+    np.testing.assert_allclose(maxC_got, maxC_want, rtol=5e-7)
     assert stats.last_path == ["window", "window"]                        # one sweep per stage
     # the exact fallback (a window that misses): force it and compare -- the two paths select the same keys
     from stainlib_amd import distributed as sd
@@ -273,8 +273,8 @@ def test_pooled_slide_mode_matches_reference_on_concatenated_tiles():
     s5 = PooledSlideStatistics()
     M5, c5 = s5(to_dev(struct))
     print("structured slide: selection paths", s5.last_path)
-    np.testing.assert_allclose(M5, M_ws, rtol=0, atol=2e-6)
-    np.testing.assert_allclose(c5, c_ws, rtol=2e-6)
+    np.testing.assert_allclose(M5, M_ws, rtol=0, atol=5e-7)
+    np.testing.assert_allclose(c5, c_ws, rtol=5e-7)
     assert s5.last_path == ["window", "window"]          # the sample is good enough to centre the window on a structured slide too
     tgt = so.synth_tile(128, 128, 1001, so.M_TRUE_TGT)
     n = sl.MacenkoNormalizer()
@@ -513,8 +513,8 @@ def test_device_driven_pooled_statistics_match_the_host_driven_rounds_and_captur
     np.testing.assert_allclose(mc_d, mc_h, rtol=1e-13)
     tall = np.concatenate(tiles, axis=0)
     M_ref = so.macenko_stain_matrix(tall)
-    np.testing.assert_allclose(M_d, M_ref, rtol=0, atol=2e-6)
-    np.testing.assert_allclose(mc_d, np.percentile(so.get_concentrations(tall, M_ref), 99, axis=0), rtol=2e-6)
+    np.testing.assert_allclose(M_d, M_ref, rtol=0, atol=5e-7)
+    np.testing.assert_allclose(mc_d, np.percentile(so.get_concentrations(tall, M_ref), 99, axis=0), rtol=5e-7)
     # captured once, replayed on new contents of the same tensor
     from stainlib_amd import engine
     ws = engine.Workspace()

@@ -12,8 +12,10 @@ from tests.gpu_util import oracle_fit_tile, to_dev, u8_parity
 
 pytestmark = pytest.mark.gpu
 
-M_ATOL = 2e-6       # stain-matrix tolerance (unit-norm rows): binary32 keys, binary64 everything else
-MAXC_RTOL = 2e-6
+# measured against the float64 oracle: stain matrix <= 1.4e-7, maxC <= 2.6e-7 relative over 300 random small tiles (tools/small_tile_errors.py),
+# 5.3e-8 / 1.9e-7 on the bench batch: the bars sit a factor 2-4 above what the kernel delivers (round-4 review: were 2e-6)
+M_ATOL = 5e-7       # stain-matrix tolerance (unit-norm rows): binary32 keys, binary64 everything else
+MAXC_RTOL = 5e-7
 
 
 def _fit_oracle(I):
@@ -611,3 +613,39 @@ def test_the_1024_thread_fused_kernel_agrees_with_both_other_schedules():
             ok = (ref[3] == 0)
             np.testing.assert_allclose(got[1][ok].cpu().numpy(), ref[1][ok].cpu().numpy(), rtol=0, atol=1e-12)
             np.testing.assert_allclose(got[2][ok].cpu().numpy(), ref[2][ok].cpu().numpy(), rtol=1e-12)
+
+
+def _real_tissue_1024():
+    ihc = np.load(os.path.join(os.path.dirname(__file__), "golden", "tissue_ihc_512.npz"))["input"]
+    row = np.concatenate([ihc, ihc[:, ::-1]], axis=1)
+    return np.ascontiguousarray(np.concatenate([row, row[::-1]], axis=0))
+
+
+@pytest.mark.parametrize("which", ["golden_1024", "real_tissue"])
+def test_end_to_end_pre_quantisation_error(which):
+    """The north star's figure on reconstructed RGB, END TO END (round-4 review: no test asserted it): the values before the truncating
+    cast -- the device's statistics of the tile, then the device's apply pass (sl_normalize_apply hands them out; its bytes are the
+    fused transform's by construction, asserted here) -- against the float64 oracle's 255 exp(-C M_t).  Bar 1e-5 relative: the
+    north star allows 1e-4, the kernel delivers ~1.5e-6."""
+    from stainlib_amd import engine
+    if which == "golden_1024":
+        g = np.load(os.path.join(os.path.dirname(__file__), "golden", "macenko_1024_s1.npz"))
+        I = so.synth_tile(1024, 1024, int(g["seed"]))
+        tgt = so.synth_tile(1024, 1024, 1000 + int(g["seed"]), so.M_TRUE_TGT)
+    else:
+        I = _real_tissue_1024()
+        tgt = so.synth_tile(256, 256, 1001, so.M_TRUE_TGT)
+    Mt, mct = _fit_oracle(tgt)
+    dev = to_dev([I])
+    out, M, mc, st = engine.macenko_transform(dev, Mt, mct)
+    assert int(st[0]) == 0
+    out2, pre = engine.normalize_apply(dev, M, mc, Mt, mct, want_prequant=True)
+    assert torch.equal(out, out2)
+    Mo, mco = _fit_oracle(I)
+    want = 255.0 * np.exp(-(so.get_concentrations(I, Mo) * (mct / mco)) @ Mt)
+    got = pre.cpu().numpy().reshape(-1, 3).astype(np.float64)
+    rel = np.abs(got - want) / np.maximum(np.abs(want), 1.0)
+    print(f"end-to-end pre-quantisation error ({which}): max {rel.max():.2e}, 99.9 % {np.percentile(rel, 99.9):.2e}; "
+          f"|M - oracle| {np.abs(M.cpu().numpy()[0] - Mo).max():.1e}, maxC rel {np.abs(mc.cpu().numpy()[0] / mco - 1).max():.1e}")
+    assert rel.max() <= 1e-5
+    u8_parity(out.cpu().numpy()[0], so.truncate_u8(want).reshape(I.shape), label=f"end to end, {which}", src=I)

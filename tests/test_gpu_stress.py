@@ -57,8 +57,8 @@ def test_random_small_tiles_against_the_oracle():
         out, M, mc, st = engine.macenko_transform(to_dev([I]), torch.as_tensor(Mt, device="cuda"), torch.as_tensor(mct, device="cuda"), params=p)
         label = f"{kind} {h}x{w} seed {seed} thr {thr} pct {pct} schedule {p.schedule} prefilter {p.prefilter}"
         assert int(st[0]) == 0, label
-        np.testing.assert_allclose(M.cpu().numpy()[0], Mo, rtol=0, atol=5e-6, err_msg=label)
-        np.testing.assert_allclose(mc.cpu().numpy()[0], mco, rtol=5e-6, err_msg=label)
+        np.testing.assert_allclose(M.cpu().numpy()[0], Mo, rtol=0, atol=5e-7, err_msg=label)
+        np.testing.assert_allclose(mc.cpu().numpy()[0], mco, rtol=5e-7, err_msg=label)
         pre = 255 * np.exp(-(Co * (mct / mco)) @ Mt)
         want = so.truncate_u8(pre).reshape(I.shape)
         u8_parity(out.cpu().numpy()[0], want, label=label, src=I, prequant=pre)
@@ -120,8 +120,8 @@ def test_random_mid_size_tiles_against_the_oracle():
             out, M, mc, st = engine.macenko_transform(to_dev([I]), torch.as_tensor(Mt, device="cuda"), torch.as_tensor(mct, device="cuda"), params=p)
             label = f"{kind} {h}x{w} seed {seed} background {frac} thr {thr} pct {pct} schedule {sched} prefilter {pf}"
             assert int(st[0]) == 0, label
-            np.testing.assert_allclose(M.cpu().numpy()[0], Mo, rtol=0, atol=5e-6, err_msg=label)
-            np.testing.assert_allclose(mc.cpu().numpy()[0], mco, rtol=5e-6, err_msg=label)
+            np.testing.assert_allclose(M.cpu().numpy()[0], Mo, rtol=0, atol=5e-7, err_msg=label)
+            np.testing.assert_allclose(mc.cpu().numpy()[0], mco, rtol=5e-7, err_msg=label)
             outs.append(out)
             if sched == 2 and pf == 0:
                 routes[int(rs[0])] = routes.get(int(rs[0]), 0) + 1

@@ -15,8 +15,8 @@ pytestmark = pytest.mark.gpu
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TISSUE = sorted(glob.glob(os.path.join(GOLDEN, "tissue_*.npz")))
-M_ATOL = 2e-6
-MAXC_RTOL = 2e-6
+M_ATOL = 5e-7      # (round 5: were 2e-6; the kernel delivers <= 1.4e-7 / 2.6e-7, tools/small_tile_errors.py)
+MAXC_RTOL = 5e-7
 
 
 def mirror_tile(I, size):
