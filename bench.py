@@ -169,21 +169,39 @@ def cpu_baseline(size: int, transforms_per_core: int = 20):
     t_single = _cpu_worker((None, 0, 4, size, Mt, mct)) / 4.0                    # mode A: one process, one thread
     split = _cpu_stage_split(size, Mt, mct)
     ctx = mp.get_context("fork")
-    with ctx.Pool(len(cpus)) as pool:                                            # mode B: one pinned process per physical core
-        el = pool.map(_cpu_worker, [(cpu, k + 1, transforms_per_core, size, Mt, mct) for k, cpu in enumerate(cpus)])
-    value = len(cpus) * transforms_per_core / max(el)
+
+    def run(procs, per_proc):                                                    # mode B: `procs` pinned single-thread processes, spread over the cores
+        use = [cpus[(i * len(cpus)) // procs] for i in range(procs)]
+        with ctx.Pool(procs) as pool:
+            el_ = pool.map(_cpu_worker, [(cpu, k + 1, per_proc, size, Mt, mct) for k, cpu in enumerate(use)])
+        return procs * per_proc / max(el_), el_
+
+    # the port is memory-bound (25 MB float64 temporaries, ~30 per transform): one process per core is its WORST operating point on a shared host
+    # (round-4 review).  A small sweep of process counts; the reported value is the best of it, with its process count.
+    sweep = {}
+    el = None
+    for procs in sorted({c for c in (8, 16, 32, 64, len(cpus)) if c <= len(cpus)}):
+        per = transforms_per_core if procs == len(cpus) else max(4, transforms_per_core // 3)
+        rate, el_ = run(procs, per)
+        sweep[procs] = round(rate, 3)
+        if procs == len(cpus):
+            el = el_
+    best = max(sweep, key=lambda k: sweep[k])
+    value = sweep[best]
     cross = None
     try:
         cross = json.load(open(os.path.join(REPO, "profiles", "r02_cpu_crosscheck.json")))
     except Exception:  # noqa: BLE001
         pass
     return {
-        "value": round(value, 3), "unit": "tiles/s", "cores": len(cpus), "kind": "port",
-        "sample": f"{len(cpus)} processes (one per physical core of the {n_logical} logical CPUs this job may use, each pinned, 1 thread) x "
-                  f"{transforms_per_core} transforms of {size}x{size} tiles (numpy oracle of the reference's op sequence, float64; 4 distinct "
-                  f"tiles cycled); slowest process {max(el):.1f} s, fastest {min(el):.1f} s",
+        "value": round(value, 3), "unit": "tiles/s", "cores": best, "kind": "port",
+        "sample": f"best of a sweep over {sorted(sweep)} pinned single-thread processes (of {len(cpus)} physical cores / {n_logical} logical CPUs this job may "
+                  f"use): {best} processes; {transforms_per_core} transforms of {size}x{size} tiles per process at {len(cpus)} processes, "
+                  f"{max(4, transforms_per_core // 3)} at the smaller counts (numpy oracle of the reference's op sequence, float64; 4 distinct tiles cycled); "
+                  f"at {len(cpus)} processes the slowest took {max(el):.1f} s, the fastest {min(el):.1f} s",
+        "tiles_per_s_by_process_count": {str(k): v for k, v in sorted(sweep.items())},
         "single_core_tiles_per_s": round(1.0 / t_single, 3),
-        "parallel_efficiency": round(value / (len(cpus) / t_single), 3),
+        "parallel_efficiency": round(value / (best / t_single), 3),
         "stage_seconds_single_thread": split,
         "note": "the lasso stage is a vectorised closed form, not spams' OpenMP LARS, and the mask an integer-table restatement, not "
                 "OpenCV: the reference's own third-party calls cannot be timed (absent); the stage split lets the reader discount them. "

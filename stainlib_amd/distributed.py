@@ -216,9 +216,14 @@ class PooledSlideStatistics:
     def enqueue(self, tiles_local: torch.Tensor, ws=None, n_tiles_total: Optional[int] = None) -> torch.Tensor:
         """DEVICE-DRIVEN: enqueue the whole computation (4 full sweeps, 6 sampled passes, the all-reduces between them and the
         single-workgroup decision steps) on the current stream and return the pool state tensor (device float64,
-        _ffi.POOL_STATE_DOUBLES) WITHOUT reading anything back: state[POOL_M:POOL_M+6] / state[POOL_MAXC:+2] are the slide's stain
-        matrix and maxC once state[POOL_STATUS] == 0 and state[POOL_MISS] == 0 (``finish`` checks them with one read-back).  Every
-        rank reaches the same state: each step consumes all-reduced data only.  On one rank the chain is graph-capturable."""
+        _ffi.POOL_STATE_DOUBLES): state[POOL_M:POOL_M+6] / state[POOL_MAXC:+2] are the slide's stain matrix and maxC once
+        state[POOL_STATUS] == 0 and state[POOL_MISS] == 0 (``finish`` checks them with one read-back).  Every rank reaches the same
+        state: each step consumes all-reduced data only.
+        With ``n_tiles_total`` (the slide's tile count over ALL ranks -- every rank must pass the same value, or none of them may) nothing
+        is read back and no extra collective runs; on one rank the chain is then graph-capturable.  WITHOUT it, on more than one rank,
+        the sample density is agreed on with one small MAX all-reduce of the shard sizes whose result IS read back (a host
+        synchronisation per call): pass the total where the call sits on a latency-critical path.  Ranks that disagree on whether they
+        pass it issue different collective sequences and hang -- it is part of the call's collective contract."""
         import math
         from . import engine, _ffi
         params = engine.make_params(luminosity_threshold=self.thr, angular_percentile=self.pct, lasso_lambda=self.lam)
@@ -274,9 +279,10 @@ class PooledSlideStatistics:
         self.last_path = ["window", "window"]
         return s[_ffi.POOL_M:_ffi.POOL_M + 6].reshape(2, 3).copy(), s[_ffi.POOL_MAXC:_ffi.POOL_MAXC + 2].copy()
 
-    def __call__(self, tiles_local: torch.Tensor, device_driven: bool = True):
+    def __call__(self, tiles_local: torch.Tensor, device_driven: bool = True, n_tiles_total: Optional[int] = None):
+        """(M, maxC) of the slide.  n_tiles_total: see ``enqueue`` (the same on every rank, or on none)."""
         if device_driven:
-            got = self.finish(self.enqueue(tiles_local))
+            got = self.finish(self.enqueue(tiles_local, n_tiles_total=n_tiles_total))
             if got is not None:
                 return got
         return self.host_driven(tiles_local)

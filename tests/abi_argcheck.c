@@ -57,6 +57,23 @@ int main(void) {
         EXPECT(sl_vahadane_transform(rgb, 0, n, h, w, &p, d6, d2, 0, 0, 0, ws, needv, 0), SL_ERR_BADARG);
     }
     p.schedule = 0;
+    /* SlParams.struct_size: set by sl_default_params; a struct of another size (a caller built against another header) is refused by
+     * every entry point that takes one, before anything else is looked at */
+    EXPECT(p.struct_size == sizeof(SlParams), 1);
+    {
+        const uint32_t sizes[] = {0u, (uint32_t)sizeof(SlParams) - 8u, (uint32_t)sizeof(SlParams) + 8u};
+        for (unsigned i = 0; i < 3; ++i) {
+            SlParams q = p;
+            q.struct_size = sizes[i];
+            EXPECT(sl_macenko_fit(rgb, n, h, w, &q, d6, d2, st, ws, need, 0), SL_ERR_BADARG);
+            EXPECT(sl_macenko_transform(rgb, out, n, h, w, &q, d6, d2, 0, 0, 0, ws, need, 0), SL_ERR_BADARG);
+            EXPECT(sl_vahadane_fit(rgb, n, h, w, &q, d6, d2, st, st, ws, needv, 0), SL_ERR_BADARG);
+            EXPECT(sl_vahadane_transform(rgb, out, n, h, w, &q, d6, d2, 0, 0, 0, ws, needv, 0), SL_ERR_BADARG);
+            EXPECT(sl_stain_augment(rgb, out, n, h, w, d6, d6, 0, &q, 0), SL_ERR_BADARG);
+            EXPECT(sl_tile_moments(rgb, n, h, w, &q, d6, ws, sl_workspace_bytes(SL_OP_TILE_MOMENTS, n, h, w), 0), SL_ERR_BADARG);
+            EXPECT(sl_pool_begin(d6, &q, d6, 0), SL_ERR_BADARG);
+        }
+    }
     /* single-pass operators */
     EXPECT(sl_normalize_apply(0, out, n, h, w, d6, d2, d6, d2, 0.01, 0, 0), SL_ERR_BADARG);
     EXPECT(sl_normalize_apply(rgb, 0, n, h, w, d6, d2, d6, d2, 0.01, 0, 0), SL_ERR_BADARG);
