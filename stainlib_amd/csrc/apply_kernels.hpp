@@ -145,6 +145,28 @@ __device__ __forceinline__ float fma_clamp01(float r, float m, float a) {
 #endif
 }
 
+// The lasso's min(a_other, 0) without a v_min_f32 (a 4-cycle instruction; multiplies and FMAs issue in 2): the concentrations are
+// carried scaled into [-1, 1], so  -min(a, 0) = max(0, min(1, -a))  is ONE v_mul_f32 by -1 with the clamp modifier, and the FMA that
+// follows takes r negated.  Bit-identical to the v_min form (a negation is exact; NaN clamps to 0 as fminf(NaN, 0) gives 0).
+__device__ __forceinline__ float neg_part01(float a) {          // -min(a, 0) for |a| <= 1
+#ifdef SL_EXP_NOCLAMP
+    return -fminf(a, 0.0f);
+#else
+    float o;
+    asm("v_mul_f32 %0, -1.0, %1 clamp" : "=v"(o) : "v"(a));
+    return o;
+#endif
+}
+__device__ __forceinline__ float fnma_clamp01(float r, float m, float a) {     // max(a - r m, 0) for results in [-1, 1]
+#ifdef SL_EXP_NOCLAMP
+    return fmaxf(fmaf(-r, m, a), 0.0f);
+#else
+    float o;
+    asm("v_fma_f32 %0, -%1, %2, %3 clamp" : "=v"(o) : "v"(r), "v"(m), "v"(a));
+    return o;
+#endif
+}
+
 __device__ __forceinline__ void apply_consts(const double* M_src, const double* maxC_src, const double* M_tgt,
                                              const double* maxC_tgt, double lam, ApplyK& K) {
     lasso_consts(M_src, lam, K.L);
@@ -172,8 +194,8 @@ __device__ __forceinline__ void apply_px(const ApplyK& K, float x, float y, floa
     if (FAST) {                                    // g12 >= 0: branch-free lasso (see lasso2)
         float a1, a2;
         lasso_interior(K.L, x, y, z, a1, a2);
-        c1 = fma_clamp01(K.L.r1, fminf(a2, 0.0f), a1);
-        c2 = fma_clamp01(K.L.r2, fminf(a1, 0.0f), a2);
+        c1 = fnma_clamp01(K.L.r1, neg_part01(a2), a1);
+        c2 = fnma_clamp01(K.L.r2, neg_part01(a1), a2);
     } else {
         lasso2(K.L, x, y, z, c1, c2);
     }
@@ -378,8 +400,8 @@ __device__ __forceinline__ void augment_sweep(const uint8_t* src, uint8_t* dst, 
             if (FAST) {                                    // g12 >= 0: branch-free lasso (see lasso2, apply_px)
                 float i1, i2;
                 lasso_interior(K.L, er.y, eg.y, eb.y, i1, i2);
-                a1 = fma_clamp01(K.L.r1, fminf(i2, 0.0f), i1);
-                a2 = fma_clamp01(K.L.r2, fminf(i1, 0.0f), i2);
+                a1 = fnma_clamp01(K.L.r1, neg_part01(i2), i1);
+                a2 = fnma_clamp01(K.L.r2, neg_part01(i1), i2);
             } else {
                 lasso2(K.L, er.y, eg.y, eb.y, a1, a2);
             }

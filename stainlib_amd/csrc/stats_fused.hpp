@@ -578,6 +578,7 @@ __device__ SL_FINISH_ATTR void fused_phase0(FusedShared<NT>* shp, const uint8_t*
     // ---------------- the sample: gathered into registers (8 loads in flight), written out for the fallback routes, summed on the way
     uint32_t w[KPT];
     Moments mo;
+    BurstMoments bm;                                              // (binary32 sums of a thread's <= 32 entries: the estimate needs no more)
     double cnt = 0.0;
     {
         const uint32_t nl = (uint32_t)(((3ll * P) >> 7) < 1 ? 1 : ((3ll * P) >> 7));
@@ -596,12 +597,13 @@ __device__ SL_FINISH_ATTR void fused_phase0(FusedShared<NT>* shp, const uint8_t*
                     as_global(samp)[b] = w[j0 + u];
                     const uint32_t r = w[j0 + u] & 255u, g = (w[j0 + u] >> 8) & 255u, bl = (w[j0 + u] >> 16) & 255u;
                     if (is_tissue_f(tab.gam(r), tab.gam(g), tab.gam(bl), ylimf)) {
-                        mo.add((double)tab.odf(r), (double)tab.odf(g), (double)tab.odf(bl));
+                        bm.add(tab.odf(r), tab.odf(g), tab.odf(bl));
                         cnt += 1.0;
                     }
                 }
             }
         }
+        bm.flush(mo);
     }
     {
         double v[10];
@@ -769,18 +771,23 @@ __device__ SL_FINISH_ATTR void fused_phase0(FusedShared<NT>* shp, const uint8_t*
     // ---------------- concentration brackets under the box centre: both stains' keys as c / (c + 1) into 512 bins each
     if (sh.mk.ok) {                                               // block-uniform
         LassoK L = sh.mk.Lc;
+        uint32_t nz1 = 0, nz2 = 0;                                // wave-uniform
 #pragma unroll
         for (int j = 0; j < KPT; ++j) {
             const int b = j * NT + tid;
             float c1, c2;
             lasso2(L, tab.odf(w[j] & 255u), tab.odf((w[j] >> 8) & 255u), tab.odf((w[j] >> 16) & 255u), c1, c2);
-            if (b < n_sample) {
-                const int b1 = min(511, max(0, (int)(512.0f * c1 * __builtin_amdgcn_rcpf(c1 + 1.0f))));
-                const int b2 = min(511, max(0, (int)(512.0f * c2 * __builtin_amdgcn_rcpf(c2 + 1.0f))));
-                atomicAdd(&sh.S.hist[b1], 1u);
-                atomicAdd(&sh.S.hist[512 + b2], 1u);
-            }
+            const int b1 = min(511, max(0, (int)(512.0f * c1 * __builtin_amdgcn_rcpf(c1 + 1.0f))));
+            const int b2 = min(511, max(0, (int)(512.0f * c2 * __builtin_amdgcn_rcpf(c2 + 1.0f))));
+            // (background pixels all have concentration 0: thousands of atomics on ONE bin took most of this step -- entries of bin 0 are
+            //  counted off the ballot instead, one add per wave and row)
+            const bool in = b < n_sample;
+            const unsigned long long z1 = __builtin_amdgcn_ballot_w64(in & (b1 == 0)), z2 = __builtin_amdgcn_ballot_w64(in & (b2 == 0));
+            if (in & (b1 != 0)) atomicAdd(&sh.S.hist[b1], 1u);
+            if (in & (b2 != 0)) atomicAdd(&sh.S.hist[512 + b2], 1u);
+            nz1 += (uint32_t)__popcll(z1); nz2 += (uint32_t)__popcll(z2);
         }
+        if (lane == 0) { if (nz1) atomicAdd(&sh.S.hist[0], nz1); if (nz2) atomicAdd(&sh.S.hist[512], nz2); }
         __syncthreads();
         if (wave < 4) {                                           // ranks of the 99th percentile of ALL sample entries -/+ z sigma, per stain
             const int col = wave >> 1, upper = wave & 1;
@@ -807,6 +814,7 @@ __device__ SL_FINISH_ATTR void fused_phase0(FusedShared<NT>* shp, const uint8_t*
         }
     }
     __syncthreads();
+    SL_SUB(7);
     // No box of stain matrices (a small tissue sample: the widened ranks leave it; or a box over which the map changes too much): the
     // concentration candidates could not ride in the sweep, and the three-sweep route, whose stratified sample needs no widening, may
     // well have its box -- declined.
@@ -820,41 +828,32 @@ __device__ SL_FINISH_ATTR void fused_phase0(FusedShared<NT>* shp, const uint8_t*
         sh.S.misc[34] = 0; sh.S.misc[35] = 0;
     }
     __syncthreads();
-    // Will the lists hold what the sweep is going to collect?  The sweep's own exact test on the sample entries says how many candidates
-    // of either kind to expect.  Real tissue with a strong second stain (the ihc fixture) puts a quarter of its pixels on the
-    // concentration list once the box has to cover a tilt as well -- the uncertainty of the weaker stain's concentration under a
-    // heavily stained pixel is real -- and a list that overflows costs the tile a separate concentration sweep on top (measured:
-    // 2.06 ms per 512 such tiles against 1.62 for three sweeps): such a tile keeps the three-sweep schedule.
-    {
-        uint32_t na = 0, nc = 0;
-        float gH[3], gL[3], nf[3], W[2][3];
-        for (int c = 0; c < 3; ++c) { gH[c] = sh.ts.fgH[c]; gL[c] = sh.ts.fgL[c]; nf[c] = sh.ts.fn[c]; W[0][c] = sh.ts.W[0][c]; W[1][c] = sh.ts.W[1][c]; }
-        const float k1 = sh.ts.fk1;
-#pragma unroll
-        for (int j = 0; j < KPT; ++j) {
-            const int b = j * NT + tid;
-            const uint32_t r = w[j] & 255u, g = (w[j] >> 8) & 255u, bl = (w[j] >> 16) & 255u;
-            const float ox = tab.odf(r), oy = tab.odf(g), oz = tab.odf(bl);
-            const bool tissue = is_tissue_f(tab.gam(r), tab.gam(g), tab.gam(bl), ylimf);
-            const float z = fabsf(fmaf(nf[2], oz, fmaf(nf[1], oy, nf[0] * ox)));
-            const float tH = fmaf(gH[2], oz, fmaf(gH[1], oy, gH[0] * ox)), tL = fmaf(gL[2], oz, fmaf(gL[1], oy, gL[0] * ox));
-            const bool pp = fmaf(-k1, z, fminf(tH, tL)) > 0.0f;
-            const float a1 = fmaf(W[0][2], oz, fmaf(W[0][1], oy, fmaf(W[0][0], ox, sh.ts.kt[0]))), a2 = fmaf(W[1][2], oz, fmaf(W[1][1], oy, fmaf(W[1][0], ox, sh.ts.kt[1])));
-            const float sa = fabsf(a1) + fabsf(a2);
-            const bool g1 = fmaf(sh.ts.zeta[0], z, fmaf(sh.ts.eps[0], sa, a1)) >= sh.ts.thr[0], g2 = fmaf(sh.ts.zeta[1], z, fmaf(sh.ts.eps[1], sa, a2)) >= sh.ts.thr[1];
-            if (b < n_sample) { na += (tissue && !pp) ? 1u : 0u; nc += (g1 || g2) ? 1u : 0u; }
+    // Will the lists hold what the sweep is going to collect?  The histograms of the sample's concentrations (still in S.hist) say how many
+    // entries lie above each stain's threshold once it is lowered by what the box adds to a typical candidate (eps (ref_1 + ref_2) + zeta
+    // zref: the exact test's own allowance at the bracket) -- an estimate, which is all a decision about SPEED needs.  Real tissue with a
+    // strong second stain (the ihc fixture) puts a quarter of its pixels on the concentration list once the box has to cover a tilt as
+    // well -- the uncertainty of the weaker stain's concentration under a heavily stained pixel is real -- and a list that overflows
+    // costs the tile a separate concentration sweep on top (measured: 2.06 ms per 512 such tiles against 1.62 for three sweeps): such a
+    // tile keeps the three-sweep schedule.  (A pass of the sweep's exact test over the sample gave the same verdicts for 57 us more.)
+    if (sh.mk.ok) {                                               // block-uniform
+        if (wave < 2) {
+            const float ref = (sh.mk.H[0] < INFINITY ? sh.mk.H[0] : 2.0f * sh.mk.L[0] + 1.0f) + (sh.mk.H[1] < INFINITY ? sh.mk.H[1] : 2.0f * sh.mk.L[1] + 1.0f);
+            const float cut = fmaxf(sh.mk.thr[wave] - sh.mk.eps[wave] * ref - (float)sh.mk.zeta[wave] * sh.res[0], 0.0f);
+            const int bl = min(511, max(0, (int)(512.0f * cut / (cut + 1.0f))));
+            uint32_t cntm = 0;
+            for (int b = lane; b < 512; b += 64) cntm += b >= bl ? sh.S.hist[512 * wave + b] : 0u;
+            for (int o = 32; o > 0; o >>= 1) cntm += (uint32_t)__shfl_xor((int)cntm, o, 64);
+            if (lane == 0) atomicAdd(&sh.S.misc[35], cntm);
         }
-        for (int o = 32; o > 0; o >>= 1) { na += (uint32_t)__shfl_xor((int)na, o, 64); nc += (uint32_t)__shfl_xor((int)nc, o, 64); }
-        if (lane == 0) { atomicAdd(&sh.S.misc[34], na); atomicAdd(&sh.S.misc[35], nc); }
         __syncthreads();
         const double scale = (double)P / (double)n_sample;
-        const bool full = (double)sh.S.misc[34] * scale > 0.75 * (double)cap_ang || (double)sh.S.misc[35] * scale > 0.75 * (double)cap_raw ||
-                          (double)sh.S.misc[35] * scale > 1.5 * (double)cap_list;       // (members: most of the candidates, split over two lists)
+        const bool full = (double)sh.S.misc[35] * scale > 0.75 * (double)cap_raw || (double)sh.S.misc[35] * scale > 1.5 * (double)cap_list;
         if (full && mode < 2) {                                   // block-uniform
             if (tid == 0) sh.ts.why = kTsLists;
             return;
         }
     }
+    (void)cap_ang;
     SL_SUB(5);
     // ---------------- the colour cube of the merged sweep
     {
@@ -1126,13 +1125,13 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
             }
             __syncthreads();
             // ---------------- two-sweep schedule, phase 0: the cluster sample and everything the merged sweep needs (stats_twosweep.hpp)
-            // Every workgroup of a launch starts at the same moment, and phase 0 streams nothing: with both workgroups of a CU in it the chip
-            // idles for its ~170 us (measured: the whole batch two-sweep gains 0-6 %, and a tile that DECLINES in phase 0 loses 10-13 %).  So
-            // on its first tile only the workgroup that was launched second on its CU tries: its phase 0 hides behind its partner's moments
-            // sweep, and it is the one whose tile ends the launch.  Later tiles of a workgroup (batches beyond the resident grid) start while
-            // other workgroups stream.
+            // Every workgroup of a launch starts at the same moment, and phase 0 streams nothing: its length is paid in full on a workgroup's
+            // first tile (measured, interleaved: with the 290 us phase 0 of the first version the whole-batch route gained 0-6 % and a tile
+            // that DECLINED lost 10-13 %; letting only the workgroup launched second on its CU try -- SL_TS_WHO = younger -- gave -3 % / +1-3 %;
+            // with phase 0 at ~130 us every workgroup tries: -6.5 ... -7.4 % on tiles that take the route, +3 % on real tissue that leaves
+            // after the eigen-solve, +7 % on the spatially smooth synthetic tiles that decline at its end).
 #ifndef SL_TS_WHO
-#define SL_TS_WHO younger
+#define SL_TS_WHO true
 #endif
             const bool ts_try = a.two_sweep >= 2 || (a.two_sweep == 1 && NT == kFusedThreads && (SL_TS_WHO || tile != (int)blockIdx.x));   // block-uniform
             if (ts_try) {
@@ -1148,7 +1147,7 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
                 __syncthreads();
             }
             const bool ts_on = sh.ts.ok != 0;                                 // block-uniform
-            SL_PHASE(4);      // (slot 4 is otherwise written on the resweep path only: the end of phase 0)
+            if (ts_try) { SL_PHASE(4); }      // (slot 4 is otherwise written on the resweep path only: the end of phase 0)
             // ---------------- sweep 1: moments (+ sample, or + the candidates of all four order statistics)
             prio_sweep(0);
             if (ts_on) fused_sweep1c<NT, ALIGNED>(&sh, src, rawl, rawa, a.P, a.cap_raw, a.cap_ang, a.ylimf, stream ? 1 : 0);

@@ -67,7 +67,7 @@ struct __attribute__((packed, aligned(1))) U32U { uint32_t v; };
 __device__ __forceinline__ uint32_t cluster_word(const uint8_t* src, int P, uint32_t wl, uint32_t b) {
     const uint32_t i = b / (uint32_t)kClusterPx, j = b % (uint32_t)kClusterPx;
     const uint32_t h = sample_hash(i);
-    const uint32_t line = i * wl + (h >> 8) % wl;
+    const uint32_t line = i * wl + __umulhi(h << 8, wl);           // a draw in [0, wl) off 24 hash bits (no runtime division)
     uint32_t px = (line * 128u + 2u) / 3u + (h >> 28) % 3u + (uint32_t)kClusterStep * j;      // (3 P <= 3 x 2^30 fits 32 bits)
     px = px < (uint32_t)(P - 2) ? px : (uint32_t)(P - 2);                                       // 4 bytes from 3 px stay inside the tile
     return ((SL_GLOBAL const U32U*)(as_global(src) + 3 * (size_t)px))->v & 0xffffffu;

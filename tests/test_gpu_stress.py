@@ -83,7 +83,7 @@ def test_random_mid_size_tiles_against_the_oracle():
     tgt = so.synth_tile(96, 96, 1001, so.M_TRUE_TGT)
     Mt = so.macenko_stain_matrix(tgt)
     mct = np.percentile(so.get_concentrations(tgt, Mt), 99, axis=0)
-    routes = {}
+    routes, attempts = {}, {}
     for case in range(int(os.environ.get("SL_FUZZ_CASES", "14"))):
         h, w = int(rng.choice([512, 640, 768, 1024])), int(rng.choice([512, 600, 768, 1024]))
         kind = rng.choice(["iid", "iid", "quantized", "blobs"])
@@ -113,23 +113,30 @@ def test_random_mid_size_tiles_against_the_oracle():
         want = so.truncate_u8(pre).reshape(I.shape)
         outs = []
         # (round 4) schedule 3 = the 1024-thread fused kernel; prefilter 2 = the colour-cube mask forced wherever it can be built
-        for sched, pf in ((1, 0), (2, 0), (3, 0), (2, 2), (2, 1)):
-            p = engine.make_params(luminosity_threshold=thr, angular_percentile=pct, schedule=sched, prefilter=pf)
+        # (round 5) two_sweep 2 / 3 / 4: the two-read-sweep route forced, forced with a failing plane check, forced under a tilted sample plane
+        for sched, pf, ts in ((1, 0, 0), (2, 0, 1), (3, 0, 0), (2, 2, 1), (2, 1, 0), (2, 0, 2), (2, 0, 3), (2, 0, 4), (3, 0, 2)):
+            p = engine.make_params(luminosity_threshold=thr, angular_percentile=pct, schedule=sched, prefilter=pf, two_sweep=ts)
             rs = torch.full((1,), -1, dtype=torch.int32, device="cuda")
             p.resweeps_out = rs.data_ptr()
+            tsw = torch.full((1,), 99, dtype=torch.int32, device="cuda")
+            p.twosweep_out = tsw.data_ptr()
             out, M, mc, st = engine.macenko_transform(to_dev([I]), torch.as_tensor(Mt, device="cuda"), torch.as_tensor(mct, device="cuda"), params=p)
-            label = f"{kind} {h}x{w} seed {seed} background {frac} thr {thr} pct {pct} schedule {sched} prefilter {pf}"
+            label = f"{kind} {h}x{w} seed {seed} background {frac} thr {thr} pct {pct} schedule {sched} prefilter {pf} two_sweep {ts}"
+            if ts == 2 and sched == 2:
+                attempts[int(tsw[0])] = attempts.get(int(tsw[0]), 0) + 1
             assert int(st[0]) == 0, label
             np.testing.assert_allclose(M.cpu().numpy()[0], Mo, rtol=0, atol=5e-7, err_msg=label)
             np.testing.assert_allclose(mc.cpu().numpy()[0], mco, rtol=5e-7, err_msg=label)
             outs.append(out)
-            if sched == 2 and pf == 0:
+            if sched == 2 and pf == 0 and ts == 1:
                 routes[int(rs[0])] = routes.get(int(rs[0]), 0) + 1
                 if int(rs[0]):
                     print("  separate sweep, reason", int(rs[0]), ":", label)
         assert all(torch.equal(outs[0], o) for o in outs[1:]), label
         u8_parity(outs[0].cpu().numpy()[0], want, label=label, src=I, prequant=pre)
     print("resweep reasons over the cases (0 = merged sweep settled the tile):", routes)
+    print("two-sweep attempts when forced (1 = direct; -1 no estimate, -3 plane, -4 bracket):", attempts)
+    assert attempts.get(1, 0) >= 5        # the forced route is taken by most tiles of these sizes
     assert routes.get(0, 0) >= 7          # the merged route is the normal one at these sizes
 
 

@@ -2,7 +2,7 @@
 # Collects every measurement the docs cite into gpurun_out/ (run on the GPU box from the repo root):
 #   make -C tools && /usr/local/graft/bin/gpurun --timeout 1800 -- 'bash tools/collect_profiles.sh r04'
 # then copy gpurun_out/r04_* to profiles/ (tracked); bench.py reads <tag>_pmc_traffic.json from there.
-tag=${1:-r04}
+tag=${1:-r05}
 cd "$GRAFT_REPO_ROOT" || exit 1
 out=$PWD/gpurun_out
 mkdir -p "$out"
@@ -45,6 +45,14 @@ for pass in "f:FETCH_SIZE" "w:WRITE_SIZE" "s1:SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_W
   rm -rf /tmp/pmc_$t; timeout 400 rocprofv3 --pmc $c -d /tmp/pmc_$t -o p -- python tools/run_fused_once.py 512 > /dev/null 2>&1
   python tools/pmc_summary.py "$(ls /tmp/pmc_$t/*/*.db /tmp/pmc_$t/*.db 2>/dev/null | head -1)" > "$out/${tag}_pmc_$t.txt" 2>&1
 done
+# round 5: the same two traffic counters with the two-sweep route off (three sweeps for every tile) and forced (every tile tries)
+for ts in 1 2; do
+  for pass in "f:FETCH_SIZE" "w:WRITE_SIZE"; do
+    t=${pass%%:*}; c=${pass#*:}
+    rm -rf /tmp/pmc_${t}_ts$ts; timeout 400 rocprofv3 --pmc $c -d /tmp/pmc_${t}_ts$ts -o p -- python tools/run_fused_once.py 512 0 $ts > /dev/null 2>&1
+    python tools/pmc_summary.py "$(ls /tmp/pmc_${t}_ts$ts/*/*.db /tmp/pmc_${t}_ts$ts/*.db 2>/dev/null | head -1)" > "$out/${tag}_pmc_${t}_ts$ts.txt" 2>&1
+  done
+done
 # the same two traffic counters on the one-launch-per-phase schedule at 64 tiles (192 MB: fits the Infinity Cache) and 512
 for n in 64 512; do
   rm -rf /tmp/pm_$n; timeout 300 rocprofv3 --pmc FETCH_SIZE -d /tmp/pm_$n -o p -- python tools/run_fused_once.py $n 1 > /dev/null 2>&1
@@ -56,6 +64,8 @@ python tools/slide_scale.py 512,2048,12500 2>/dev/null | grep -v amdgpu > "$out/
 timeout 200 python tools/power_classes.py 2>/dev/null | grep -v amdgpu > "$out/${tag}_power_classes.txt"
 python tools/structured_rate.py 2>/dev/null | grep -v amdgpu > "$out/${tag}_structured_rate.txt"
 python tools/cube_ab.py iid white_bg quantized ihc grey_bg blobs 2>/dev/null | grep -v amdgpu > "$out/${tag}_cube_prefilter_ab.txt"
+python tools/ts_check.py 512 1024 iid,white_bg,quantized,blobs,ihc,palette12 2>/dev/null | grep -v amdgpu > "$out/${tag}_two_sweep_ab.txt"
+[ -f "$dev" ] && STAINLIB_HIP_LIB=$dev python tools/ts_phases.py 512 1024 iid 2>/dev/null | grep -v amdgpu > "$out/${tag}_two_sweep_phases.txt"
 rm -rf /tmp/kl; timeout 300 rocprofv3 --kernel-trace -d /tmp/kl -o p -- python tools/run_lab.py > /dev/null 2>&1
 python tools/rocpd_stats.py "$(ls /tmp/kl/*/*.db /tmp/kl/*.db 2>/dev/null | head -1)" 2>&1 | grep -v "at::native\|rocclr\|Cijk" > "$out/${tag}_kernel_stats_lab.md"
 [ -x tools/bin/ubench_ops ] && timeout 120 tools/bin/ubench_ops > "$out/${tag}_ubench_ops.txt" 2>&1

@@ -48,6 +48,19 @@ for name, needle, alg_bpp, sched_bpp in (("k_fused<macenko,transform>", "k_fused
                      "traffic_over_schedule_bytes": round(hbm / (sched_bpp * tiles * px), 4),
                      "read_over_tile_reads": round(2.0 * fr * 1024 / ((sched_bpp - 3) * tiles * px), 4),
                      "write_over_output": round(wr * 1024 / (3 * tiles * px), 4)}
+# round 5: the fused kernel with the two-sweep route off / forced (run_fused_once.py 512 0 1 / 512 0 2)
+two_sweep = {}
+for ts, label in ((1, "three_sweep_every_tile (two_sweep=1)"), (2, "every_tile_tries (two_sweep=2)")):
+    try:
+        f2, w2 = dump(f"{d}/{tag}_pmc_f_ts{ts}.txt"), dump(f"{d}/{tag}_pmc_w_ts{ts}.txt")
+    except OSError:
+        continue
+    fr, wr = pick(f2, "k_fused<0, true, true", "FETCH_SIZE"), pick(w2, "k_fused<0, true, true", "WRITE_SIZE")
+    if fr is None or wr is None:
+        continue
+    hbm = int(round((2.0 * fr + wr) * 1024))
+    two_sweep[label] = {"FETCH_SIZE_KiB_raw": fr, "WRITE_SIZE_KiB": wr, "hbm_bytes_per_launch": hbm, "bytes_per_pixel": round(hbm / (tiles * px), 2),
+                        "read_bytes_per_pixel": round(2.0 * fr * 1024 / (tiles * px), 2), "write_over_output": round(wr * 1024 / (3 * tiles * px), 4)}
 phase = {}
 for n in (64, 512):
     try:
@@ -65,6 +78,8 @@ doc = {
            "calibration is k_apply in this same file, whose read volume is known exactly (512 x 3 145 728 B = 1 572 864 KiB). "
            "WRITE_SIZE needs no correction.",
     "tiles_per_launch": tiles, "pixels_per_tile": px, "kernels": kernels,
+    "fused_kernel_by_two_sweep_mode": dict(two_sweep, note="round 5 (stats_twosweep.hpp): `kernels` above is the DEFAULT (on its first tile only the workgroup launched "
+                                           "second on its CU tries the two-sweep route: half of a 512-tile batch); here the route off for every tile and forced for every tile"),
     "per_phase_schedule_fetch_KiB_raw": dict(phase, tile_KiB=3072, note="one launch per phase, FETCH_SIZE per kernel launch at 64 tiles (192 MB of "
                                              "tiles: fits the 256 MB Infinity Cache) and at 512 tiles (1.6 GB): the same raw KiB per tile in both -- "
                                              "the counter does not see Infinity Cache hits; whether residency buys TIME: *_phase_classes.txt, DESIGN.md 4.1"),

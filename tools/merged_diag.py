@@ -18,7 +18,7 @@ size = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 rgb = synth_tiles(n, size, size, seed=3)
 tgt = synth_tiles(1, size, size, seed=1, M_true=[[0.55, 0.75, 0.35], [0.10, 0.95, 0.20]])
 Mt, mct, st = engine.macenko_fit(tgt)
-p = engine.make_params(schedule=2, prefilter=int(os.environ.get("SL_PREFILTER", "0")))      # SL_PREFILTER=1: the per-pixel selection sweep
+p = engine.make_params(schedule=2, prefilter=int(os.environ.get("SL_PREFILTER", "0")), two_sweep=1)      # SL_PREFILTER=1: the per-pixel selection sweep; the THREE-sweep route for every tile (tools/ts_phases.py times the two-sweep one)
 fb = engine.attach_fallbacks(p, n)
 rs = torch.full((n,), -1, dtype=torch.int32, device="cuda")
 p.resweeps_out = rs.data_ptr()
