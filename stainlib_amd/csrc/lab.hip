@@ -34,6 +34,22 @@ struct LabTabs {
     }
 };
 
+// the static tables a sweep needs, without the ones its per-tile tables (LabTileTabs) already contain
+struct LabCbrt {              // RGB -> Lab8 behind a per-tile gamma table
+    uint16_t cbrt[3072];
+    __device__ __forceinline__ void fill() {
+        for (int i = threadIdx.x; i < 3072 / 2; i += blockDim.x) ((uint32_t*)cbrt)[i] = ((const uint32_t*)d_lab_cbrt)[i];
+    }
+};
+struct LabCbrtInv {           // ... and back through per-tile yf / a / b tables
+    uint16_t cbrt[3072];
+    uint8_t invg[4096];
+    __device__ __forceinline__ void fill() {
+        for (int i = threadIdx.x; i < 3072 / 2; i += blockDim.x) ((uint32_t*)cbrt)[i] = ((const uint32_t*)d_lab_cbrt)[i];
+        for (int i = threadIdx.x; i < 4096 / 4; i += blockDim.x) ((uint32_t*)invg)[i] = ((const uint32_t*)d_inv_gamma)[i];
+    }
+};
+
 // Compiler hazard (hipcc 7.2, gfx950): clamp(x >> n, 0, 255) of two values is selected as ONE v_ashr_pk_u8_i32, whose result the
 // compiler then ORs into a word as if bits 31:16 were zero -- on the hardware they are not (found by the exhaustive Lab test:
 // bytes 2 of every packed word came out with stray bits).  The empty asm keeps the shift and the clamp apart.
@@ -45,13 +61,16 @@ __device__ __forceinline__ int sat8(int v) {
 // OpenCV RGB2Lab_b::operator(): coefficients cvRound(4096 * sRGB2XYZ_D65[i][j] / whitePt[i]), lab_shift 12, lab_shift2 15.
 // R, G, Bc are the gamma-table values of the three bytes (the sweeps read them from a per-tile table that already
 // contains the brightness table: gamma[lut[v]]).
-__device__ __forceinline__ void gamma_to_lab8(const LabTabs& t, int R, int G, int Bc, int& L, int& A, int& B) {
-    const int fX = t.cbrt[(R * 1777 + G * 1541 + Bc * 778 + 2048) >> 12];
-    const int fY = t.cbrt[(R * 871 + G * 2929 + Bc * 296 + 2048) >> 12];
-    const int fZ = t.cbrt[(R * 73 + G * 448 + Bc * 3575 + 2048) >> 12];
-    L = sat8((296 * fY - 1336934 + 16384) >> 15);
-    A = sat8((500 * (fX - fY) + 128 * 32768 + 16384) >> 15);
-    B = sat8((200 * (fY - fZ) + 128 * 32768 + 16384) >> 15);
+template <class T>
+__device__ __forceinline__ void gamma_to_lab8(const T& t, int R, int G, int Bc, int& L, int& A, int& B) {
+    // (24-bit multiplies: the gamma values stay below 2^11, the cube-root values below 2^16, every product below 2^31 -- the compiler
+    //  cannot see the ranges behind the table reads and would issue twelve full-width multiplies at a quarter of the vector rate)
+    const int fX = t.cbrt[(__mul24(R, 1777) + __mul24(G, 1541) + __mul24(Bc, 778) + 2048) >> 12];
+    const int fY = t.cbrt[(__mul24(R, 871) + __mul24(G, 2929) + __mul24(Bc, 296) + 2048) >> 12];
+    const int fZ = t.cbrt[(__mul24(R, 73) + __mul24(G, 448) + __mul24(Bc, 3575) + 2048) >> 12];
+    L = sat8((__mul24(296, fY) - 1336934 + 16384) >> 15);
+    A = sat8((__mul24(500, fX - fY) + 128 * 32768 + 16384) >> 15);
+    B = sat8((__mul24(200, fY - fZ) + 128 * 32768 + 16384) >> 15);
 }
 __device__ __forceinline__ void rgb_to_lab8(const LabTabs& t, uint32_t r, uint32_t g, uint32_t b, int& L, int& A, int& B) {
     gamma_to_lab8(t, t.gamma[r], t.gamma[g], t.gamma[b], L, A, B);
@@ -76,7 +95,8 @@ __device__ __forceinline__ int ab_to_xz(int i) {
 // lab_adiv / lab_bdiv: the a and b bytes on the table's scale (128*BASE/500 = 4194, 128*BASE/200 = 10485).
 __device__ __forceinline__ int lab_adiv(int a) { return ((5 * a * 53687 + 128) >> 13) - 4194; }
 __device__ __forceinline__ int lab_bdiv(int b) { return ((b * 41943 + 16) >> 9) - 10485 + 1; }
-__device__ __forceinline__ void yf_to_rgb(const LabTabs& t, int y, int ify, int adiv, int bdiv, uint32_t& r, uint32_t& g, uint32_t& bl) {
+template <class T>
+__device__ __forceinline__ void yf_to_rgb(const T& t, int y, int ify, int adiv, int bdiv, uint32_t& r, uint32_t& g, uint32_t& bl) {
     const int x = ab_to_xz(ify + adiv), z = ab_to_xz(ify - bdiv);
     // x, z < 2^17 (ab_to_xz of an argument below 2^15 + 2^14), y < 2^15: 24-bit multiplies (the compiler cannot see the ranges and
     // would issue full-width ones at a quarter of the rate); every sum stays below 2^31 as in OpenCV's int arithmetic
@@ -176,23 +196,44 @@ __device__ __forceinline__ int l8_limit(double thr) {
     return lim;
 }
 
+// Per-tile composed tables (workspace, behind the LabScratch array): written ONCE per tile by k_lab_pre / k_lab_tables and loaded by every
+// workgroup of the sweeps that follow.  (Round 5: until then every workgroup of k_lab_hist / k_lab_map rebuilt them -- a serial
+// percentile over 256 global counters, three mean/std loops in binary64, five table passes -- before it touched a pixel: ~20 us of a
+// workgroup's ~450, which also kept the sweeps from being cut into workgroups small enough to fill the last round.)
+struct LabTileTabs {
+    uint16_t g[256];          // byte -> gamma value, through the brightness table where the op standardises
+    uint32_t yf[256];         // L8 -> (y, f(y)) of the MAPPED L byte, packed
+    int ad[256], bd[256];     // a8 / b8 -> the mapped byte on abToXZ's scale (MODE 0)
+    uint8_t lut[256];         // the brightness table (identity when the op does not standardise)
+    double p;                 // the percentile the op reports (p90 of the bytes / the L percentile of MODE 1)
+    double pad_;
+};
+
+// after sweep A: the brightness table and the gamma values behind it (what sweep B needs)
+static __global__ __launch_bounds__(256) void k_lab_pre(const LabScratch* __restrict__ sc, int standardize, LabTileTabs* __restrict__ tt) {
+    __shared__ uint8_t s_lut[256];
+    __shared__ double s_p;
+    const int tile = blockIdx.x, tid = threadIdx.x;
+    fill_brightness_lut(s_lut, sc[tile], standardize, &s_p);
+    tt[tile].lut[tid] = s_lut[tid];
+    tt[tile].g[tid] = (uint16_t)d_gamma[s_lut[tid]];
+    if (tid == 0) tt[tile].p = s_p;
+}
+
 // ---- sweep B: histograms of the Lab bytes of the (standardised) tile ------------------------------------------------
 template <bool ALIGNED>
-static __global__ __launch_bounds__(kLabWG) void k_lab_hist(const uint8_t* __restrict__ rgb, int P, int parts, int standardize,
-                                                            int want_ab, double thr, LabScratch* __restrict__ sc) {
-    __shared__ LabTabs s_t;
+static __global__ __launch_bounds__(kLabWG) void k_lab_hist(const uint8_t* __restrict__ rgb, int P, int parts, int want_ab, double thr,
+                                                            LabScratch* __restrict__ sc, const LabTileTabs* __restrict__ tt) {
+    __shared__ LabCbrt s_t;
     __shared__ uint32_t s_h[kLabWG / 64][256];
-    __shared__ uint8_t s_lut[256];
     __shared__ uint16_t s_g[256];
-    __shared__ double s_p;
     __shared__ unsigned long long s_tissue, s_ab[4];
     const int tile = blockIdx.x / parts, part = blockIdx.x % parts, wave = threadIdx.x >> 6;
     s_t.fill();
     for (int i = threadIdx.x; i < (kLabWG / 64) * 256; i += kLabWG) (&s_h[0][0])[i] = 0;
     if (threadIdx.x == 0) s_tissue = 0;
     if (threadIdx.x < 4) s_ab[threadIdx.x] = 0;
-    fill_brightness_lut(s_lut, sc[tile], standardize, &s_p);
-    for (int v = threadIdx.x; v < 256; v += kLabWG) s_g[v] = s_t.gamma[s_lut[v]];     // brightness table and gamma table in one lookup
+    for (int v = threadIdx.x; v < 256; v += kLabWG) s_g[v] = tt[tile].g[v];     // brightness table and gamma table in one lookup (k_lab_pre)
     __syncthreads();
     const int lim = l8_limit(thr);
     const size_t nbytes = (size_t)P * 3;
@@ -271,26 +312,24 @@ static __global__ __launch_bounds__(64) void k_lab_stats(const LabScratch* __res
 struct LabMapArgs {
     const uint8_t* rgb; uint8_t* out; int P, parts;
     const LabScratch* sc;
+    LabTileTabs* tt;                                            // [n] per-tile tables (k_lab_pre, k_lab_tables)
     const double* target_means; const double* target_stds;      // MODE 0 (device, 3 each)
     int mask_background; double thr;                            // MODE 0
     double percentile;                                          // MODE 1
     double* p_out;                                              // MODE 1 / 2 (may be NULL)
 };
 
-template <int MODE, bool ALIGNED>
-static __global__ __launch_bounds__(kLabWG) void k_lab_map(LabMapArgs a) {
-    __shared__ LabTabs s_t;
-    __shared__ uint8_t s_lut[256];            // brightness table (MODE 0, 2)
+// The per-tile tables of the map sweep, one workgroup per tile (what every workgroup of the sweep used to rebuild): normalizer.py:81-83 /
+// stain_utils.py:65 evaluated in binary64 on the 256 possible bytes, composed with the conversion tables the pixel path would
+// look up next.  MODE 0: needs k_lab_pre's brightness table; MODE 1: identity brightness.
+template <int MODE>
+static __global__ __launch_bounds__(256) void k_lab_tables(LabMapArgs a) {
     __shared__ uint8_t s_ch[3][256];          // per-channel Lab byte tables (MODE 0: all three; MODE 1: L only)
     __shared__ double s_p;
     __shared__ double s_ms[6];
-    const int tile = blockIdx.x / a.parts, part = blockIdx.x % a.parts, tid = threadIdx.x;
+    const int tile = blockIdx.x, tid = threadIdx.x;
     const LabScratch& sc = a.sc[tile];
-    if (MODE != 2) s_t.fill();
-    if (MODE == 0 || MODE == 2) {
-        fill_brightness_lut(s_lut, sc, 1, &s_p);
-        if (MODE == 2 && part == 0 && tid == 0 && a.p_out) a.p_out[tile] = s_p;
-    }
+    LabTileTabs& tt = a.tt[tile];
     if (MODE == 0) {
         if (tid < 3) {
             double m, s;
@@ -306,30 +345,44 @@ static __global__ __launch_bounds__(kLabWG) void k_lab_map(LabMapArgs a) {
             const double nrm = ((x - s_ms[ch]) * ratio) + a.target_means[ch];
             s_ch[ch][tid] = (uint8_t)clip_trunc_u8(ch == 0 ? nrm * 2.55 : nrm + 128.0);
         }
-    } else if (MODE == 1) {
+    } else {
         if (tid == 0) s_p = percentile_of_hist(sc.lab_l, a.percentile);
         __syncthreads();
         s_ch[0][tid] = (uint8_t)clip_trunc_u8(255.0 * (double)tid / s_p);          // stain_utils.py:65: 255 * L_float / p
-        if (part == 0 && tid == 0 && a.p_out) a.p_out[tile] = s_p;
+        if (tid == 0) tt.p = s_p;
+        tt.g[tid] = (uint16_t)d_gamma[tid];
+        tt.lut[tid] = (uint8_t)tid;
     }
     __syncthreads();
-    // Per-tile composed tables: one lookup where the pixel path had two or three.  s_g: byte -> gamma value (through the
-    // brightness table in MODE 0); s_yf: L8 -> (y, f(y)) of the MAPPED L byte, packed; s_ad / s_bd: a8 / b8 -> the mapped
-    // byte on abToXZ's scale.
+    const int L2 = s_ch[0][tid], A2 = MODE == 0 ? s_ch[1][tid] : tid, B2 = MODE == 0 ? s_ch[2][tid] : tid;
+    tt.yf[tid] = (uint32_t)d_lab_yf[2 * L2] | ((uint32_t)d_lab_yf[2 * L2 + 1] << 16);
+    tt.ad[tid] = lab_adiv(A2);
+    tt.bd[tid] = lab_bdiv(B2);
+}
+
+// The sweep: per-tile tables from k_lab_pre / k_lab_tables; two chunks per lane in flight.
+template <int MODE, bool ALIGNED>
+static __global__ __launch_bounds__(kLabWG) void k_lab_map(LabMapArgs a) {
+    __shared__ LabCbrtInv s_t;
+    __shared__ uint8_t s_lut[256];            // brightness table (MODE 2)
     __shared__ uint16_t s_g[256];
     __shared__ uint32_t s_yf[256];
     __shared__ int s_ad[256], s_bd[256];
+    const int tile = blockIdx.x / a.parts, part = blockIdx.x % a.parts, tid = threadIdx.x;
+    const LabTileTabs& tt = a.tt[tile];
     if (MODE != 2) {
-        const int L2 = s_ch[0][tid], A2 = MODE == 0 ? s_ch[1][tid] : tid, B2 = MODE == 0 ? s_ch[2][tid] : tid;
-        s_g[tid] = MODE == 0 ? s_t.gamma[s_lut[tid]] : s_t.gamma[tid];
-        s_yf[tid] = (uint32_t)s_t.yf[2 * L2] | ((uint32_t)s_t.yf[2 * L2 + 1] << 16);
-        s_ad[tid] = lab_adiv(A2);
-        s_bd[tid] = lab_bdiv(B2);
+        s_t.fill();
+        s_g[tid] = tt.g[tid];
+        s_yf[tid] = tt.yf[tid];
+        if (MODE == 0) { s_ad[tid] = tt.ad[tid]; s_bd[tid] = tt.bd[tid]; }
+    } else {
+        s_lut[tid] = tt.lut[tid];
     }
+    if (MODE != 0 && part == 0 && tid == 0 && a.p_out) a.p_out[tile] = tt.p;
     __syncthreads();
     const int lim = MODE == 0 ? l8_limit(a.thr) : 256;
     // background (normalizer.py:86-90): 254 + 0 on the L/2.55 scale -> clips to 255; a = b = 0 + 128
-    const uint32_t yf_bg = (uint32_t)s_t.yf[2 * 255] | ((uint32_t)s_t.yf[2 * 255 + 1] << 16);
+    const uint32_t yf_bg = (uint32_t)d_lab_yf[2 * 255] | ((uint32_t)d_lab_yf[2 * 255 + 1] << 16);
     const int ad_bg = lab_adiv(128), bd_bg = lab_bdiv(128);
     const bool mask_bg = MODE == 0 && a.mask_background;
     const size_t nbytes = (size_t)a.P * 3;
@@ -338,8 +391,8 @@ static __global__ __launch_bounds__(kLabWG) void k_lab_map(LabMapArgs a) {
     const int nch = (a.P + 3) >> 2;
     const int span = (nch + a.parts - 1) / a.parts;
     const int c0 = part * span, c1 = min(nch, c0 + span);
-    for (int c = c0 + tid; c < c1; c += kLabWG) {
-        const Chunk in = load_chunk<ALIGNED>(src, nbytes, c);
+    if (c0 >= c1) return;
+    auto one = [&](const Chunk& in, int c) {
         uint32_t ob[12];
 #pragma unroll
         for (int px = 0; px < 4; ++px) {
@@ -359,6 +412,15 @@ static __global__ __launch_bounds__(kLabWG) void k_lab_map(LabMapArgs a) {
             yf_to_rgb(s_t, (int)(yf & 0xffffu), (int)(yf >> 16), ad, bd, ob[3 * px], ob[3 * px + 1], ob[3 * px + 2]);
         }
         store_chunk<ALIGNED>(dst, nbytes, c, pack12(ob));
+    };
+    // (the next trip's two chunks are requested before this trip's arithmetic; clamped loads, never predicated)
+    Chunk n0 = load_chunk_clamped<ALIGNED, true>(src, nbytes, c0 + tid, c1), n1 = load_chunk_clamped<ALIGNED, true>(src, nbytes, c0 + tid + kLabWG, c1);
+    for (int c = c0 + tid; c < c1; c += 2 * kLabWG) {
+        const Chunk i0 = n0, i1 = n1;
+        n0 = load_chunk_clamped<ALIGNED, true>(src, nbytes, c + 2 * kLabWG, c1);
+        n1 = load_chunk_clamped<ALIGNED, true>(src, nbytes, c + 3 * kLabWG, c1);
+        one(i0, c);
+        if (c + kLabWG < c1) one(i1, c + kLabWG);
     }
 }
 
@@ -440,16 +502,21 @@ using namespace sl;
 
 namespace {
 
-// Workgroups per tile of the Lab sweeps: every workgroup merges a 256-bin histogram into the tile's with global atomics and
-// rebuilds the per-tile tables (a few hundred serial binary64 operations) before it touches a pixel, so a tile is split only
-// as far as it takes to put ~8 workgroups on every CU (1 250 tiles of 512^2: one workgroup per tile, 2.4 -> 1.1 ms).
+// Workgroups per tile of the Lab sweeps: every workgroup merges a 256-bin histogram into the tile's with global atomics (sweeps A, B) or
+// fills 14 KB of LDS tables (sweep C) before it touches a pixel, so a tile is split only as far as it takes to put ~8 workgroups on
+// every CU.  Measured on 1 250 tiles of 512^2 (round 5, per-tile tables precomputed): 1 250 / 2 500 / 3 750 / 8 750 / 17 500 workgroups:
+// k_lab_hist 529 / 526 / 525 / 629 / 882 us, k_lab_map<0> 909 / 903 / 927 / 1 016 / - us.
 int lab_parts(int n, long P) {
     const long want = (2048 + n - 1) / n;
-    const int full = parts_for(P);
-    return (int)(want < 1 ? 1 : (want < full ? want : full));
+    const long nch = (P + 3) >> 2;
+    long most = nch / (16L * kLabWG);
+    if (most < 1) most = 1;
+    return (int)(want < 1 ? 1 : (want < most ? want : most));
 }
 
-size_t lab_ws_bytes(int n) { return (sizeof(LabScratch) * (size_t)n + 255) & ~(size_t)255; }
+size_t lab_scratch_bytes(int n) { return (sizeof(LabScratch) * (size_t)n + 255) & ~(size_t)255; }
+size_t lab_ws_bytes(int n) { return lab_scratch_bytes(n) + ((sizeof(LabTileTabs) * (size_t)n + 255) & ~(size_t)255); }
+LabTileTabs* lab_tabs_of(void* ws, int n) { return (LabTileTabs*)((char*)ws + lab_scratch_bytes(n)); }
 
 int lab_check(const void* rgb, const void* out, int n, int h, int w, const void* ws, size_t ws_bytes) {
     if (!rgb || !out || n <= 0 || h <= 0 || w <= 0) return SL_ERR_BADARG;
@@ -458,9 +525,10 @@ int lab_check(const void* rgb, const void* out, int n, int h, int w, const void*
     return SL_OK;
 }
 
-// the two statistics sweeps shared by the entry points below
+// the two statistics sweeps shared by the entry points below (and k_lab_pre between them: the tile's brightness table)
 int lab_statistics(const uint8_t* rgb, int n, long P, int standardize, int want_ab, double thr, LabScratch* sc, hipStream_t s) {
     SL_HIP_TRY(hipMemsetAsync(sc, 0, sizeof(LabScratch) * (size_t)n, s));
+    LabTileTabs* tt = lab_tabs_of(sc, n);
     const int parts = lab_parts(n, P);
     const dim3 grid((unsigned)((long)n * parts)), block(kLabWG);
     const bool al = aligned4(rgb, P);
@@ -468,15 +536,17 @@ int lab_statistics(const uint8_t* rgb, int n, long P, int standardize, int want_
         if (al) hipLaunchKernelGGL((k_byte_hist<true>), grid, block, 0, s, rgb, (int)P, parts, sc);
         else    hipLaunchKernelGGL((k_byte_hist<false>), grid, block, 0, s, rgb, (int)P, parts, sc);
     }
+    hipLaunchKernelGGL(k_lab_pre, dim3((unsigned)n), dim3(256), 0, s, sc, standardize, tt);
     if (want_ab >= 0) {
-        if (al) hipLaunchKernelGGL((k_lab_hist<true>), grid, block, 0, s, rgb, (int)P, parts, standardize, want_ab, thr, sc);
-        else    hipLaunchKernelGGL((k_lab_hist<false>), grid, block, 0, s, rgb, (int)P, parts, standardize, want_ab, thr, sc);
+        if (al) hipLaunchKernelGGL((k_lab_hist<true>), grid, block, 0, s, rgb, (int)P, parts, want_ab, thr, sc, tt);
+        else    hipLaunchKernelGGL((k_lab_hist<false>), grid, block, 0, s, rgb, (int)P, parts, want_ab, thr, sc, tt);
     }
     return launch_status();
 }
 
 template <int MODE>
 int lab_map(const LabMapArgs& a, int n, hipStream_t s) {
+    if (MODE != 2) hipLaunchKernelGGL((k_lab_tables<MODE>), dim3((unsigned)n), dim3(256), 0, s, a);
     const dim3 grid((unsigned)((long)n * a.parts)), block(kLabWG);
     if (aligned4(a.rgb, a.P) && aligned4(a.out, a.P)) hipLaunchKernelGGL((k_lab_map<MODE, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((k_lab_map<MODE, false>), grid, block, 0, s, a);
@@ -544,7 +614,7 @@ extern "C" int sl_standardize_brightness(const uint8_t* rgb, uint8_t* out, int n
     rc = lab_statistics(rgb, n, P, 1, -1, 0.0, sc, s);
     if (rc) return rc;
     LabMapArgs a{};
-    a.rgb = rgb; a.out = out; a.P = (int)P; a.parts = lab_parts(n, P); a.sc = sc; a.p_out = p_out;
+    a.rgb = rgb; a.out = out; a.P = (int)P; a.parts = lab_parts(n, P); a.sc = sc; a.tt = lab_tabs_of(sc, n); a.p_out = p_out;
     return lab_map<2>(a, n, s);
 }
 
@@ -573,7 +643,7 @@ extern "C" int sl_reinhard_transform(const uint8_t* rgb, uint8_t* out, int n, in
     if (rc) return rc;
     if (stats_out) hipLaunchKernelGGL(k_lab_stats, dim3((unsigned)n), dim3(64), 0, s, sc, 1, stats_out);
     LabMapArgs a{};
-    a.rgb = rgb; a.out = out; a.P = (int)P; a.parts = lab_parts(n, P); a.sc = sc;
+    a.rgb = rgb; a.out = out; a.P = (int)P; a.parts = lab_parts(n, P); a.sc = sc; a.tt = lab_tabs_of(sc, n);
     a.target_means = target_means; a.target_stds = target_stds;
     a.mask_background = mask_background ? 1 : 0; a.thr = luminosity_threshold;
     return lab_map<0>(a, n, s);
@@ -589,6 +659,6 @@ extern "C" int sl_luminosity_standardize(const uint8_t* rgb, uint8_t* out, int n
     rc = lab_statistics(rgb, n, P, 0, 0, 0.8, sc, s);
     if (rc) return rc;
     LabMapArgs a{};
-    a.rgb = rgb; a.out = out; a.P = (int)P; a.parts = lab_parts(n, P); a.sc = sc; a.percentile = percentile; a.p_out = p_out;
+    a.rgb = rgb; a.out = out; a.P = (int)P; a.parts = lab_parts(n, P); a.sc = sc; a.tt = lab_tabs_of(sc, n); a.percentile = percentile; a.p_out = p_out;
     return lab_map<1>(a, n, s);
 }

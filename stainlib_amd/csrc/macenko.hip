@@ -55,7 +55,7 @@ struct Layout {
     bool wide;                              // fused with 1024-thread workgroups, one per CU (Macenko, batches of up to #CU tiles)
     int grid;                               // fused: workgroups launched
     int max_grid;                           // resident sweep workgroups of the device
-    size_t off_M, off_maxC, off_status, off_partials, off_sample, off_cand, off_ang, off_list, off_state, off_dstate, off_mstate, off_diag, total;
+    size_t off_M, off_maxC, off_status, off_partials, off_sample, off_cand, off_ang, off_list, off_state, off_dstate, off_mstate, off_diag, off_next, total;
 };
 
 size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -126,6 +126,7 @@ Layout make_layout(int n, long P, int method = kMethodMacenko, int schedule = 0,
     L.off_state = o;    o = align_up(o + sizeof(TileState) * (size_t)L.G);
     L.off_dstate = o;   o = align_up(o + sizeof(DictState) * (size_t)L.G);
     L.off_mstate = o;   o = align_up(o + sizeof(TileMerged) * (size_t)L.G);
+    L.off_next = o;     o = align_up(o + sizeof(unsigned long long));      // the fused kernel's tile counter
     L.total = o;
     return L;
 }
@@ -281,6 +282,8 @@ int run_fused(int method, const uint8_t* rgb, uint8_t* out, int n, long P, const
     a.cl_scale_log2 = 1;
     while (((long)a.cl_lines * kClusterPx << a.cl_scale_log2) < P && a.cl_scale_log2 < 30) ++a.cl_scale_log2;
     a.ts_out = p.twosweep_out;
+    a.next_tile = (unsigned long long*)(ws + L.off_next);
+    if (n > L.grid && hipMemsetAsync(a.next_tile, 0, sizeof(unsigned long long), s) != hipSuccess) return launch_status();
     const bool al = aligned4(rgb, P) && (!out || aligned4(out, P));
     ProfScope ps(p.profile, out ? SL_PROF_FUSED_TRANSFORM : SL_PROF_FUSED_FIT, n, s);
     // (the twelve instantiations of k_fused live in three translation units of their own -- fused_macenko.hip, fused_macenko_wide.hip,

@@ -52,6 +52,8 @@ struct FusedArgs {
     int cl_lines;            // lines of the cluster sample (cluster_lines(P)); its entries: cl_lines * kClusterPx <= the sample buffer
     int cl_scale_log2;       // log2 of the pixels one entry of the cluster sample stands for (rounded up, >= 1)
     int32_t* ts_out;         // [n_tiles] kTs* (diagnostics, may be NULL)
+    unsigned long long* next_tile;    // one word, zero before a launch of more tiles than workgroups: hands out the tiles beyond the first round
+                                      // (NULL: a workgroup's tiles are blockIdx.x + k gridDim.x)
 };
 
 template <int NT>
@@ -81,6 +83,7 @@ struct FusedShared {
     int use_cube;            // finish 1 built the colour-cube mask (in S.hist) and the sample says it pays: sweep 2 = select_sweep_cube
     MergedConc mk;
     TwoSweep ts;             // two-sweep schedule: the estimate phase 0 left for sweep 1 (ts.ok) and what the finish must verify
+    int next_tile;           // the workgroup's next tile (k_fused)
 };
 
 // Every kernel that owns a FusedShared block declares it as its ONLY __shared__ object, so the block starts at LDS address 0
@@ -1042,6 +1045,95 @@ static __global__ __launch_bounds__(kMFinishThreads) void k_finish2m(StatsArgs a
     if (tid == 0 && fallbacks_out) fallbacks_out[tile0 + tile] = bad ? 0 : st.fallbacks;
 }
 
+// The separate concentration pass of a tile whose merged sweep did not settle maxC (Macenko: rare -- SL_RESWEEP_*; Vahadane: always):
+// concentration brackets under the tile's M from the sample, sweep 3 (concentration select), finish 3 (the exact 99th percentiles ->
+// sh.maxC).  Out of line: inlined, its fully unrolled sample loops left three dozen per-thread addresses live across the whole tile
+// loop of k_fused -- 79 scratch stores per lane in the kernel's prologue.  stride_log2 < 0: the cluster sample of the two-sweep
+// schedule.  Returns the fallbacks of the order statistics.
+template <int NT, bool ALIGNED>
+__device__ __noinline__ int fused_conc_resweep(FusedShared<NT>* shp, const uint8_t* src_, uint32_t* samp_, uint32_t* rawl_, float* cand0_, float* cand1_, int P_,
+                                               int cap_raw_, int cap_list_, float ylimf_, double lam_, int stream_, int n_sample_, int stride_log2_,
+                                               long long* clk_, long long* subclk_) {
+    FusedShared<NT>& sh = *shp;
+    const uint8_t* src = uni_ptr(src_);
+    uint32_t* samp = uni_ptr(samp_);
+    uint32_t* rawl = uni_ptr(rawl_);
+    float* cand0 = uni_ptr(cand0_);
+    float* cand1 = uni_ptr(cand1_);
+    const int P = __builtin_amdgcn_readfirstlane(P_), cap_raw = __builtin_amdgcn_readfirstlane(cap_raw_), cap_list = __builtin_amdgcn_readfirstlane(cap_list_);
+    const int stream = __builtin_amdgcn_readfirstlane(stream_), n_sample = __builtin_amdgcn_readfirstlane(n_sample_);
+    const int stride_log2 = __builtin_amdgcn_readfirstlane(stride_log2_);
+    const float ylimf = uni(ylimf_);
+    const double lam = uni_d(lam_);
+    long long* clk = uni_ptr(clk_);
+    long long* subclk = uni_ptr(subclk_);
+    const int tid = threadIdx.x;
+    int fallbacks = 0;
+#ifdef SL_DEBUG_SUBCLK
+#define SL_SUB(j) { __syncthreads(); if (subclk && tid == 0) subclk[(j)] = wall_clock64(); }
+#else
+#define SL_SUB(j)
+    (void)subclk;
+#endif
+    if (tid == 0) {
+        LassoK L;
+        lasso_consts(sh.M, lam, L);
+        sh.L = L;
+        sh.n_raw = 0; sh.overflow = 0;
+    }
+    __syncthreads();
+    SL_SUB(7);
+    {
+        const bool dense = stride_log2 < 0;                            // block-uniform
+        SampleConcKey ckey;
+        ckey.sample = samp; ckey.tab = view_of_b(sh.tab); ckey.L = sh.L; ckey.cps_log2 = dense ? kDenseCps : stride_log2 - 2;
+        ckey.P = P; ckey.col = 0;
+        float lo[2], hi[2];
+        conc_brackets<NT>(ckey, n_sample, lo, hi, sh.S, dense ? (float)sqrt(kClusterDeff) : 1.0f);
+        if (tid == 0) { sh.lo[0] = lo[0]; sh.hi[0] = hi[0]; sh.lo[1] = lo[1]; sh.hi[1] = hi[1]; }
+        __syncthreads();
+    }
+    if (clk && tid == 0) clk[4] = wall_clock64();
+    fused_select<NT, ALIGNED>(shp, src, rawl, P, cap_raw, ylimf, stream, 0);
+    __threadfence_block();
+    __syncthreads();
+    if (clk && tid == 0) clk[5] = wall_clock64();
+    {
+        long long k;
+        double gfrac;
+        percentile_pos((double)P, 99.0, k, gfrac);
+        ConcTileKey tkey;
+        tkey.src = src; tkey.tab = view_of_b(sh.tab); tkey.L = sh.L;
+        RawConcKey2 rkey;
+        rkey.raw = rawl; rkey.tab = view_of_b(sh.tab); rkey.L = sh.L;
+        const bool complete = sh.n_raw <= (uint32_t)cap_raw && sh.overflow == 0;
+        const uint32_t n_raw = sh.n_raw < (uint32_t)cap_raw ? sh.n_raw : (uint32_t)cap_raw;
+        const float los[2] = {sh.lo[0], sh.lo[1]}, his[2] = {sh.hi[0], sh.hi[1]};
+        const long long n_plain = (long long)P - (long long)sh.n_raw;        // plain = pixels not collected
+        uint32_t n_lt[2], n_in[2];
+        SL_SUB(8);
+        wg_refine((int)n_raw, rkey, los, his, cand0, cand1, (uint32_t)cap_list, n_lt, n_in, sh.S);
+        SL_SUB(9);
+        for (int col = 0; col < 2; ++col) {
+            tkey.col = col;
+            float xa, xb;
+            stage_order_stats(col ? cand1 : cand0, n_in[col], (uint32_t)cap_list, complete, los[col], his[col], n_plain + n_lt[col], P,
+                              tkey, (uint32_t)P, k, xa, xb, fallbacks, sh.S);
+            if (tid == 0) { sh.res[2 * col] = xa; sh.res[2 * col + 1] = xb; }
+            __syncthreads();
+            SL_SUB(10 + col);
+        }
+        if (tid == 0) {
+            sh.maxC[0] = np_lerp((double)sh.res[0], (double)sh.res[1], gfrac);   // normalizer.py:36,47
+            sh.maxC[1] = np_lerp((double)sh.res[2], (double)sh.res[3], gfrac);
+            if (!(sh.maxC[0] > 0.0) || !(sh.maxC[1] > 0.0)) sh.status = SL_TILE_ZERO_MAXC;
+        }
+        __syncthreads();
+    }
+#undef SL_SUB
+    return fallbacks;
+}
+
 enum { kMethodMacenko = 0, kMethodVahadane = 1 };
 
 // NT = 512: two workgroups per CU (the throughput configuration).  NT = 1024 (Macenko, round 4): one workgroup per CU for batches of
@@ -1051,7 +1143,7 @@ template <int METHOD, bool TRANSFORM, bool ALIGNED, int NT>
 static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
     __shared__ FusedShared<NT> sh;
     fused_lds_origin(sh);
-    const int tid = threadIdx.x;
+    [[maybe_unused]] const int tid = threadIdx.x;      // (the development macros; the glue below reads lane_id())
     const TabReaderB TB = TabReaderB::make(sh.tab);       // the 8-byte {gamma, od32} rows serve every sweep
     const int nch = (a.P + 3) >> 2;
     uint32_t* samp = a.sample + (size_t)blockIdx.x * a.sample_cap;
@@ -1092,7 +1184,15 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
             if (younger) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
         }
     };
-    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    // Tiles: the first by position, the later rounds from the launch's counter -- a workgroup whose tiles were quick (empty, background)
+    // takes more of them (a batch of 2 048 tiles 512^2, every fourth one white: 2.15 -> 1.88 ms); a tile's results do not depend on who
+    // computes them.  The counter is asked before the apply sweep, whose length hides the answer's way back; sh.next_tile is read after
+    // the barrier that ends the tile.
+    // (the thread's index, read afresh wherever the glue between the phases needs it: from one `tid` the compiler derived three dozen
+    //  per-thread addresses before the tile loop and kept them in scratch across it -- 86 stores per lane, 0.56 KB, in a kernel whose
+    //  scratch is written back to HBM once per tile)
+    auto lane_id = []() { int t = (int)threadIdx.x; asm volatile("" : "+v"(t)); return t; };
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile = __builtin_amdgcn_readfirstlane(sh.next_tile)) {
         const size_t nbytes = (size_t)a.P * 3;
 #ifdef SL_DEBUG_SAMETILE
         const uint8_t* src = a.rgb + (size_t)(tile & SL_DEBUG_SAMETILE) * nbytes;   // development aid: cache-resident input (0: one tile, 7: eight)
@@ -1103,7 +1203,7 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
         int sweeps_used = 0;
 #ifdef SL_DEVTOOLS
 // (Macenko only: in k_fused<vahadane, transform, unaligned> the extra `continue` edges run into the hipcc bug described in the Makefile)
-#define SL_PHASE(i) { if (METHOD == kMethodMacenko) { if (a.phase_clock && tid == 0) a.phase_clock[(size_t)tile * 8 + (i)] = wall_clock64(); if (a.debug_stop == (i) + 1) { __syncthreads(); continue; } } }
+#define SL_PHASE(i) { if (METHOD == kMethodMacenko) { if (a.phase_clock && tid == 0) a.phase_clock[(size_t)tile * 8 + (i)] = wall_clock64(); if (a.debug_stop == (i) + 1) { if (tid == 0) sh.next_tile = tile + (int)gridDim.x; __syncthreads(); continue; } } }
 #else
 #define SL_PHASE(i)
 #endif
@@ -1117,7 +1217,7 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
         __syncthreads();
 
         if constexpr (METHOD == kMethodMacenko) {
-            if (tid == 0) {
+            if (lane_id() == 0) {
                 sh.n_raw = 0; sh.n_ang = 0; sh.overflow = 0;
                 sh.conc_done = 0;
                 sh.use_cube = 0;
@@ -1152,20 +1252,20 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
             prio_sweep(0);
             if (ts_on) fused_sweep1c<NT, ALIGNED>(&sh, src, rawl, rawa, a.P, a.cap_raw, a.cap_ang, a.ylimf, stream ? 1 : 0);
             else fused_sweep1<NT, ALIGNED>(&sh, src, samp, a.P, a.ylimf, a.stride_log2, stream ? 1 : 0);   // (a declined tile: the stratified sample replaces the cluster sample)
-            if (ts_on && tid == 0) sh.ts.dense = 1;
+            if (ts_on && lane_id() == 0) sh.ts.dense = 1;
             prio_finish();
             __threadfence_block();
             __syncthreads();
-            if (tid < 10) {
+            if (lane_id() < 10) {
                 double t = 0;
-                for (int w = 0; w < NT / 64; ++w) t += sh.red[w][tid];
-                sh.sum[tid] = t;
+                for (int w = 0; w < NT / 64; ++w) t += sh.red[w][lane_id()];
+                sh.sum[lane_id()] = t;
             }
             __syncthreads();
             SL_PHASE(1);
             // ---------------- finish 1: eigenvectors, angle brackets
             SL_SUB(0);
-            if (tid == 0) {
+            if (lane_id() == 0) {
                 double Vd[6];
                 float Vf[6];
                 sh.status = eigvecs_from_moments(sh.sum, Vd, Vf);
@@ -1177,10 +1277,10 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
             bool direct = false;                                              // block-uniform: the two-sweep route settled the tile's M
             if (sh.status == SL_TILE_OK && ts_on) {                           // block-uniform
                 // ---------------- two-sweep finish: do the half-spaces the sweep tested against hold for the exact eigenvectors?
-                if (tid < 64) {
+                if (lane_id() < 64) {
                     float br[4];
-                    const bool okv = ts_verify(sh.ts, sh.Vd, br, tid, a.two_sweep == 3);
-                    if (tid == 0) {
+                    const bool okv = ts_verify(sh.ts, sh.Vd, br, lane_id(), a.two_sweep == 3);
+                    if (lane_id() == 0) {
                         sh.lo[0] = br[0]; sh.hi[0] = br[1]; sh.lo[1] = br[2]; sh.hi[1] = br[3];
                         if (!okv) { sh.ts.ok = 0; sh.ts.why = kTsPlane; }
 #ifdef SL_TS_DEBUG
@@ -1198,10 +1298,10 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
 #endif
                                                      , 1);
                     if (fb >= 0) { fallbacks += fb; direct = true; }
-                    else if (tid == 0) { sh.ts.ok = 0; sh.ts.why = kTsBracket; }
+                    else if (lane_id() == 0) { sh.ts.ok = 0; sh.ts.why = kTsBracket; }
                 }
                 if (!direct) {                                                // the three-sweep route from the exact moments
-                    if (tid == 0) {
+                    if (lane_id() == 0) {
                         sh.n_raw = 0; sh.n_ang = 0; sh.overflow = 0;
                         sh.conc_done = 0;
                         sh.use_cube = 0;
@@ -1241,20 +1341,20 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
         } else {
             // ---------------- Vahadane: class-moment dictionary learning
             prio_sweep(0);
-            gather_sample<ALIGNED>(src, a.P, a.stride_log2, samp, a.n_sample, tid, NT);
-            if (tid == 0) {
+            gather_sample<ALIGNED>(src, a.P, a.stride_log2, samp, a.n_sample, lane_id(), NT);
+            if (lane_id() == 0) {
                 dict_iter_init(sh.it);
                 sh.n_raw = 0; sh.overflow = 0;
                 sh.conc_done = 0;
             }
             __syncthreads();
             DictProgress pr{1, 0, 0, 0};
-            if (stream) dict_learn<ALIGNED, NT, false, true>(src, a.P, nch, tid, TB, a.ylimf, a.stride_log2, samp, a.n_sample, a.dl_lambda,
+            if (stream) dict_learn<ALIGNED, NT, false, true>(src, a.P, nch, lane_id(), TB, a.ylimf, a.stride_log2, samp, a.n_sample, a.dl_lambda,
                                                              a.dl_tol, a.dl_max_sweeps, sh.it, sh.red, sh.sum, pr);
-            else dict_learn<ALIGNED, NT, false, false>(src, a.P, nch, tid, TB, a.ylimf, a.stride_log2, samp, a.n_sample, a.dl_lambda,
+            else dict_learn<ALIGNED, NT, false, false>(src, a.P, nch, lane_id(), TB, a.ylimf, a.stride_log2, samp, a.n_sample, a.dl_lambda,
                                                        a.dl_tol, a.dl_max_sweeps, sh.it, sh.red, sh.sum, pr);
             sweeps_used = pr.sweeps_used;
-            if (tid == 0) {
+            if (lane_id() == 0) {
                 sh.status = sh.it.status;
                 if (sh.status == SL_TILE_OK) {
                     dict_iter_stain_matrix(sh.it, sh.M);
@@ -1266,83 +1366,50 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
         const bool bad = sh.status != SL_TILE_OK;                               // block-uniform
         const bool resweep = !bad && !sh.conc_done;                             // block-uniform: sweep 3 of the four-sweep schedule
         if (resweep) {
-            if (tid == 0) {
-                LassoK L;
-                lasso_consts(sh.M, a.lam, L);
-                sh.L = L;
-                sh.n_raw = 0; sh.overflow = 0;
-            }
-            __syncthreads();
-            SL_SUB(7);
-            // ---------------- concentration brackets from the sample
-            {
-                const bool dense = METHOD == kMethodMacenko && sh.ts.dense != 0;       // block-uniform: the cluster sample of the two-sweep schedule
-                SampleConcKey ckey;
-                ckey.sample = samp; ckey.tab = view_of_b(sh.tab); ckey.L = sh.L; ckey.cps_log2 = dense ? kDenseCps : a.stride_log2 - 2;
-                ckey.P = a.P; ckey.col = 0;
-                float lo[2], hi[2];
-                conc_brackets<NT>(ckey, dense ? a.cl_lines * kClusterPx : a.n_sample, lo, hi, sh.S, dense ? (float)sqrt(kClusterDeff) : 1.0f);
-                if (tid == 0) { sh.lo[0] = lo[0]; sh.hi[0] = hi[0]; sh.lo[1] = lo[1]; sh.hi[1] = hi[1]; }
-                __syncthreads();
-            }
-            SL_PHASE(4);
-            // ---------------- sweep 3: concentration select
+            // ---------------- concentration brackets from the sample, sweep 3 (concentration select), finish 3 (exact 99th percentiles -> maxC)
             prio_sweep(2);
-            run_select(false, src);
+            fallbacks += fused_conc_resweep<NT, ALIGNED>(&sh, src, samp, rawl, cand0, cand1, a.P, a.cap_raw, a.cap_list, a.ylimf, a.lam, stream ? 1 : 0,
+                                                         (METHOD == kMethodMacenko && sh.ts.dense != 0) ? a.cl_lines * kClusterPx : a.n_sample,
+                                                         (METHOD == kMethodMacenko && sh.ts.dense != 0) ? -1 : a.stride_log2,
+#ifdef SL_DEVTOOLS
+                                                         (METHOD == kMethodMacenko && a.phase_clock) ? a.phase_clock + (size_t)tile * 8 : nullptr,
+#else
+                                                         nullptr,
+#endif
+#ifdef SL_DEBUG_SUBCLK
+                                                         a.phase_clock ? a.phase_clock + (size_t)a.n_tiles * 8 + (size_t)tile * 16 : nullptr
+#else
+                                                         nullptr
+#endif
+                                                         );
             prio_finish();
-            SL_PHASE(5);
-            // ---------------- finish 3: exact 99th percentiles -> maxC
-            {
-                long long k;
-                double gfrac;
-                percentile_pos((double)a.P, 99.0, k, gfrac);
-                ConcTileKey tkey;
-                tkey.src = src; tkey.tab = view_of_b(sh.tab); tkey.L = sh.L;
-                RawConcKey2 rkey;
-                rkey.raw = rawl; rkey.tab = view_of_b(sh.tab); rkey.L = sh.L;
-                const bool complete = sh.n_raw <= (uint32_t)a.cap_raw && sh.overflow == 0;
-                const uint32_t n_raw = sh.n_raw < (uint32_t)a.cap_raw ? sh.n_raw : (uint32_t)a.cap_raw;
-                const float los[2] = {sh.lo[0], sh.lo[1]}, his[2] = {sh.hi[0], sh.hi[1]};
-                const long long n_plain = (long long)a.P - (long long)sh.n_raw;        // plain = pixels not collected
-                uint32_t n_lt[2], n_in[2];
-                SL_SUB(8);
-                wg_refine((int)n_raw, rkey, los, his, cand0, cand1, (uint32_t)a.cap_list, n_lt, n_in, sh.S);
-                SL_SUB(9);
-                for (int col = 0; col < 2; ++col) {
-                    tkey.col = col;
-                    float xa, xb;
-                    stage_order_stats(col ? cand1 : cand0, n_in[col], (uint32_t)a.cap_list, complete, los[col], his[col], n_plain + n_lt[col], a.P,
-                                      tkey, (uint32_t)a.P, k, xa, xb, fallbacks, sh.S);
-                    if (tid == 0) { sh.res[2 * col] = xa; sh.res[2 * col + 1] = xb; }
-                    __syncthreads();
-                    SL_SUB(10 + col);
-                }
-                if (tid == 0) {
-                    sh.maxC[0] = np_lerp((double)sh.res[0], (double)sh.res[1], gfrac);   // normalizer.py:36,47
-                    sh.maxC[1] = np_lerp((double)sh.res[2], (double)sh.res[3], gfrac);
-                    if (!(sh.maxC[0] > 0.0) || !(sh.maxC[1] > 0.0)) sh.status = SL_TILE_ZERO_MAXC;
-                }
-                __syncthreads();
-            }
-        } else if (bad && sh.status != SL_TILE_ZERO_MAXC && tid == 0) {     // (a zero maxC keeps its M and maxC, as after finish 3)
+        } else if (bad && sh.status != SL_TILE_ZERO_MAXC && lane_id() == 0) {     // (a zero maxC keeps its M and maxC, as after finish 3)
             for (int i = 0; i < 6; ++i) sh.M[i] = nan_d();
             sh.maxC[0] = sh.maxC[1] = nan_d();
         }
         __syncthreads();
-        if (tid == 0 && a.resweep_out) a.resweep_out[tile] = (METHOD == kMethodMacenko && resweep) ? (sh.why ? sh.why : SL_RESWEEP_NO_BOX) : 0;
-        if (tid < 6 && a.M_out) a.M_out[(size_t)tile * 6 + tid] = sh.M[tid];
-        if (tid < 2 && a.maxC_out) a.maxC_out[(size_t)tile * 2 + tid] = sh.maxC[tid];
-        if (tid == 0 && a.status_out) a.status_out[tile] = sh.status;
-        if (tid == 0 && a.diag_out) a.diag_out[tile] = fallbacks;
-        if (tid == 0 && a.sweeps_out) a.sweeps_out[tile] = sweeps_used;
-        if (METHOD == kMethodMacenko && tid == 0 && a.cube_out) a.cube_out[tile] = (sh.status == SL_TILE_OK || sh.status == SL_TILE_ZERO_MAXC) ? sh.use_cube : 0;
-        if (METHOD == kMethodMacenko && tid == 0 && a.ts_out) a.ts_out[tile] = sh.ts.why;
+        if (lane_id() == 0) sh.next_tile = a.n_tiles <= (int)gridDim.x ? a.n_tiles : a.next_tile ? (int)gridDim.x + (int)atomicAdd(a.next_tile, 1ull) : tile + (int)gridDim.x;
+        if (lane_id() == 0 && a.resweep_out) a.resweep_out[tile] = (METHOD == kMethodMacenko && resweep) ? (sh.why ? sh.why : SL_RESWEEP_NO_BOX) : 0;
+        if (lane_id() < 6 && a.M_out) a.M_out[(size_t)tile * 6 + lane_id()] = sh.M[lane_id()];
+        if (lane_id() < 2 && a.maxC_out) a.maxC_out[(size_t)tile * 2 + lane_id()] = sh.maxC[lane_id()];
+        if (lane_id() == 0 && a.status_out) a.status_out[tile] = sh.status;
+        if (lane_id() == 0 && a.diag_out) a.diag_out[tile] = fallbacks;
+        if (lane_id() == 0 && a.sweeps_out) a.sweeps_out[tile] = sweeps_used;
+        if (METHOD == kMethodMacenko && lane_id() == 0 && a.cube_out) a.cube_out[tile] = (sh.status == SL_TILE_OK || sh.status == SL_TILE_ZERO_MAXC) ? sh.use_cube : 0;
+        if (METHOD == kMethodMacenko && lane_id() == 0 && a.ts_out) a.ts_out[tile] = sh.ts.why;
         SL_PHASE(6);
         // ---------------- sweep 4: apply
         if (TRANSFORM) {
             uint8_t* dst = a.out + (size_t)tile * nbytes;
             if (sh.status != SL_TILE_OK) {       // block-uniform (sh.status is final: barrier above); includes a zero maxC found in finish 3
-                for (int c = tid; c < nch; c += NT) store_chunk<ALIGNED>(dst, nbytes, c, load_chunk<ALIGNED>(src, nbytes, c));
+                for (int c = lane_id(); c < nch; c += 8 * NT) {          // eight chunks in flight per lane (one at a time: 340 us per Mpixel tile; now ~60)
+                    Chunk ch[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) ch[k] = load_chunk_clamped<ALIGNED, false>(src, nbytes, c + k * NT, nch);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (c + k * NT < nch) store_chunk<ALIGNED>(dst, nbytes, c + k * NT, ch[k]);
+                }
             } else {
                 prio_sweep(3);
                 fused_apply<NT, ALIGNED>(&sh, src, dst, a.P, a.M_tgt, a.maxC_tgt, a.lam, stream ? 1 : 0);
