@@ -553,6 +553,74 @@ __device__ SL_FINISH_ATTR int fused_finish2(FusedShared<NT>* shp, const uint8_t*
 // fixed-range histogram and one wave_locate per rank (the register-resident windowed search of finish 1 needs four passes and three
 // times the barriers: 33-45 us per set where this takes ~15; its brackets are tighter by a histogram bin -- 0.002 of pseudo-angle,
 // ~1 % of a concentration -- which costs this schedule a few hundred candidates), and the fourth moments ride in the angle pass.
+// Phase 0, one thread: the sample's eigenvectors, the plane's normal and the Gaussian tilt bound from sh.sum (out of line: the binary64
+// Jacobi sweep wants three dozen registers of its own while every thread of fused_phase0 holds its 32 sample words -- inlined, 28 of
+// them went to scratch around it; out of line they sit in callee-saved registers).
+template <int NT>
+__device__ __noinline__ void phase0_estimate(FusedShared<NT>* shp, int mode_) {
+    FusedShared<NT>& sh = *shp;
+    const int mode = __builtin_amdgcn_readfirstlane(mode_);
+    double Vd[6], wv[3];
+    float Vf[6];
+    const int st = eigvecs_from_moments(sh.sum, Vd, Vf, wv);
+    const double ns = sh.sum[0];
+    // the tilt a Gaussian cloud of this size would show: v_j^T dC v_3 / (l_j - l_3), sd sqrt(l_j l_3 / n)
+    const double l1 = wv[0], l2 = wv[1], l3 = wv[2] > 0.0 ? wv[2] : 0.0;
+    bool ok = st == SL_TILE_OK && ns >= (double)kTsMinTissue && l2 > 1e-9 * l1 && l2 - l3 > 0.05 * l2;
+    double tau = 0.0;
+    if (ok) {
+        tau = kTiltZ * sqrt(kClusterDeff / ns) * fmax(sqrt(l3 * l2) / (l2 - l3), sqrt(l3 * l1) / (l1 - l3));
+        tau = fmax(tau, kTsMinTau);
+        // Tissue with a strong third component (the ihc fixture: 1.3e-2 here; H&E-like tiles 2-4e-3): the tilt allowance then puts a quarter
+        // of the pixels on the concentration list and the tile would decline at the END of this phase, 170 us later -- it leaves now.
+        ok = tau <= (mode >= 2 ? kTsMaxTau : kTsAutoMaxTau);
+    }
+    double nd[3] = {Vd[2] * Vd[5] - Vd[4] * Vd[3], Vd[4] * Vd[1] - Vd[0] * Vd[5], Vd[0] * Vd[3] - Vd[2] * Vd[1]};
+    const double nn = 1.0 / sqrt(nd[0] * nd[0] + nd[1] * nd[1] + nd[2] * nd[2]);
+    if (mode == 4 && ok) {                                    // tests: the sample's plane tilted by 0.05 (second column towards the normal)
+        double b[3];
+        for (int c = 0; c < 3; ++c) b[c] = Vd[2 * c + 1] + 0.05 * nd[c] * nn;
+        const double nb = 1.0 / sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
+        for (int c = 0; c < 3; ++c) { Vd[2 * c + 1] = b[c] * nb; Vf[2 * c + 1] = (float)Vd[2 * c + 1]; }
+        nd[0] = Vd[2] * Vd[5] - Vd[4] * Vd[3]; nd[1] = Vd[4] * Vd[1] - Vd[0] * Vd[5]; nd[2] = Vd[0] * Vd[3] - Vd[2] * Vd[1];
+    }
+    const double nn2 = 1.0 / sqrt(nd[0] * nd[0] + nd[1] * nd[1] + nd[2] * nd[2]);
+    for (int i = 0; i < 6; ++i) { sh.ts.Vd[i] = Vd[i]; sh.Vd[i] = Vd[i]; sh.Vf[i] = Vf[i]; }
+    for (int c = 0; c < 3; ++c) { sh.ts.nd[c] = nd[c] * nn2; sh.ts.fn[c] = (float)(nd[c] * nn2); }
+    sh.ts.tau = tau;
+    sh.ts.gH[0] = l1 - l3; sh.ts.gH[1] = l2 - l3;             // (scratch: the eigenvalue gaps for the fourth moments below)
+    sh.res[0] = (float)(4.0 * sqrt(l3));                      // zref of ts_thresholds
+    sh.res[1] = (float)(sh.sum[1] / ns); sh.res[2] = (float)(sh.sum[2] / ns); sh.res[3] = (float)(sh.sum[3] / ns);     // the sample's mean
+    sh.status = ok ? SL_TILE_OK : SL_TILE_DEGENERATE_COV;     // (scratch here: sweep 1 sets the tile's real status)
+}
+
+// Phase 0, wave 0: the two half-spaces of the plain cone (normals from the inner bracket ends) and the box of stain matrices.  Out of line
+// like phase0_estimate: its binary64 trigonometry made EVERY wave of fused_phase0 park 26 registers in scratch on the way past it.
+template <int NT>
+__device__ __noinline__ void phase0_cone_and_box(FusedShared<NT>* shp, float hi0_, float lo1_, double lam_) {
+    FusedShared<NT>& sh = *shp;
+    const float hi0 = uni(hi0_), lo1 = uni(lo1_);
+    const double lam = uni_d(lam_);
+    const int tid = threadIdx.x;
+    // half-space normals: H-type (-sin a, cos a), L-type (sin a, -cos a) in the plane, then V~ n
+    const double aH = angle_of_pseudo((double)hi0), aL = angle_of_pseudo((double)lo1);
+    double sH, cH, sL, cL;
+    sincos(aH, &sH, &cH);
+    sincos(aL, &sL, &cL);
+    if (tid == 0) {
+        const double k2 = sh.ts.kappa2 + 6e-6;                // + the sweep's own binary32 rounding and that of the finish's keys
+        for (int c = 0; c < 3; ++c) {
+            const double gH = sh.ts.Vd[2 * c] * -sH + sh.ts.Vd[2 * c + 1] * cH, gL = sh.ts.Vd[2 * c] * sL + sh.ts.Vd[2 * c + 1] * -cL;
+            sh.ts.gH[c] = gH; sh.ts.gL[c] = gL;
+            sh.ts.fgH[c] = (float)(gH - k2); sh.ts.fgL[c] = (float)(gL - k2);
+        }
+        sh.ts.fk1 = (float)(sh.ts.kappa1 * (1.0 + 1e-6));
+        sh.ts.lo0 = sh.lo[0]; sh.ts.hi1 = sh.hi[1];
+    }
+    // ---------------- the box of stain matrices (in-plane grid x tilts)
+    ts_box(sh.ts.Vd, sh.ts.nd, sh.ts.tau, sh.box, lam, tid, sh.mk);
+}
+
 constexpr int kP0Bins = 1024;            // angle keys: pseudo-angle [-1, 1) in 1024 bins; concentrations: 512 bins per stain of c / (c + 1)
 template <int NT>
 __device__ SL_FINISH_ATTR void fused_phase0(FusedShared<NT>* shp, const uint8_t* src_, uint32_t* samp_, int P_, int n_lines_, float ylimf_, double pct_, double lam_,
@@ -626,40 +694,7 @@ __device__ SL_FINISH_ATTR void fused_phase0(FusedShared<NT>* shp, const uint8_t*
         sh.sum[tid] = t;
     }
     __syncthreads();
-    if (tid == 0) {
-        double Vd[6], wv[3];
-        float Vf[6];
-        const int st = eigvecs_from_moments(sh.sum, Vd, Vf, wv);
-        const double ns = sh.sum[0];
-        // the tilt a Gaussian cloud of this size would show: v_j^T dC v_3 / (l_j - l_3), sd sqrt(l_j l_3 / n)
-        const double l1 = wv[0], l2 = wv[1], l3 = wv[2] > 0.0 ? wv[2] : 0.0;
-        bool ok = st == SL_TILE_OK && ns >= (double)kTsMinTissue && l2 > 1e-9 * l1 && l2 - l3 > 0.05 * l2;
-        double tau = 0.0;
-        if (ok) {
-            tau = kTiltZ * sqrt(kClusterDeff / ns) * fmax(sqrt(l3 * l2) / (l2 - l3), sqrt(l3 * l1) / (l1 - l3));
-            tau = fmax(tau, kTsMinTau);
-            // Tissue with a strong third component (the ihc fixture: 1.3e-2 here; H&E-like tiles 2-4e-3): the tilt allowance then puts a quarter
-            // of the pixels on the concentration list and the tile would decline at the END of this phase, 170 us later -- it leaves now.
-            ok = tau <= (mode >= 2 ? kTsMaxTau : kTsAutoMaxTau);
-        }
-        double nd[3] = {Vd[2] * Vd[5] - Vd[4] * Vd[3], Vd[4] * Vd[1] - Vd[0] * Vd[5], Vd[0] * Vd[3] - Vd[2] * Vd[1]};
-        const double nn = 1.0 / sqrt(nd[0] * nd[0] + nd[1] * nd[1] + nd[2] * nd[2]);
-        if (mode == 4 && ok) {                                    // tests: the sample's plane tilted by 0.05 (second column towards the normal)
-            double b[3];
-            for (int c = 0; c < 3; ++c) b[c] = Vd[2 * c + 1] + 0.05 * nd[c] * nn;
-            const double nb = 1.0 / sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
-            for (int c = 0; c < 3; ++c) { Vd[2 * c + 1] = b[c] * nb; Vf[2 * c + 1] = (float)Vd[2 * c + 1]; }
-            nd[0] = Vd[2] * Vd[5] - Vd[4] * Vd[3]; nd[1] = Vd[4] * Vd[1] - Vd[0] * Vd[5]; nd[2] = Vd[0] * Vd[3] - Vd[2] * Vd[1];
-        }
-        const double nn2 = 1.0 / sqrt(nd[0] * nd[0] + nd[1] * nd[1] + nd[2] * nd[2]);
-        for (int i = 0; i < 6; ++i) { sh.ts.Vd[i] = Vd[i]; sh.Vd[i] = Vd[i]; sh.Vf[i] = Vf[i]; }
-        for (int c = 0; c < 3; ++c) { sh.ts.nd[c] = nd[c] * nn2; sh.ts.fn[c] = (float)(nd[c] * nn2); }
-        sh.ts.tau = tau;
-        sh.ts.gH[0] = l1 - l3; sh.ts.gH[1] = l2 - l3;             // (scratch: the eigenvalue gaps for the fourth moments below)
-        sh.res[0] = (float)(4.0 * sqrt(l3));                      // zref of ts_thresholds
-        sh.res[1] = (float)(sh.sum[1] / ns); sh.res[2] = (float)(sh.sum[2] / ns); sh.res[3] = (float)(sh.sum[3] / ns);     // the sample's mean
-        sh.status = ok ? SL_TILE_OK : SL_TILE_DEGENERATE_COV;     // (scratch here: sweep 1 sets the tile's real status)
-    }
+    if (tid == 0) phase0_estimate<NT>(shp, mode);
     __syncthreads();
     SL_SUB(2);
     if (sh.status != SL_TILE_OK) return;                          // block-uniform: no estimate
@@ -750,25 +785,7 @@ __device__ SL_FINISH_ATTR void fused_phase0(FusedShared<NT>* shp, const uint8_t*
     // the plain cone must be closed on its inner sides and lie within +-90 degrees of the first eigenvector
     const float hi0 = sh.hi[0], lo1 = sh.lo[1];
     if (!(hi0 > -0.95f && hi0 < lo1 && lo1 < 0.95f)) return;      // block-uniform (NaN / open ends fail the comparisons)
-    if (tid < 64) {
-        // half-space normals: H-type (-sin a, cos a), L-type (sin a, -cos a) in the plane, then V~ n
-        const double aH = angle_of_pseudo((double)hi0), aL = angle_of_pseudo((double)lo1);
-        double sH, cH, sL, cL;
-        sincos(aH, &sH, &cH);
-        sincos(aL, &sL, &cL);
-        if (tid == 0) {
-            const double k2 = sh.ts.kappa2 + 6e-6;                // + the sweep's own binary32 rounding and that of the finish's keys
-            for (int c = 0; c < 3; ++c) {
-                const double gH = sh.ts.Vd[2 * c] * -sH + sh.ts.Vd[2 * c + 1] * cH, gL = sh.ts.Vd[2 * c] * sL + sh.ts.Vd[2 * c + 1] * -cL;
-                sh.ts.gH[c] = gH; sh.ts.gL[c] = gL;
-                sh.ts.fgH[c] = (float)(gH - k2); sh.ts.fgL[c] = (float)(gL - k2);
-            }
-            sh.ts.fk1 = (float)(sh.ts.kappa1 * (1.0 + 1e-6));
-            sh.ts.lo0 = sh.lo[0]; sh.ts.hi1 = sh.hi[1];
-        }
-        // ---------------- the box of stain matrices (in-plane grid x tilts)
-        ts_box(sh.ts.Vd, sh.ts.nd, sh.ts.tau, sh.box, lam, tid, sh.mk);
-    }
+    if (tid < 64) phase0_cone_and_box<NT>(shp, hi0, lo1, lam);
     __syncthreads();
     SL_SUB(4);
     // ---------------- concentration brackets under the box centre: both stains' keys as c / (c + 1) into 512 bins each
