@@ -58,7 +58,20 @@ for n in 64 512; do
   rm -rf /tmp/pm_$n; timeout 300 rocprofv3 --pmc FETCH_SIZE -d /tmp/pm_$n -o p -- python tools/run_fused_once.py $n 1 > /dev/null 2>&1
   python tools/pmc_summary.py "$(ls /tmp/pm_$n/*/*.db /tmp/pm_$n/*.db 2>/dev/null | head -1)" > "$out/${tag}_pmc_phase_fetch_n$n.txt" 2>&1
 done
+# round 5: what the fused FIT kernel writes (no output: lists, sample and scratch) and reads beyond the tile
+for pass in "f:FETCH_SIZE" "w:WRITE_SIZE"; do
+  t=${pass%%:*}; c=${pass#*:}
+  rm -rf /tmp/pmc_fit_$t; timeout 400 rocprofv3 --pmc $c -d /tmp/pmc_fit_$t -o p -- python tools/run_fused_once.py 512 2 0 fit > /dev/null 2>&1
+  python tools/pmc_summary.py "$(ls /tmp/pmc_fit_$t/*/*.db /tmp/pmc_fit_$t/*.db 2>/dev/null | head -1)" 2>&1 | grep -A2 "k_fused" > "$out/${tag}_pmc_fit_$t.txt"
+done
+# ... and what bounds the Lab sweeps: instruction counts and LDS conflicts
+for pass in "v:SQ_INSTS_VALU SQ_INSTS_LDS" "l:SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "b:SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU"; do
+  t=${pass%%:*}; c=${pass#*:}
+  rm -rf /tmp/pmc_lab_$t; timeout 400 rocprofv3 --pmc $c -d /tmp/pmc_lab_$t -o p -- python tools/run_lab.py > /dev/null 2>&1
+  python tools/pmc_summary.py "$(ls /tmp/pmc_lab_$t/*/*.db /tmp/pmc_lab_$t/*.db 2>/dev/null | head -1)" 2>&1 | grep -A3 "k_lab\|k_byte" >> "$out/${tag}_pmc_lab.txt"
+done
 python tools/make_pmc_traffic.py "$tag" "$out" > "$out/${tag}_pmc_traffic.json" 2> /dev/null
+python tools/time_batches.py 2>/dev/null | grep " ms" > "$out/${tag}_batches_mixed.txt"
 # configs[4] at one GPU's shard size, the Lab family's kernels
 python tools/slide_scale.py 512,2048,12500 2>/dev/null | grep -v amdgpu > "$out/${tag}_slide_scale.txt"
 timeout 200 python tools/power_classes.py 2>/dev/null | grep -v amdgpu > "$out/${tag}_power_classes.txt"

@@ -61,6 +61,18 @@ for ts, label in ((1, "three_sweep_every_tile (two_sweep=1)"), (2, "every_tile_t
     hbm = int(round((2.0 * fr + wr) * 1024))
     two_sweep[label] = {"FETCH_SIZE_KiB_raw": fr, "WRITE_SIZE_KiB": wr, "hbm_bytes_per_launch": hbm, "bytes_per_pixel": round(hbm / (tiles * px), 2),
                         "read_bytes_per_pixel": round(2.0 * fr * 1024 / (tiles * px), 2), "write_over_output": round(wr * 1024 / (3 * tiles * px), 4)}
+# round 5: the fused FIT kernel (no output): everything it writes is candidate lists, member lists, the sample and scratch
+fit = {}
+try:
+    ff, fw = dump(f"{d}/{tag}_pmc_fit_f.txt"), dump(f"{d}/{tag}_pmc_fit_w.txt")
+    fr, wr = pick(ff, "k_fused<0, false, true", "FETCH_SIZE"), pick(fw, "k_fused<0, false, true", "WRITE_SIZE")
+    if fr is not None and wr is not None:
+        fit = {"FETCH_SIZE_KiB_raw": fr, "WRITE_SIZE_KiB": wr, "read_bytes_per_pixel": round(2.0 * fr * 1024 / (tiles * px), 2),
+               "write_bytes_per_pixel": round(wr * 1024 / (tiles * px), 3), "write_bytes_per_tile": int(wr * 1024 / tiles),
+               "note": "k_fused<macenko, fit>: reads = the one tile sweep (3 B/px) + lists / sample / scratch read back; writes = lists + sample + scratch "
+                       "(i.i.d. tiles: ~0.36 MB raw candidates + ~0.32 MB bracket members + 0.06 MB sample per tile; the rest is scratch)"}
+except OSError:
+    pass
 phase = {}
 for n in (64, 512):
     try:
@@ -78,8 +90,9 @@ doc = {
            "calibration is k_apply in this same file, whose read volume is known exactly (512 x 3 145 728 B = 1 572 864 KiB). "
            "WRITE_SIZE needs no correction.",
     "tiles_per_launch": tiles, "pixels_per_tile": px, "kernels": kernels,
-    "fused_kernel_by_two_sweep_mode": dict(two_sweep, note="round 5 (stats_twosweep.hpp): `kernels` above is the DEFAULT (on its first tile only the workgroup launched "
-                                           "second on its CU tries the two-sweep route: half of a 512-tile batch); here the route off for every tile and forced for every tile"),
+    "fused_kernel_by_two_sweep_mode": dict(two_sweep, note="round 5 (stats_twosweep.hpp): `kernels` above is the DEFAULT (every workgroup tries the two-sweep route; on the "
+                                           "i.i.d. tiles of this run every tile takes it); here the route off for every tile and forced for every tile"),
+    "fused_fit_kernel": fit,
     "per_phase_schedule_fetch_KiB_raw": dict(phase, tile_KiB=3072, note="one launch per phase, FETCH_SIZE per kernel launch at 64 tiles (192 MB of "
                                              "tiles: fits the 256 MB Infinity Cache) and at 512 tiles (1.6 GB): the same raw KiB per tile in both -- "
                                              "the counter does not see Infinity Cache hits; whether residency buys TIME: *_phase_classes.txt, DESIGN.md 4.1"),
