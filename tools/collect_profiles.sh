@@ -78,6 +78,7 @@ timeout 200 python tools/power_classes.py 2>/dev/null | grep -v amdgpu > "$out/$
 python tools/structured_rate.py 2>/dev/null | grep -v amdgpu > "$out/${tag}_structured_rate.txt"
 python tools/cube_ab.py iid white_bg quantized ihc grey_bg blobs 2>/dev/null | grep -v amdgpu > "$out/${tag}_cube_prefilter_ab.txt"
 python tools/ts_check.py 512 1024 iid,white_bg,quantized,blobs,ihc,palette12 2>/dev/null | grep -v amdgpu > "$out/${tag}_two_sweep_ab.txt"
+(python tools/wide_two_sweep.py 160,192,224,256; python tools/wide_two_sweep.py 192,256 1024 ihc) 2>/dev/null | grep " n " > "$out/${tag}_wide_two_sweep.txt"
 [ -f "$dev" ] && STAINLIB_HIP_LIB=$dev python tools/ts_phases.py 512 1024 iid 2>/dev/null | grep -v amdgpu > "$out/${tag}_two_sweep_phases.txt"
 rm -rf /tmp/kl; timeout 300 rocprofv3 --kernel-trace -d /tmp/kl -o p -- python tools/run_lab.py > /dev/null 2>&1
 python tools/rocpd_stats.py "$(ls /tmp/kl/*/*.db /tmp/kl/*.db 2>/dev/null | head -1)" 2>&1 | grep -v "at::native\|rocclr\|Cijk" > "$out/${tag}_kernel_stats_lab.md"
