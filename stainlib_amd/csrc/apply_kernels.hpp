@@ -136,35 +136,23 @@ __device__ __forceinline__ void scale_lasso(LassoK& k, float sc) {
 // max(a + r m, 0) for results in [-1, 1]: v_fma_f32 with the VOP3 clamp modifier.  With m = min(a_other, 0) this is the lasso's
 // max(0, min(a, s)) (sl_device.hpp: s = a + r a_other), one instruction where a separate s cost three FMAs and a clamped min.
 __device__ __forceinline__ float fma_clamp01(float r, float m, float a) {
-#ifdef SL_EXP_NOCLAMP
-    return fmaxf(fmaf(r, m, a), 0.0f);
-#else
     float o;
     asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(o) : "v"(r), "v"(m), "v"(a));
     return o;
-#endif
 }
 
 // The lasso's min(a_other, 0) without a v_min_f32 (a 4-cycle instruction; multiplies and FMAs issue in 2): the concentrations are
 // carried scaled into [-1, 1], so  -min(a, 0) = max(0, min(1, -a))  is ONE v_mul_f32 by -1 with the clamp modifier, and the FMA that
 // follows takes r negated.  Bit-identical to the v_min form (a negation is exact; NaN clamps to 0 as fminf(NaN, 0) gives 0).
 __device__ __forceinline__ float neg_part01(float a) {          // -min(a, 0) for |a| <= 1
-#ifdef SL_EXP_NOCLAMP
-    return -fminf(a, 0.0f);
-#else
     float o;
     asm("v_mul_f32 %0, -1.0, %1 clamp" : "=v"(o) : "v"(a));
     return o;
-#endif
 }
 __device__ __forceinline__ float fnma_clamp01(float r, float m, float a) {     // max(a - r m, 0) for results in [-1, 1]
-#ifdef SL_EXP_NOCLAMP
-    return fmaxf(fmaf(-r, m, a), 0.0f);
-#else
     float o;
     asm("v_fma_f32 %0, -%1, %2, %3 clamp" : "=v"(o) : "v"(r), "v"(m), "v"(a));
     return o;
-#endif
 }
 
 __device__ __forceinline__ void apply_consts(const double* M_src, const double* maxC_src, const double* M_tgt,

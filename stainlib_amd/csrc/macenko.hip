@@ -525,12 +525,6 @@ extern "C" SL_API void sl_debug_set_phase_clock(long long* device_buf) { g_phase
 extern "C" SL_API void sl_debug_set_stop(int phase) { g_debug_stop = phase; }
 extern "C" SL_API void sl_debug_set_dyn_lds(unsigned bytes) { g_debug_dyn_lds = bytes; }
 
-#ifdef SL_DEBUG_INNER
-extern "C" SL_API void sl_debug_inner(unsigned long long* out, int reset) {
-    hipMemcpyFromSymbol(out, HIP_SYMBOL(sl::g_dbg_inner), 32);
-    if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; hipMemcpyToSymbol(HIP_SYMBOL(sl::g_dbg_inner), z, 32); }
-}
-#endif
 
 #ifdef SL_DEBUG_SUBCLK
 extern "C" SL_API void sl_debug_bclk(unsigned long long* out, int reset) {

@@ -11,16 +11,8 @@ namespace sl {
 constexpr int kMaxSample = 16384;   // samples per tile (<= P/64)
 constexpr int kMinCapRaw = 65536;   // raw-pixel candidate capacity per tile and stage: max(this, P/6), set by the host
 constexpr int kMinCapList = 16384;  // exact-key bracket members per list after the refine pass: max(this, P/8)
-#ifdef SL_EXP_FIN512
-constexpr int kFinishThreads = 512;
-#else
 constexpr int kFinishThreads = 1024;
-#endif
-#ifdef SL_EXP_FIN2
-#define SL_FINISH_BOUNDS __launch_bounds__(kFinishThreads, 2)
-#else
 #define SL_FINISH_BOUNDS __launch_bounds__(kFinishThreads)
-#endif
 constexpr int kFusedThreads = 512;  // 2 resident workgroups per CU (<=128 VGPRs, <80 KB LDS each)
 constexpr int kSweepThreads = 512;  // sweep kernels of the one-launch-per-phase schedule (same occupancy: 64 KB table each)
 constexpr int kFusedTrip = 4;       // chunks per lane and sweep trip in the fused kernel (even)

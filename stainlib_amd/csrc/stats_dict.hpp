@@ -290,9 +290,6 @@ __device__ __forceinline__ double dict_objective(const double (&D)[2][3], double
     return -tdb + 0.5 * (g11 * A[0][0] + 2.0 * g12 * A[0][1] + g22 * A[1][1]) + lam * sa;
 }
 
-#ifdef SL_DEBUG_INNER
-__device__ unsigned long long g_dbg_inner[4];     // solves, passes, wall-clock ticks (development aid)
-#endif
 // one pass of the block-coordinate dictionary update on frozen class moments: D <- g(D)
 __device__ __forceinline__ void dict_bcd_update(const double (&A)[2][2], const double (&B)[3][2], double (&D)[2][3]) {
 #pragma unroll
@@ -326,10 +323,6 @@ __device__ __forceinline__ void dict_bcd_pass(const double* mom, double (&D)[2][
 // G_first = g(D) of the incoming D, which the caller has from evaluating the objective there (the first pass is not computed twice).
 __device__ __forceinline__ double dict_inner_solve(const double* mom, double (&D)[2][3], double lam, int max_it, double inner_tol, bool mix,
                                                    const double (&G_first)[2][3]) {
-#ifdef SL_DEBUG_INNER
-    const long long dbg_t0 = wall_clock64();
-    int dbg_its = 0;
-#endif
     double D0[2][3], gp[2][3], fp[2][3];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -351,9 +344,6 @@ __device__ __forceinline__ double dict_inner_solve(const double* mom, double (&D
                 for (int k = 0; k < 3; ++k) G[j][k] = D[j][k];
             dict_bcd_pass(mom, G, lam);
         }
-#ifdef SL_DEBUG_INNER
-        ++dbg_its;
-#endif
         double f[2][3], step = 0.0, fn = 0.0, fdf = 0.0, dfdf = 0.0;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -396,10 +386,6 @@ __device__ __forceinline__ double dict_inner_solve(const double* mom, double (&D
         have_prev = true;
         if (step < inner_tol) break;
     }
-#ifdef SL_DEBUG_INNER
-    atomicAdd(&g_dbg_inner[0], 1ull); atomicAdd(&g_dbg_inner[1], (unsigned long long)dbg_its);
-    atomicAdd(&g_dbg_inner[2], (unsigned long long)(wall_clock64() - dbg_t0));
-#endif
     double delta = 0.0;
 #pragma unroll
     for (int j = 0; j < 2; ++j)

@@ -104,12 +104,8 @@ __device__ __forceinline__ void fused_lds_origin(const FusedShared<NT>& sh) {
     if (lds_address(&sh) != 0u) __builtin_trap();
 }
 
-// (SL_FINISH_INLINE: the finish steps inlined into the kernel again -- measured +3.7 %; kept as a build switch)
-#ifdef SL_FINISH_INLINE
-#define SL_FINISH_ATTR __forceinline__
-#else
+// (the finish steps inlined into the kernel again: measured +3.7 %)
 #define SL_FINISH_ATTR __noinline__
-#endif
 // wave-uniform values arrive in VGPRs at an out-of-line function: back to SGPRs
 template <class T>
 __device__ __forceinline__ T* uni_ptr(T* p) {
@@ -1178,29 +1174,9 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
         __syncthreads();
     };
 
-    // ---- sharing the CU.  Two workgroups live on a CU and the instruction arbiter serves the OLDER one's waves first: left alone,
-    // the first-launched workgroup of every CU runs its sweeps ~20 % faster than its partner, whose latency-bound finish steps
-    // stretch by half (measured: tile latency 1.50 vs 1.83 ms; the launch ends when the slow half does, with the CU
-    // half empty for the last 0.3 ms).  s_setprio overrides age: the finish steps (few instructions, long dependent
-    // latencies) always run at top priority, and the sweeps' priorities alternate between the two workgroups by sweep.
-    uint32_t lds_alloc_;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_LDS_ALLOC)" : "=s"(lds_alloc_));
-    const bool younger = (lds_alloc_ & 0xffu) != 0u;          // the workgroup that got the upper half of the CU's LDS was launched second
-#ifndef SL_PRIO_SCHEME
-#define SL_PRIO_SCHEME 0
-#endif
-    auto prio_finish = [&]() { if (SL_PRIO_SCHEME >= 1) __builtin_amdgcn_s_setprio(3); };
-    auto prio_sweep = [&](int which) {              // which: 0 moments, 1 select, 2 conc resweep / dictionary, 3 apply
-        if (SL_PRIO_SCHEME == 1) __builtin_amdgcn_s_setprio(0);
-        if (SL_PRIO_SCHEME == 2) {
-            if (younger) __builtin_amdgcn_s_setprio(1);
-            else if (which & 1) __builtin_amdgcn_s_setprio(2);
-            else __builtin_amdgcn_s_setprio(0);
-        }
-        if (SL_PRIO_SCHEME == 3) {
-            if (younger) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-        }
-    };
+    // (Two workgroups live on a CU and the instruction arbiter serves the OLDER one's waves first: the first-launched workgroup of every CU
+    //  runs its sweeps ~20 % faster than its partner and the launch ends when the slow half does.  s_setprio schemes -- finish steps on
+    //  top, sweeps alternating or by age -- were measured in rounds 1, 4 and 5 and changed nothing: the tail is bound by bytes)
     // Tiles: the first by position, the later rounds from the launch's counter -- a workgroup whose tiles were quick (empty, background)
     // takes more of them (a batch of 2 048 tiles 512^2, every fourth one white: 2.15 -> 1.88 ms); a tile's results do not depend on who
     // computes them.  The counter is asked before the apply sweep, whose length hides the answer's way back; sh.next_tile is read after
@@ -1211,11 +1187,7 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
     auto lane_id = []() { int t = (int)threadIdx.x; asm volatile("" : "+v"(t)); return t; };
     for (int tile = blockIdx.x; tile < a.n_tiles; tile = __builtin_amdgcn_readfirstlane(sh.next_tile)) {
         const size_t nbytes = (size_t)a.P * 3;
-#ifdef SL_DEBUG_SAMETILE
-        const uint8_t* src = a.rgb + (size_t)(tile & SL_DEBUG_SAMETILE) * nbytes;   // development aid: cache-resident input (0: one tile, 7: eight)
-#else
         const uint8_t* src = a.rgb + (size_t)tile * nbytes;
-#endif
         int fallbacks = 0;
         int sweeps_used = 0;
 #ifdef SL_DEVTOOLS
@@ -1244,15 +1216,11 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
             // ---------------- two-sweep schedule, phase 0: the cluster sample and everything the merged sweep needs (stats_twosweep.hpp)
             // Every workgroup of a launch starts at the same moment, and phase 0 streams nothing: its length is paid in full on a workgroup's
             // first tile (measured, interleaved: with the 290 us phase 0 of the first version the whole-batch route gained 0-6 % and a tile
-            // that DECLINED lost 10-13 %; letting only the workgroup launched second on its CU try -- SL_TS_WHO = younger -- gave -3 % / +1-3 %;
+            // that DECLINED lost 10-13 %; letting only the workgroup launched second on its CU try gave -3 % / +1-3 %;
             // with phase 0 at ~130 us every workgroup tries: -6.5 ... -7.4 % on tiles that take the route, +3 % on real tissue that leaves
             // after the eigen-solve, +7 % on the spatially smooth synthetic tiles that decline at its end).
-#ifndef SL_TS_WHO
-#define SL_TS_WHO true
-#endif
-            const bool ts_try = a.two_sweep >= 2 || (a.two_sweep == 1 && (SL_TS_WHO || tile != (int)blockIdx.x));   // block-uniform (both workgroup sizes: the 1024-thread kernel gains 5-8 % at 192-256 tiles)
+            const bool ts_try = a.two_sweep >= 2 || a.two_sweep == 1;   // block-uniform (both workgroup sizes: the 1024-thread kernel gains 5-8 % at 192-256 tiles)
             if (ts_try) {
-                prio_finish();
                 fused_phase0<NT>(&sh, src, samp, a.P, a.cl_lines, a.ylimf, a.pct, a.lam, a.two_sweep, a.cap_raw, a.cap_ang, a.cap_list,
 #ifdef SL_DEBUG_SUBCLK
                                  // (development: a third region of the clock buffer, only for the tool that allocates it: sl_debug_set_stop(-7))
@@ -1266,11 +1234,9 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
             const bool ts_on = sh.ts.ok != 0;                                 // block-uniform
             if (ts_try) { SL_PHASE(4); }      // (slot 4 is otherwise written on the resweep path only: the end of phase 0)
             // ---------------- sweep 1: moments (+ sample, or + the candidates of all four order statistics)
-            prio_sweep(0);
             if (ts_on) fused_sweep1c<NT, ALIGNED>(&sh, src, rawl, rawa, a.P, a.cap_raw, a.cap_ang, a.ylimf, stream ? 1 : 0);
             else fused_sweep1<NT, ALIGNED>(&sh, src, samp, a.P, a.ylimf, a.stride_log2, stream ? 1 : 0);   // (a declined tile: the stratified sample replaces the cluster sample)
             if (ts_on && lane_id() == 0) sh.ts.dense = 1;
-            prio_finish();
             __threadfence_block();
             __syncthreads();
             if (lane_id() < 10) {
@@ -1300,9 +1266,6 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
                     if (lane_id() == 0) {
                         sh.lo[0] = br[0]; sh.hi[0] = br[1]; sh.lo[1] = br[2]; sh.hi[1] = br[3];
                         if (!okv) { sh.ts.ok = 0; sh.ts.why = kTsPlane; }
-#ifdef SL_TS_DEBUG
-                        if (!okv) sh.ts.why = (int)sh.ts.lo0;
-#endif
                     }
                 }
                 __syncthreads();
@@ -1340,9 +1303,7 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
                                   , a.use_cube);
                 SL_PHASE(2);
                 // ---------------- sweep 2: angle select + concentration select under the box
-                prio_sweep(1);
                 run_select(true, src);
-                prio_finish();
                 SL_PHASE(3);
                 // ---------------- finish 2 (out of line: its registers are allocated apart from the sweeps'): exact angular percentiles
                 // -> M, then the concentration percentiles -> maxC from the same raw list
@@ -1357,7 +1318,6 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
             }
         } else {
             // ---------------- Vahadane: class-moment dictionary learning
-            prio_sweep(0);
             gather_sample<ALIGNED>(src, a.P, a.stride_log2, samp, a.n_sample, lane_id(), NT);
             if (lane_id() == 0) {
                 dict_iter_init(sh.it);
@@ -1384,7 +1344,6 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
         const bool resweep = !bad && !sh.conc_done;                             // block-uniform: sweep 3 of the four-sweep schedule
         if (resweep) {
             // ---------------- concentration brackets from the sample, sweep 3 (concentration select), finish 3 (exact 99th percentiles -> maxC)
-            prio_sweep(2);
             fallbacks += fused_conc_resweep<NT, ALIGNED>(&sh, src, samp, rawl, cand0, cand1, a.P, a.cap_raw, a.cap_list, a.ylimf, a.lam, stream ? 1 : 0,
                                                          (METHOD == kMethodMacenko && sh.ts.dense != 0) ? a.cl_lines * kClusterPx : a.n_sample,
                                                          (METHOD == kMethodMacenko && sh.ts.dense != 0) ? -1 : a.stride_log2,
@@ -1399,7 +1358,6 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
                                                          nullptr
 #endif
                                                          );
-            prio_finish();
         } else if (bad && sh.status != SL_TILE_ZERO_MAXC && lane_id() == 0) {     // (a zero maxC keeps its M and maxC, as after finish 3)
             for (int i = 0; i < 6; ++i) sh.M[i] = nan_d();
             sh.maxC[0] = sh.maxC[1] = nan_d();
@@ -1428,7 +1386,6 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
                         if (c + k * NT < nch) store_chunk<ALIGNED>(dst, nbytes, c + k * NT, ch[k]);
                 }
             } else {
-                prio_sweep(3);
                 fused_apply<NT, ALIGNED>(&sh, src, dst, a.P, a.M_tgt, a.maxC_tgt, a.lam, stream ? 1 : 0);
             }
         }

@@ -307,11 +307,7 @@ static __global__ __launch_bounds__(kDictFinishThreads) void k_dict_tail(StatsAr
     if (tid == 0) {
         st.fallbacks = 0;
         st.n_raw = 0; st.overflow = 0;
-#ifdef SL_EXP_DICT_DIAG      // development: sample iterations and rejected steps ride in the sweep count (x 100, x 10000)
-        if (a.sweeps_out) a.sweeps_out[a.tile0 + tile] = ds.pr.sweeps_used + 100 * ds.pr.sample_its + 10000 * ds.it.rejected;
-#else
         if (a.sweeps_out) a.sweeps_out[a.tile0 + tile] = ds.pr.sweeps_used;
-#endif
         s_status = st.status;
         if (st.status == SL_TILE_OK) { LassoK L; lasso_consts(st.M, a.lam, L); s_L = L; }
     }

@@ -254,14 +254,6 @@ __device__ __forceinline__ void select_sweep(const uint8_t* src, int P, int c0, 
                 lasso_interior(K.L, g.v[3 * px], g.v[3 * px + 1], g.v[3 * px + 2], a1, a2);
                 const bool g1 = a1 >= clo0, g2 = a2 >= clo1;
                 m = __builtin_amdgcn_ballot_w64(g1) | __builtin_amdgcn_ballot_w64(g2);
-#ifdef SL_DEBUG_EXTRA_MATH
-                {   // development aid: the same arithmetic once more (a VALU-bound sweep slows down in proportion)
-                    float b1, b2;
-                    lasso_interior(K.L, g.v[3 * px + 1], g.v[3 * px + 2], g.v[3 * px], b1, b2);
-                    const bool h1 = b1 >= 1e30f, h2 = b2 >= 1e30f;
-                    m |= __builtin_amdgcn_ballot_w64(h1) | __builtin_amdgcn_ballot_w64(h2);
-                }
-#endif
             }
             if (TAIL) {
                 const bool inb = (cc < c1) & (ALIGNED | ((size_t)cc * 4 + px < (size_t)P));

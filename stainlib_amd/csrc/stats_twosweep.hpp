@@ -465,15 +465,6 @@ __device__ __forceinline__ bool ts_verify(const TwoSweep& ts, const double* Vd, 
     if (!(br[0] < br[1])) br[0] = -INFINITY;
     if (!(br[3] > br[2])) br[3] = INFINITY;
     (void)lane;
-#ifdef SL_TS_DEBUG
-    if (!ok && lane == 0) {      // development: why the check failed, into ts.why through the caller (see k_fused)
-        int code = -1000 - (int)fmin(999.0, 100.0 * cmax / ts.kappa1);
-        if (!((rHx > 1e-3) & (rLx > 1e-3))) code = -5000;
-        else if (!(pH + 4.0 * (double)kAngleMargin < pL)) code = -6000;
-        else if (cmax <= ts.kappa1) code = -2000 - (int)fmin(999.0, 100.0 * cmax * dn / ts.kappa2);
-        const_cast<TwoSweep&>(ts).lo0 = (float)code;
-    }
-#endif
     return ok;
 }
 
