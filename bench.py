@@ -896,7 +896,8 @@ def main():
         # HBM traffic from PMC counters: collected in separate rocprofv3 --pmc passes (profiles/*_pmc_traffic.json
         # documents command, units and the gfx950 FETCH_SIZE correction), scaled to this launch's pixel count
         traffic_dom = traffic_ap = traffic_src = None
-        for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):
+        import glob
+        for name in sorted((os.path.basename(f) for f in glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_pmc_traffic.json"))), reverse=True):     # newest round first
             try:
                 pmc = json.load(open(os.path.join(REPO, "profiles", name)))["kernels"]
                 if fused:
@@ -1017,8 +1018,8 @@ def main():
                          "traffic_rate": ({"GBps": round(traffic_dom / (dom_ms * 1e-3) / 1e9, 1),
                                            "frac_of_peak": round(traffic_dom / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                            "note": "PMC bytes per launch (committed profile) over THIS run's launch time: what the memory system "
-                                                   "actually carries; the pure pattern of the schedule (three read streams + one write stream of 512 "
-                                                   "persistent workgroups, no arithmetic) reaches 0.73-0.75 of peak (profiles/r03_kbench_stream.txt)"}
+                                                   "actually carries; the pure streaming patterns (persistent workgroups, no arithmetic) reach 0.69 of peak for 4 reads + "
+                                                   "1 write, 0.63 for 1 read + 1 write, 0.76 read-only (profiles/r05_kbench_stream.txt)"}
                                           if traffic_dom else None)},
             "roofline_apply": {"kernel": "k_apply (OD + reconstruction pass, sl_normalize_apply)", "bound": "hbm",
                                "achieved": round(ap_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
