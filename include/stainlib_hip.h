@@ -159,7 +159,8 @@ typedef struct SlParams {
     int32_t two_sweep;          /* the two-read-sweep schedule of the fused Macenko kernel (the candidates of all four order statistics are
                                    collected in the moments sweep, under eigenvectors estimated from a cluster sample gathered before it, and
                                    the finish verifies the estimate against the exact eigenvectors; a tile that fails takes the three-sweep
-                                   route): 0 (default) = per tile, wherever the sample says it pays; 1 = never; 2 = wherever an estimate
+                                   route): 0 (default) = per tile, wherever the sample says it pays (a workgroup whose tile declined skips the attempt on its next
+                                   three tiles); 1 = never; 2 = wherever an estimate
                                    exists (tests); 3 = as 2 with the verification forced to fail, 4 = as 2 with the sample's plane tilted
                                    (tests of the fallback).  Results do not depend on it. */
     int32_t reserved1;

@@ -1185,6 +1185,7 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
     //  per-thread addresses before the tile loop and kept them in scratch across it -- 86 stores per lane, 0.56 KB, in a kernel whose
     //  scratch is written back to HBM once per tile)
     auto lane_id = []() { int t = (int)threadIdx.x; asm volatile("" : "+v"(t)); return t; };
+    int ts_backoff = 0;                 // tiles this workgroup still skips the two-sweep attempt on (automatic mode; uniform)
     for (int tile = blockIdx.x; tile < a.n_tiles; tile = __builtin_amdgcn_readfirstlane(sh.next_tile)) {
         const size_t nbytes = (size_t)a.P * 3;
         const uint8_t* src = a.rgb + (size_t)tile * nbytes;
@@ -1219,7 +1220,10 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
             // that DECLINED lost 10-13 %; letting only the workgroup launched second on its CU try gave -3 % / +1-3 %;
             // with phase 0 at ~130 us every workgroup tries: -6.5 ... -7.4 % on tiles that take the route, +3 % on real tissue that leaves
             // after the eigen-solve, +7 % on the spatially smooth synthetic tiles that decline at its end).
-            const bool ts_try = a.two_sweep >= 2 || a.two_sweep == 1;   // block-uniform (both workgroup sizes: the 1024-thread kernel gains 5-8 % at 192-256 tiles)
+            // Automatic mode backs off: a workgroup whose tile DECLINED the route in phase 0 (no estimate within the tilt limit, too many ambiguous
+            // cells, lists predicted to overflow) does not try on its next kTsBackoff tiles -- the tiles of a batch are mostly of a kind, and a
+            // declined attempt costs 50-160 us (real tissue, 2 048 tiles of 512^2: +9 % against three sweeps without the back-off).
+            const bool ts_try = a.two_sweep >= 2 || (a.two_sweep == 1 && ts_backoff == 0);   // block-uniform (both workgroup sizes: the 1024-thread kernel gains 5-8 % at 192-256 tiles)
             if (ts_try) {
                 fused_phase0<NT>(&sh, src, samp, a.P, a.cl_lines, a.ylimf, a.pct, a.lam, a.two_sweep, a.cap_raw, a.cap_ang, a.cap_list,
 #ifdef SL_DEBUG_SUBCLK
@@ -1232,6 +1236,7 @@ static __global__ __launch_bounds__(NT, 4) void k_fused(FusedArgs a) {
                 __syncthreads();
             }
             const bool ts_on = sh.ts.ok != 0;                                 // block-uniform
+            if (a.two_sweep == 1) ts_backoff = ts_try ? (ts_on ? 0 : kTsBackoff) : ts_backoff - 1;
             if (ts_try) { SL_PHASE(4); }      // (slot 4 is otherwise written on the resweep path only: the end of phase 0)
             // ---------------- sweep 1: moments (+ sample, or + the candidates of all four order statistics)
             if (ts_on) fused_sweep1c<NT, ALIGNED>(&sh, src, rawl, rawa, a.P, a.cap_raw, a.cap_ang, a.ylimf, stream ? 1 : 0);

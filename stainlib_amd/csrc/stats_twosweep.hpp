@@ -31,6 +31,7 @@ constexpr double kClusterDeff = 2.0;     // design effect assumed for the cluste
 constexpr double kTiltZ = 5.0;           // a-priori tilt bound tau = kTiltZ x the standard error a Gaussian cloud of the sample's size would give
 constexpr double kTiltZ4 = 4.0;          // ... and kTiltZ4 x the standard error the sample's own fourth moments give (whichever is larger)
 constexpr double kTsMinTau = 2e-4, kTsMaxTau = 0.05;
+constexpr int kTsBackoff = 3;            // automatic mode: tiles a workgroup does not try on after one of its tiles declined in phase 0 (k_fused)
 constexpr double kTsAutoMaxTau = 6e-3;   // automatic mode: a Gaussian tilt bound above this leaves phase 0 right after the eigen-solve (see fused_phase0)
 constexpr int kTsMinTissue = 256;        // tissue entries the sample must hold for an estimate
 constexpr int kTsMaxSharePct = 40;       // above this share of sample pixels in ambiguous cells the two-sweep schedule is declined (measured, interleaved: i.i.d. tiles at
