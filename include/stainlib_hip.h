@@ -109,7 +109,7 @@ typedef struct SlProfile {
 #define SL_RESWEEP_LIST_FULL 4      /* the candidate list overflowed */
 /* what became of a tile's two-sweep attempt (SlParams.twosweep_out) */
 #define SL_TWOSWEEP_DIRECT 1        /* the tile's stain matrix came out of two read sweeps (moments + candidates in one, then the apply pass) */
-#define SL_TWOSWEEP_OFF 0           /* not attempted (SlParams.two_sweep == 1, or a schedule without it) */
+#define SL_TWOSWEEP_OFF 0           /* not attempted (SlParams.two_sweep == 1, a schedule without it, or the workgroup was backing off after a decline) */
 #define SL_TWOSWEEP_NO_ESTIMATE (-1) /* the cluster sample gave no usable estimate (few tissue entries, an ill-defined plane, open brackets) */
 #define SL_TWOSWEEP_SHARE (-2)      /* too many of the sample's pixels in colour-cube cells the mask could not prove plain: not worth it */
 #define SL_TWOSWEEP_PLANE (-3)      /* the exact eigenvector plane left the tilt the sweep allowed for: three-sweep route from the exact moments */
