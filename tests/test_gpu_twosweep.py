@@ -141,3 +141,26 @@ def test_real_tissue_and_a_full_grid_in_the_automatic_mode():
     forced = _run(rgb, Mt, mct, 2)
     _same(ref, forced, "forced, full grid")
     assert (forced["ts"] == DIRECT).sum() >= n - 8
+
+
+def test_a_workgroup_backs_off_after_a_declined_attempt_and_results_do_not_change():
+    """Automatic mode on a batch of several rounds whose tiles decline the route in phase 0 (crops of the real-tissue fixture: its third
+    eigenvalue puts the tilt bound above the limit): a workgroup that saw a decline skips the attempt on its next tiles (kTsBackoff), so
+    twosweep_out holds both "no estimate" and "not attempted" -- and bytes, statistics and status equal the three-sweep run's."""
+    I = np.load(os.path.join(os.path.dirname(__file__), "golden", "tissue_ihc_512.npz"))["input"]
+    rng = np.random.RandomState(4242)
+    h, w = 160, 176
+    n = 1600                                   # more than three rounds of the 512 resident workgroups
+    tiles = []
+    for _ in range(n):
+        y, x = int(rng.randint(0, 512 - h)), int(rng.randint(0, 512 - w))
+        tiles.append(np.ascontiguousarray(I[y:y + h, x:x + w]))
+    dev = to_dev(tiles)
+    Mt, mct = oracle_fit_tile(so.synth_tile(128, 128, 1001, so.M_TRUE_TGT))
+    ref = _run(dev, Mt, mct, 1)
+    got = _run(dev, Mt, mct, 0)
+    _same(got, ref, "automatic mode with back-off")
+    codes = {int(k): int((got["ts"] == k).sum()) for k in np.unique(got["ts"])}
+    print("two-sweep attempts over", n, "tiles:", codes)
+    assert codes.get(OFF, 0) > 0 and any(k < 0 for k in codes), codes      # some declined, some were skipped after a decline
+    assert (ref["ts"] == OFF).all()
