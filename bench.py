@@ -433,7 +433,7 @@ def secondary_configs(dev, Mt, mct):
     sec["pooled_slide_512x1024"] = {
         "ms_per_slide": round(ms, 4), "tiles_per_s": round(512 / ms * 1e3, 1), "selection_paths": list(sn.last_path),
         "parity_8_tile_slide": {"M_max_abs_err": float(np.abs(Mp - Mo).max()), "maxC_max_rel_err": float(np.abs(cp / co - 1).max())},
-        "note": "device-driven since round 3 (sl_pool_*): 4 full sweeps + 6 over a pixel sample + 9 single-workgroup decision steps enqueued as one chain, the apply pass enqueued behind it, ONE read-back at the end (wall clock, not event time)"}
+        "note": "device-driven, ONE statistics sweep since round 6 (sl_pool2_*: a pixel sample's estimate, the moments sweep that also collects the raw candidates of all four order statistics, exact selection on the candidate list; falls back to the three-sweep chain of round 3 when a check of the estimate fails -- selection_paths says which ran), the apply pass enqueued behind it, ONE read-back at the end (wall clock, not event time)"}
     del rgb, out
 
     # ---- configs[4] at the size of ONE GPU's shard: 100 k tiles / 8 GPUs = 12 500 tiles (39 GB in, 39 GB out, resident in HBM);
@@ -457,8 +457,8 @@ def secondary_configs(dev, Mt, mct):
             "ms_per_shard": round(ms, 3), "tiles_per_s": round(n_big / ms * 1e3, 1), "selection_paths": list(sn.last_path),
             "bytes_resident": int(2 * rgb.numel()), "M_slide": [round(float(x), 6) for x in M_s.reshape(-1).tolist()],
             "M_slide_within_per_tile_range_of_64_tiles": inside,
-            "note": "one rank's share of a 100 k-tile slide: moments sweep, two window sweeps (angle, concentrations), apply; "
-                    "in the 8-GPU run each stage adds one tiny all-reduce (bench.py --slide-pooled)"}
+            "note": "one rank's share of a 100 k-tile slide: one statistics sweep (moments + candidates; selection_paths 'merged') and the "
+                    "apply sweep; in the 8-GPU run the chain adds eight to ten small all-reduces (bench.py --slide-pooled)"}
         del rgb, out
     return sec
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SL_VERSION 500 /* 0.5.0: SlParams starts with struct_size (checked by every entry point), two_sweep / twosweep_out; 0.4.0: prefilter, prefilter_out; 0.3.0: fused_min_tiles, sl_pool_*, resweeps_out carries reasons */
+#define SL_VERSION 600 /* 0.6.0: sl_pool2_* (the pooled slide statistics in one full sweep), two_sweep validated; 0.5.0: SlParams starts with struct_size (checked by every entry point), two_sweep / twosweep_out; 0.4.0: prefilter, prefilter_out; 0.3.0: fused_min_tiles, sl_pool_*, resweeps_out carries reasons */
 
 /* The library is built with -fvisibility=hidden: exactly the functions declared here are exported. */
 #if defined(__GNUC__)
@@ -373,6 +373,44 @@ SL_API int sl_pool_pick(double* state, int keyset, int round, const unsigned lon
 SL_API int sl_pool_window(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int keyset, const double* state,
                    unsigned long long* hist_below, void* stream);
 SL_API int sl_pool_resolve(double* state, int keyset, const unsigned long long* window_reduced, const SlParams* params, void* stream);
+
+/* ---- the pooled statistics in ONE full sweep (round 6; stainlib_amd/csrc/slide_merged.hip) ---------------------------------------
+ * The moments sweep also collects the raw candidates of all four order statistics, against an estimate of the eigenvectors, the angular
+ * brackets and the stain matrix taken from a stratified pixel sample of the whole slide (one 64-pixel sub-row in 2^sample_log2; the same
+ * sample_log2 on every rank); once the exact moments are all-reduced the estimate is CHECKED, and the exact order statistics of the
+ * binary32 keys are those of the candidates at shifted ranks.  Results never depend on the sample: when a check fails
+ * (state[SL_POOL_MISS] != 0 at the end) the caller takes the three-sweep chain above.  One computation is the chain
+ *     sl_pool2_sample                          -> all-reduce moments16 (16 doubles, SUM)  -> sl_pool2_begin
+ *     sl_pool2_hist(0, ANGLE, 0)               -> all-reduce hist (SL_POOL2_HIST_WORDS uint64)  -> sl_pool2_bands(ANGLE)
+ *     sl_pool2_hist(0, CONC, 0)                -> all-reduce                              -> sl_pool2_bands(CONC)
+ *     sl_pool2_sweep  (THE full sweep)         -> all-reduce totals16 (16 doubles)        -> sl_pool2_exact
+ *     for keyset in (ANGLE, CONC):  three times:  sl_pool2_hist(1, keyset, 1) -> all-reduce -> sl_pool2_step
+ *         (13 bits of the ordered binary32 key per level: two levels settle every bracket that does not straddle zero; a settled
+ *          key set turns the remaining passes and steps into no-ops)
+ * on one stream; state[SL_POOL_M / _MAXC / _STATUS / _MISS] as for sl_pool_*;
+ * state[SL_POOL2_WHY] != 0 says the sample gave no usable estimate (the sweep then returns at once and the chain ends in a miss).
+ * `workspace` (sl_pool2_workspace_bytes, 256-byte aligned) carries the sample list, the candidate list (up to 1/8 of the pixels) and
+ * the per-workgroup partial sums from sl_pool2_sample to the last sl_pool2_hist.  Every step consumes all-reduced data only: the ranks
+ * reach the same state without a broadcast.  Reference: macenko_stain_extractor.py:18-44, normalizer.py:36,45-47 on the concatenation. */
+#define SL_POOL2_STATE_DOUBLES 256
+#define SL_POOL2_TAIL_SLOTS 32
+#define SL_POOL2_GRID_BINS 8192
+/* a histogram buffer: 4 x SL_POOL2_TAIL_SLOTS tail words, then 2 x SL_POOL2_GRID_BINS bins; every pass WRITES it whole */
+#define SL_POOL2_HIST_WORDS (4 * SL_POOL2_TAIL_SLOTS + 2 * SL_POOL2_GRID_BINS)
+#define SL_POOL2_WHY 33
+SL_API size_t sl_pool2_workspace_bytes(int n, int h, int w, int sample_log2);
+SL_API int sl_pool2_sample(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int sample_log2, void* workspace,
+                    size_t workspace_bytes, double* moments16_out, void* stream);
+SL_API int sl_pool2_begin(const double* moments16_reduced, const SlParams* params, int sample_log2, double* state, void* stream);
+/* which: 0 the sample list (mode 0: a uniform grid), 1 the candidate list (mode 1: a window of SL_POOL2_GRID_BINS bins of 2^sh consecutive
+ * binary32 values, position and sh from `state`); hist (SL_POOL2_HIST_WORDS uint64) is written whole */
+SL_API int sl_pool2_hist(int which, int keyset, int mode, int n, int h, int w, const SlParams* params, int sample_log2, const double* state,
+                  void* workspace, size_t workspace_bytes, unsigned long long* hist, void* stream);
+SL_API int sl_pool2_bands(double* state, int keyset, const unsigned long long* hist_reduced, void* stream);
+SL_API int sl_pool2_sweep(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int sample_log2, const double* state,
+                   void* workspace, size_t workspace_bytes, double* totals16_out, void* stream);
+SL_API int sl_pool2_exact(const double* totals16_reduced, double* state, void* stream);
+SL_API int sl_pool2_step(double* state, int keyset, const unsigned long long* hist_reduced, void* stream);
 
 #ifdef __cplusplus
 }

@@ -112,8 +112,19 @@ _SIGNATURES = {
     "sl_pool_pick": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
     "sl_pool_window": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(SlParams), C.c_int, _P, _P, _P]),
     "sl_pool_resolve": (C.c_int, [_P, C.c_int, _P, C.POINTER(SlParams), _P]),
+    # the pooled statistics in one full sweep (state: SL_POOL2_STATE_DOUBLES doubles; workspace: sl_pool2_workspace_bytes)
+    "sl_pool2_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "sl_pool2_sample": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(SlParams), C.c_int, _P, C.c_size_t, _P, _P]),
+    "sl_pool2_begin": (C.c_int, [_P, C.POINTER(SlParams), C.c_int, _P, _P]),
+    "sl_pool2_hist": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(SlParams), C.c_int, _P, _P, C.c_size_t, _P, _P]),
+    "sl_pool2_bands": (C.c_int, [_P, C.c_int, _P, _P]),
+    "sl_pool2_sweep": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(SlParams), C.c_int, _P, _P, C.c_size_t, _P, _P]),
+    "sl_pool2_exact": (C.c_int, [_P, _P, _P]),
+    "sl_pool2_step": (C.c_int, [_P, C.c_int, _P, _P]),
 }
 POOL_STATE_DOUBLES, POOL_M, POOL_MAXC, POOL_STATUS, POOL_MISS = 64, 0, 6, 8, 9
+POOL2_STATE_DOUBLES, POOL2_HIST_WORDS, POOL2_WHY = 256, 2 * 8192 + 4 * 32, 33
+EXPECTED_VERSION = 600     # the SL_VERSION this binding (SlParams, signatures) was written for
 EXPORTS = tuple(_SIGNATURES)
 
 _lib = None
@@ -134,6 +145,9 @@ def lib() -> C.CDLL:
             fn = getattr(h, name)   # AttributeError here == a symbol the header declares is missing
             fn.restype = res
             fn.argtypes = args
+        if h.sl_version() != EXPECTED_VERSION:      # a stale .so would read SlParams at other offsets (round-5 advisor finding)
+            raise StainlibHipError(f"{LIB_PATH} is ABI {h.sl_version()}, this package binds ABI {EXPECTED_VERSION}: rebuild it "
+                                   "(make -C stainlib_amd/csrc)")
         _lib = h
     return _lib
 

@@ -211,7 +211,9 @@ class PooledSlideStatistics:
     def __init__(self, group=None, luminosity_threshold=0.8, angular_percentile=99.0, lasso_lambda=0.01):
         self.group = group
         self.thr, self.pct, self.lam = luminosity_threshold, angular_percentile, lasso_lambda
-        self.last_path = []          # per stage of the last call: "window" (one sweep) or "radix" (the fallback rounds)
+        self.last_path = []          # per stage of the last call: "merged" (the one-sweep chain), "window" (a sweep per stage) or "radix" (the fallback rounds)
+        self.last_miss = 0           # state[POOL_MISS] of the last device-driven chain read back
+        self.last_why = 0            # state[POOL2_WHY] of the last one-sweep chain (why the sample gave no estimate)
 
     def enqueue(self, tiles_local: torch.Tensor, ws=None, n_tiles_total: Optional[int] = None) -> torch.Tensor:
         """DEVICE-DRIVEN: enqueue the whole computation (4 full sweeps, 6 sampled passes, the all-reduces between them and the
@@ -264,6 +266,70 @@ class PooledSlideStatistics:
             engine.pool_resolve(state, keyset, wb, params=params)
         return state
 
+    MERGED_LEVELS = 3            # window levels enqueued per key set by the one-sweep chain (13 key bits each)
+
+    @staticmethod
+    def sample_log2_for(n_pixels: int) -> int:
+        """Density of the merged chain's pixel sample (one 64-pixel sub-row in 2**result): everything up to 4 Mpx, then the sample grows
+        like the slide's size to the power 2/3 -- the candidate lists shrink like 1/sqrt(sample) while the sample passes grow with it."""
+        import math
+        if n_pixels <= (1 << 22):
+            return 0
+        return int(min(12, max(0, math.floor((math.log2(n_pixels) - 11.0) / 3.0))))
+
+    def _agreed_pixels(self, tiles_local, n_tiles_total, world):
+        """The slide's pixel count as every rank computes it alike (see ``enqueue``)."""
+        n_local, h, w, _ = tiles_local.shape
+        if n_tiles_total is not None:
+            return int(n_tiles_total) * h * w
+        if _coll(world, self.group) and world > 1:
+            nl = torch.tensor([n_local], dtype=torch.int64, device=tiles_local.device if dist.get_backend(self.group) == "nccl" else "cpu")
+            dist.all_reduce(nl, op=dist.ReduceOp.MAX, group=self.group)
+            return world * int(nl.item()) * h * w
+        return world * n_local * h * w
+
+    def enqueue_merged(self, tiles_local: torch.Tensor, ws=None, n_tiles_total: Optional[int] = None) -> torch.Tensor:
+        """DEVICE-DRIVEN, ONE full sweep (round 6; csrc/slide_merged.hip): a stratified pixel sample of the whole slide gives an estimate
+        of the eigenvectors, the angular brackets and the stain matrix; the one sweep over the tiles computes the exact moment sums AND
+        appends every pixel that is not proven plain under that estimate to a candidate list; the exact order statistics are then those
+        of the candidates (four passes over the list).  Eight small all-reduces; returns the pool state (device float64,
+        _ffi.POOL2_STATE_DOUBLES) with the layout of ``enqueue``'s in its first ten entries.  state[POOL_MISS] != 0 at the end: a check
+        of the estimate failed (or a list overflowed) -- results never depend on the sample, the caller takes ``enqueue`` then.
+        n_tiles_total: as for ``enqueue`` (the same on every rank, or on none).  ws: None, or a dict the caller keeps between calls (the
+        chain's workspace -- sample list, candidate list of up to 1/8 of the pixels -- is then allocated once per shape)."""
+        from . import engine, _ffi
+        params = engine.make_params(luminosity_threshold=self.thr, angular_percentile=self.pct, lasso_lambda=self.lam)
+        _, world = _world(self.group)
+        n_local, h, w, _ = tiles_local.shape
+        dev = tiles_local.device
+        coll = _coll(world, self.group)
+        slog = self.sample_log2_for(self._agreed_pixels(tiles_local, n_tiles_total, world))
+        if ws is None or ws.get("key") != (n_local, h, w, slog, dev):
+            buf = engine.pool2_workspace(n_local, h, w, slog, dev)
+            if ws is not None:               # a caller's cache (a dict): the buffer is reused by its next call with this shape
+                ws.clear()
+                ws.update(key=(n_local, h, w, slog, dev), buf=buf)
+            ws = {"buf": buf}
+        ws = ws["buf"]
+        shape = (n_local, h, w)
+        hists = torch.empty((2 + 2 * self.MERGED_LEVELS, _ffi.POOL2_HIST_WORDS), dtype=torch.int64, device=dev)   # every pass writes its buffer whole
+
+        def reduced(t):
+            if coll:
+                dist.all_reduce(t, group=self.group)
+            return t
+        mom = reduced(engine.pool2_sample(tiles_local, slog, ws, params=params))
+        state = engine.pool2_begin(mom, slog, params=params)
+        for i, keyset in enumerate((_ffi.KEYSET_ANGLE, _ffi.KEYSET_CONC)):
+            engine.pool2_bands(state, keyset, reduced(engine.pool2_hist(0, keyset, 0, shape, slog, state, ws, hists[i], params=params)))
+        engine.pool2_exact(reduced(engine.pool2_sweep(tiles_local, slog, state, ws, params=params)), state)
+        for i, keyset in enumerate((_ffi.KEYSET_ANGLE, _ffi.KEYSET_CONC)):
+            for level in range(self.MERGED_LEVELS):      # (a settled key set turns its remaining passes and steps into no-ops)
+                h = hists[2 + self.MERGED_LEVELS * i + level]
+                engine.pool2_step(state, keyset, reduced(engine.pool2_hist(1, keyset, 1, shape, slog, state, ws, h, params=params)))
+        self._merged_ws = ws             # (kept until the next call: the chain's kernels are still queued when this returns)
+        return state
+
     def finish(self, state: torch.Tensor):
         """The one read-back of the device-driven path: (M, maxC) as numpy, or None when a window missed (the caller then runs the
         host-driven rounds).  Raises like the reference on an empty tissue mask."""
@@ -274,14 +340,23 @@ class PooledSlideStatistics:
         status, miss = int(s[_ffi.POOL_STATUS]), int(s[_ffi.POOL_MISS])
         if status == _ffi.TILE_EMPTY_MASK:
             raise TissueMaskException("Empty tissue mask computed")
+        self.last_miss = miss
+        if len(s) > _ffi.POOL2_WHY:
+            self.last_why = int(s[_ffi.POOL2_WHY])
         if status != 0 or miss != 0:
             return None
-        self.last_path = ["window", "window"]
+        self.last_path = ["merged", "merged"] if len(s) == _ffi.POOL2_STATE_DOUBLES else ["window", "window"]
         return s[_ffi.POOL_M:_ffi.POOL_M + 6].reshape(2, 3).copy(), s[_ffi.POOL_MAXC:_ffi.POOL_MAXC + 2].copy()
 
-    def __call__(self, tiles_local: torch.Tensor, device_driven: bool = True, n_tiles_total: Optional[int] = None):
-        """(M, maxC) of the slide.  n_tiles_total: see ``enqueue`` (the same on every rank, or on none)."""
+    def __call__(self, tiles_local: torch.Tensor, device_driven: bool = True, n_tiles_total: Optional[int] = None, merged: bool = True):
+        """(M, maxC) of the slide.  n_tiles_total: see ``enqueue`` (the same on every rank, or on none).  The one-sweep chain first
+        (``merged``), the three-sweep chain if one of its checks fails, the host-driven radix rounds if a window misses: the same
+        numbers whichever route settles them (up to the order of the moment sums)."""
         if device_driven:
+            if merged:
+                got = self.finish(self.enqueue_merged(tiles_local, n_tiles_total=n_tiles_total))
+                if got is not None:
+                    return got
             got = self.finish(self.enqueue(tiles_local, n_tiles_total=n_tiles_total))
             if got is not None:
                 return got
@@ -356,12 +431,14 @@ class SlideNormalizer:
     mode="median" (default): per-tile fits, all-gather, element-wise median.  mode="pooled": the exact statistics
     of the concatenated slide (Macenko only)."""
 
-    def __init__(self, normalizer, group=None, mode="median"):
+    def __init__(self, normalizer, group=None, mode="median", merged=True):
         if mode not in ("median", "pooled"):
             raise ValueError("mode must be 'median' or 'pooled'")
         self.normalizer = normalizer          # a fitted stainlib_amd ExtractiveStainNormalizer
         self.group = group
         self.mode = mode
+        self.merged = merged                  # pooled mode: the one-sweep chain first (PooledSlideStatistics.enqueue_merged)
+        self._pool2_ws = {}                   # its workspace, kept between calls
 
     def _targets(self, device):
         """The normalizer's 8 target doubles for the apply pass: its cached device tensors where it has them (uploaded once per fit; as
@@ -387,12 +464,16 @@ class SlideNormalizer:
             # leaves NaN in (M, maxC) and the enqueued apply pass COPIES the tiles through (k_apply's rule for unusable statistics):
             # `out` then holds the input, never exp(NaN) bytes, until the host-driven rounds below rewrite it -- or, on an empty
             # mask, when TissueMaskException leaves this function.
-            state = stats.enqueue(tiles_local, n_tiles_total=n_tiles_total)
-            M_s = state[_ffi.POOL_M:_ffi.POOL_M + 6].reshape(2, 3)
-            maxC_s = state[_ffi.POOL_MAXC:_ffi.POOL_MAXC + 2]
             Mt, mct = self._targets(dev)
-            out = engine.normalize_apply(tiles_local, M_s.expand(n, 2, 3).contiguous(), maxC_s.expand(n, 2).contiguous(), Mt, mct, out=out)
-            got = stats.finish(state)
+            got = None
+            for chain in ((stats.enqueue_merged, stats.enqueue) if self.merged else (stats.enqueue,)):
+                state = chain(tiles_local, n_tiles_total=n_tiles_total, ws=self._pool2_ws if chain == stats.enqueue_merged else None)
+                M_s = state[_ffi.POOL_M:_ffi.POOL_M + 6].reshape(2, 3)
+                maxC_s = state[_ffi.POOL_MAXC:_ffi.POOL_MAXC + 2]
+                out = engine.normalize_apply(tiles_local, M_s.expand(n, 2, 3).contiguous(), maxC_s.expand(n, 2).contiguous(), Mt, mct, out=out)
+                got = stats.finish(state)
+                if got is not None:
+                    break
             if got is None:
                 M_np, maxC_np = stats.host_driven(tiles_local)
                 M_s = torch.as_tensor(M_np, dtype=torch.float64, device=dev)
@@ -400,7 +481,8 @@ class SlideNormalizer:
                 out = engine.normalize_apply(tiles_local, M_s.expand(n, 2, 3).contiguous(), maxC_s.expand(n, 2).contiguous(), Mt, mct, out=out)
             else:
                 M_s, maxC_s = M_s.clone(), maxC_s.clone()
-            self.last_path = stats.last_path             # per stage: "window" (one sweep) or "radix" (fallback rounds)
+            self.last_path = stats.last_path             # per stage: "merged" (one sweep for both), "window" (one each) or "radix"
+            self.last_miss, self.last_why = stats.last_miss, stats.last_why
             return out, M_s, maxC_s, torch.zeros((n,), dtype=torch.int32, device=dev)
         M, maxC, status = self.normalizer.fit_batch_targets(tiles_local)
         M_all, maxC_all, st_all = gather_tile_stats(M, maxC, status, self.group)

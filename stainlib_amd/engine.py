@@ -478,6 +478,65 @@ def pool_resolve(state, keyset, window_reduced, params=None):
     _ffi.check(_ffi.lib().sl_pool_resolve(_ptr(state), int(keyset), _ptr(window_reduced), C.byref(p), _stream()), "sl_pool_resolve")
 
 
+# ---- the pooled statistics in ONE full sweep (sl_pool2_*): see include/stainlib_hip.h ------------------------------------------------
+def pool2_workspace(n, h, w, sample_log2, device) -> torch.Tensor:
+    need = int(_ffi.lib().sl_pool2_workspace_bytes(int(n), int(h), int(w), int(sample_log2)))
+    if need == 0:
+        raise ValueError("sl_pool2_workspace_bytes: bad arguments")
+    return torch.empty(need, dtype=torch.uint8, device=device)
+
+
+def pool2_sample(rgb, sample_log2, ws, params=None):
+    """S1: this process's sample (packed list in ws) and its moment sums -> (16,) float64 to be all-reduced."""
+    n, h, w = _check_tiles(rgb)
+    p = params if params is not None else _ffi.default_params()
+    out = torch.empty((16,), dtype=torch.float64, device=rgb.device)
+    _ffi.check(_ffi.lib().sl_pool2_sample(_ptr(rgb), n, h, w, C.byref(p), int(sample_log2), _ptr(ws), ws.numel(), _ptr(out), _stream()),
+               "sl_pool2_sample")
+    return out
+
+
+def pool2_begin(moments16, sample_log2, state=None, params=None):
+    p = params if params is not None else _ffi.default_params()
+    if state is None:
+        state = torch.empty((_ffi.POOL2_STATE_DOUBLES,), dtype=torch.float64, device=moments16.device)
+    _ffi.check(_ffi.lib().sl_pool2_begin(_ptr(moments16), C.byref(p), int(sample_log2), _ptr(state), _stream()), "sl_pool2_begin")
+    return state
+
+
+def pool2_hist(which, keyset, mode, shape, sample_log2, state, ws, hist, params=None):
+    """A pass over the sample list (which=0, mode=0: a uniform grid) or the candidate list (which=1, mode=1: a window) of ws: the
+    histogram of the key set under the constants in `state`, written into hist ((POOL2_HIST_WORDS,) int64)."""
+    n, h, w = shape
+    p = params if params is not None else _ffi.default_params()
+    _ffi.check(_ffi.lib().sl_pool2_hist(int(which), int(keyset), int(mode), int(n), int(h), int(w), C.byref(p), int(sample_log2), _ptr(state),
+                                        _ptr(ws), ws.numel(), _ptr(hist), _stream()), "sl_pool2_hist")
+    return hist
+
+
+def pool2_bands(state, keyset, hist_reduced):
+    _ffi.check(_ffi.lib().sl_pool2_bands(_ptr(state), int(keyset), _ptr(hist_reduced), _stream()), "sl_pool2_bands")
+
+
+def pool2_sweep(rgb, sample_log2, state, ws, params=None):
+    """THE full sweep: exact moment sums + the raw candidates (into ws) -> (16,) float64 to be all-reduced."""
+    n, h, w = _check_tiles(rgb)
+    p = params if params is not None else _ffi.default_params()
+    out = torch.empty((16,), dtype=torch.float64, device=rgb.device)
+    _ffi.check(_ffi.lib().sl_pool2_sweep(_ptr(rgb), n, h, w, C.byref(p), int(sample_log2), _ptr(state), _ptr(ws), ws.numel(), _ptr(out),
+                                         _stream()), "sl_pool2_sweep")
+    return out
+
+
+def pool2_exact(totals16, state):
+    _ffi.check(_ffi.lib().sl_pool2_exact(_ptr(totals16), _ptr(state), _stream()), "sl_pool2_exact")
+
+
+def pool2_step(state, keyset, hist_reduced):
+    """One level of the exact selection on the candidates (see sl_pool2_step)."""
+    _ffi.check(_ffi.lib().sl_pool2_step(_ptr(state), int(keyset), _ptr(hist_reduced), _stream()), "sl_pool2_step")
+
+
 def slide_key_next_above(rgb, keyset, basis, key_ords, params=None):
     """Per target: smallest key (ordered uint32, Python ints) above key_ords[t] among this process's pixels; 0xffffffff if none."""
     n, h, w = _check_tiles(rgb)

@@ -486,8 +486,8 @@ def _pooled_worker(rank, world, port, force_radix, q, big=False):
     lo, hi = sd.shard_range(len(tiles), rank, world)              # 6 tiles -> 3 + 3; rank 1 holds the white-background tile
     mine = torch.from_numpy(np.stack(tiles[lo:hi]))
     stats = sd.PooledSlideStatistics()
-    M, maxC = stats(mine)
-    out, M_s, mc_s, st = sd.SlideNormalizer(_FittedTarget(), mode="pooled").transform_shard(mine)
+    M, maxC = stats(mine, merged=False)                           # the three-sweep chain (the one-sweep chain: further down)
+    out, M_s, mc_s, st = sd.SlideNormalizer(_FittedTarget(), mode="pooled", merged=False).transform_shard(mine)
     q.put((rank, M, maxC, list(stats.last_path), out.numpy(), M_s.numpy(), mc_s.numpy()))
     if world > 1:
         dist.barrier()
@@ -607,3 +607,87 @@ def test_uneven_shards_agree_on_the_sample_density(pass_total):
     assert sorted(r[1] for r in res) == [3, 4]
     assert res[0][2] == res[1][2] and len(res[0][2]) == 6 and len(set(res[0][2])) == 1
     assert res[0][2][0] == (0 if pass_total else 1)          # 7 Mpx -> every row; agreed-on 2 x 4 Mpx -> every other row
+
+
+# ---- the ONE-SWEEP pooled chain (PooledSlideStatistics.enqueue_merged, sl_pool2_*) on two gloo ranks: the product orchestration with
+# the numpy stand-ins of tests/pool2_standins.py (see there for what they restate and what they replace by harness knowledge) ----------
+def _many_tiles():
+    """48 tiles of 384 x 256 (4.7 Mpx: the chain's sample is one pixel in two), two of them background"""
+    from oracle import stain_oracle as so
+    return [so.synth_tile(384, 256, 500 + s) for s in range(46)] + [np.full((384, 256, 3), 255, np.uint8)] * 2
+
+
+def _merged_worker(rank, world, port, q, break_it=False, tiles_fn="big"):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests import pool2_standins
+    _install_numpy_engine(False)
+    tiles = _slide_tiles(True) if tiles_fn == "big" else _many_tiles()
+    pool2_standins.install(tiles, break_it)
+    lo, hi = sd.shard_range(len(tiles), rank, world)
+    mine = torch.from_numpy(np.stack(tiles[lo:hi]))
+    stats = sd.PooledSlideStatistics()
+    direct = stats.finish(stats.enqueue_merged(mine, n_tiles_total=len(tiles)))
+    miss = stats.last_miss
+    M, maxC = stats(mine, n_tiles_total=len(tiles))
+    path = list(stats.last_path)
+    out, M_s, mc_s, st = sd.SlideNormalizer(_FittedTarget(), mode="pooled").transform_shard(mine, n_tiles_total=len(tiles))
+    q.put((rank, direct is not None, miss, M, maxC, path, out.numpy(), M_s.numpy(), mc_s.numpy()))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _run_merged(world, break_it=False, tiles_fn="big"):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_merged_worker, args=(r, world, port, q, break_it, tiles_fn)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=900) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize("tiles_fn", ["big", "many"])
+def test_one_sweep_pooled_chain_on_two_gloo_ranks(tiles_fn):
+    """PooledSlideStatistics.enqueue_merged / SlideNormalizer.transform_shard (the product orchestration) on two gloo ranks: the ranks
+    agree to the bit without a broadcast, match the single-rank run and the reference's statistics of the concatenated slide, and
+    the one-sweep chain settled both stages ("big": the sample is every pixel; "many": one pixel in two)."""
+    from oracle import stain_oracle as so
+    res, one = _run_merged(2, tiles_fn=tiles_fn), _run_merged(1, tiles_fn=tiles_fn)[0]
+    tiles = _slide_tiles(True) if tiles_fn == "big" else _many_tiles()
+    tall = np.concatenate(tiles, axis=0)
+    M_ref = so.macenko_stain_matrix(tall)
+    c_ref = np.percentile(so.get_concentrations(tall, M_ref), 99, axis=0)
+    for rank, direct, miss, M, maxC, path, out, M_s, mc_s in res:
+        assert direct and miss == 0 and path == ["merged", "merged"] and path == one[5]
+        assert np.array_equal(M, res[0][3]) and np.array_equal(maxC, res[0][4])         # the ranks agree to the bit
+        np.testing.assert_allclose(M, one[3], rtol=0, atol=1e-10)                       # = the single-rank run up to the order of the moment sums
+        np.testing.assert_allclose(maxC, one[4], rtol=1e-10)                            #   (numpy's pairwise sums over 4.7 M pixels: 1e-11)
+        np.testing.assert_allclose(M, M_ref, rtol=0, atol=2e-6)                         # = the reference on the concatenated image
+        np.testing.assert_allclose(maxC, c_ref, rtol=2e-6)
+        assert np.array_equal(M_s, M) and np.array_equal(mc_s, maxC)
+    both = np.concatenate([res[0][6], res[1][6]])
+    d = both.astype(np.int16) - one[6].astype(np.int16)
+    assert np.abs(d).max() <= 1 and (d != 0).sum() <= 2
+
+
+def test_one_sweep_pooled_chain_reports_a_miss_and_the_caller_falls_back_on_two_gloo_ranks():
+    """A candidate list that lacks pixels it should hold (the stand-in's sweep drops the end of the lower angular tail): the chain's
+    checks catch it on every rank alike (a miss, NaN statistics, never a wrong number) and __call__ / transform_shard settle the slide
+    with the three-sweep chain -- same numbers as the reference."""
+    from oracle import stain_oracle as so
+    res = _run_merged(2, break_it=True)
+    tall = np.concatenate(_slide_tiles(True), axis=0)
+    M_ref = so.macenko_stain_matrix(tall)
+    for rank, direct, miss, M, maxC, path, out, M_s, mc_s in res:
+        assert not direct and (miss & 1) and path == ["window", "window"]
+        assert np.array_equal(M, res[0][3]) and np.array_equal(maxC, res[0][4])
+        np.testing.assert_allclose(M, M_ref, rtol=0, atol=2e-6)
+        assert np.array_equal(M_s, M)

@@ -225,7 +225,7 @@ def test_pooled_slide_mode_matches_reference_on_concatenated_tiles():
     maxC_want = np.percentile(so.get_concentrations(tall, M_want), 99, axis=0)
     dev = to_dev(tiles)
     stats = PooledSlideStatistics()
-    M_got, maxC_got = stats(dev)
+    M_got, maxC_got = stats(dev, merged=False)                            # the three-sweep chain (the one-sweep chain: test_gpu_pool2.py)
     np.testing.assert_allclose(M_got, M_want, rtol=0, atol=5e-7)
     np.testing.assert_allclose(maxC_got, maxC_want, rtol=5e-7)
     assert stats.last_path == ["window", "window"]                        # one sweep per stage
@@ -248,7 +248,7 @@ def test_pooled_slide_mode_matches_reference_on_concatenated_tiles():
     from tools.synth import synth_tiles
     big = synth_tiles(40, 512, 512, seed=9)
     s3, s4 = PooledSlideStatistics(), PooledSlideStatistics()
-    M3, c3 = s3(big)
+    M3, c3 = s3(big, merged=False)
     sd.window_rank_pairs = lambda *a, **k: None
     try:
         M4, c4 = s4.host_driven(big)
@@ -271,7 +271,7 @@ def test_pooled_slide_mode_matches_reference_on_concatenated_tiles():
     M_ws = so.macenko_stain_matrix(tall_s)
     c_ws = np.percentile(so.get_concentrations(tall_s, M_ws), 99, axis=0)
     s5 = PooledSlideStatistics()
-    M5, c5 = s5(to_dev(struct))
+    M5, c5 = s5(to_dev(struct), merged=False)
     print("structured slide: selection paths", s5.last_path)
     np.testing.assert_allclose(M5, M_ws, rtol=0, atol=5e-7)
     np.testing.assert_allclose(c5, c_ws, rtol=5e-7)

@@ -1,0 +1,176 @@
+"""-m gpu: the pooled slide statistics in ONE full sweep (sl_pool2_*, csrc/slide_merged.hip; SURVEY 8e-2, BASELINE.json configs[4]).
+
+The statistics are those the reference computes from the vertical concatenation of all tiles (macenko_stain_extractor.py:18-44,
+normalizer.py:36,45-47).  The one-sweep chain estimates them from a pixel sample, collects candidates under that estimate in the
+moments sweep and selects the exact order statistics on the candidates; whatever the sample, the result must equal the three-sweep
+chain's (the same binary32 keys, the same moment sums) and the oracle's on the concatenated slide."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import stain_oracle as so
+from tests.gpu_util import to_dev, u8_parity
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _both_chains(dev, n_tiles_total=None):
+    from stainlib_amd.distributed import PooledSlideStatistics
+    st = PooledSlideStatistics(group=False)
+    new = st.finish(st.enqueue_merged(dev, n_tiles_total=n_tiles_total))
+    path_new, miss, why = list(st.last_path), st.last_miss, st.last_why
+    old = st.finish(st.enqueue(dev, n_tiles_total=n_tiles_total))
+    return new, old, path_new, miss, why
+
+
+def _ihc_tiles(n, h, w, seed=3):
+    ihc = np.load(os.path.join(GOLDEN, "tissue_ihc_512.npz"))["input"]
+    rng = np.random.RandomState(seed)
+    out = []
+    for _ in range(n):
+        y0, x0 = int(rng.randint(0, 512 - h + 1)), int(rng.randint(0, 512 - w + 1))
+        out.append(ihc[y0:y0 + h, x0:x0 + w].copy())
+    return out
+
+
+SLIDES = {
+    # name: (tiles, compare with the oracle on the concatenation)
+    "mixed_256": lambda: [so.synth_tile(256, 256, 40 + s) for s in range(6)] + [so.structured_tile("white_bg", 256, 256, 9),
+                                                                              so.structured_tile("blobs", 256, 256, 5)],
+    "ragged_unaligned_503x527": lambda: [so.synth_tile(503, 527, 60 + s) for s in range(5)],
+    "tissue_windows_384": lambda: _ihc_tiles(12, 384, 384),
+    "quantized_and_white": lambda: [so.structured_tile("quantized", 200, 300, 4 + s) for s in range(4)] + [np.full((200, 300, 3), 255, np.uint8)],
+}
+
+
+@pytest.mark.parametrize("name", sorted(SLIDES))
+def test_one_sweep_chain_selects_the_same_statistics_as_three_sweeps_and_the_reference(name):
+    tiles = SLIDES[name]()
+    dev = to_dev(tiles)
+    new, old, path, miss, why = _both_chains(dev)
+    assert old is not None
+    print(f"{name}: one-sweep chain path {path} miss {miss} why {why}")
+    assert new is not None, f"the one-sweep chain did not settle this slide (miss {miss}, why {why})"
+    assert path == ["merged", "merged"]
+    # the same keys and the same moment sums: the stain matrix differs at most in the last bits of the device's trigonometry
+    np.testing.assert_allclose(new[0], old[0], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(new[1], old[1], rtol=1e-13)
+    tall = np.concatenate(tiles, axis=0)
+    M_ref = so.macenko_stain_matrix(tall)
+    np.testing.assert_allclose(new[0], M_ref, rtol=0, atol=5e-7)
+    np.testing.assert_allclose(new[1], np.percentile(so.get_concentrations(tall, M_ref), 99, axis=0), rtol=5e-7)
+
+
+def test_one_sweep_chain_on_a_slide_whose_sample_is_a_sample():
+    """40 / 160 tiles of 512^2 (10 / 42 Mpx: one sub-row in 16 / 32): the estimate really comes from a fraction of the pixels; the
+    result is still the three-sweep chain's to the bit, run to run."""
+    from tools.synth import synth_tiles
+    for n in (40, 160):
+        big = synth_tiles(n, 512, 512, seed=9)
+        new, old, path, miss, why = _both_chains(big)
+        assert new is not None and old is not None and path == ["merged", "merged"], (n, path, miss, why)
+        assert np.array_equal(new[1], old[1])
+        np.testing.assert_allclose(new[0], old[0], rtol=0, atol=1e-13)
+        again, _, _, _, _ = _both_chains(big)
+        assert np.array_equal(again[0], new[0]) and np.array_equal(again[1], new[1])          # run-to-run identical
+    # rank-independent density: the caller's tile count decides it, not this process's share
+    from stainlib_amd.distributed import PooledSlideStatistics
+    assert PooledSlideStatistics.sample_log2_for(160 * 512 * 512) == PooledSlideStatistics.sample_log2_for(160 * 512 * 512 - 1) == 4
+    assert PooledSlideStatistics.sample_log2_for(1 << 22) == 0
+
+
+def test_one_sweep_chain_falls_back_when_its_estimate_does_not_hold(monkeypatch):
+    """The checks that make the result independent of the sample: (i) the sample's plane tilted behind the chain's back -> the plane
+    check fails; (ii) thresholds that prove nothing -> every pixel is a candidate and the list overflows; (iii) a slide without
+    tissue.  Every time the chain reports a miss (never a wrong number) and the caller's result comes from the three-sweep chain."""
+    from stainlib_amd import _ffi, engine
+    from stainlib_amd.distributed import PooledSlideStatistics, SlideNormalizer
+    from tools.synth import synth_tiles
+    import stainlib_amd as sl
+    big = synth_tiles(40, 512, 512, seed=9)
+    want = PooledSlideStatistics(group=False)(big, merged=False)
+    real_bands = engine.pool2_bands
+
+    def tilted(state, keyset, hist):
+        real_bands(state, keyset, hist)
+        if keyset == _ffi.KEYSET_ANGLE:                 # the half-space normals the sweep will use, off the sample's plane by 0.05
+            s = state.cpu().numpy()
+            nh = s[46:49]
+            for base in (64, 67):
+                g = s[base:base + 3] + 0.05 * nh
+                s[base:base + 3] = g
+                s[70 + (base - 64):73 + (base - 64)] = g.astype(np.float32)
+            state.copy_(torch.from_numpy(s).to(state.device))
+    monkeypatch.setattr(engine, "pool2_bands", tilted)
+    st = PooledSlideStatistics(group=False)
+    assert st.finish(st.enqueue_merged(big)) is None and (st.last_miss & 4)
+    got = st(big)
+    assert st.last_path == ["window", "window"]
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    n = sl.MacenkoNormalizer()
+    n.fit(so.synth_tile(128, 128, 1001, so.M_TRUE_TGT))
+    sn = SlideNormalizer(n, group=False, mode="pooled")
+    out, M_s, mc_s, _ = sn.transform_shard(big)
+    assert sn.last_path == ["window", "window"]
+    np.testing.assert_array_equal(M_s.cpu().numpy(), want[0])
+
+    def proves_nothing(state, keyset, hist):
+        real_bands(state, keyset, hist)
+        if keyset == _ffi.KEYSET_CONC:
+            state[70 + 22:70 + 24] = -1.0               # thresholds no concentration lies under
+    monkeypatch.setattr(engine, "pool2_bands", proves_nothing)
+    st = PooledSlideStatistics(group=False)
+    huge = synth_tiles(160, 512, 512, seed=9)            # 42 Mpx, all of them candidates: beyond the list's capacity (1/8 of the pixels + slack)
+    assert st.finish(st.enqueue_merged(huge)) is None and (st.last_miss & 8)
+    del huge
+    small = big[:16]                                     # 4 Mpx, all on the list (it may hold every pixel of a slide this size): no proof
+    got2, want2 = st.finish(st.enqueue_merged(small)), st.finish(st.enqueue(small))      # needed, no overflow -- and the same numbers
+    assert got2 is not None and st.last_path == ["window", "window"] and np.array_equal(got2[1], want2[1])
+    monkeypatch.setattr(engine, "pool2_bands", real_bands)
+    out2, M_2, mc_2, _ = sn.transform_shard(big)
+    assert sn.last_path == ["merged", "merged"]
+    assert torch.equal(out, out2)                        # the bytes do not depend on the route either
+    # no tissue at all: reported like the reference, by either chain
+    white = to_dev([np.full((64, 64, 3), 255, np.uint8)] * 3)
+    with pytest.raises(sl.TissueMaskException):
+        PooledSlideStatistics(group=False)(white)
+    with pytest.raises(sl.TissueMaskException):
+        sn.transform_shard(white)
+
+
+def test_one_sweep_chain_transform_bytes_against_the_reference_recipe():
+    import stainlib_amd as sl
+    from stainlib_amd.distributed import SlideNormalizer
+    tiles = [so.synth_tile(192, 160, 70 + s) for s in range(7)] + [np.full((192, 160, 3), 255, np.uint8)]
+    tall = np.concatenate(tiles, axis=0)
+    tgt = so.synth_tile(128, 128, 1001, so.M_TRUE_TGT)
+    n = sl.MacenkoNormalizer()
+    n.fit(tgt)
+    sn = SlideNormalizer(n, group=False, mode="pooled")
+    out, M_s, mc_s, status = sn.transform_shard(to_dev(tiles))
+    print("selection paths", sn.last_path)
+    on = so.ExtractiveStainNormalizer("macenko")
+    on.fit(tgt)
+    u8_parity(out.cpu().numpy().reshape(tall.shape), on.transform(tall))
+
+
+def test_pool2_entry_points_refuse_bad_arguments():
+    from stainlib_amd import _ffi, engine
+    lib = _ffi.lib()
+    assert lib.sl_pool2_workspace_bytes(0, 64, 64, 0) == 0 and lib.sl_pool2_workspace_bytes(4, 64, 64, 13) == 0
+    rgb = to_dev([so.synth_tile(64, 64, 1)] * 2)
+    ws = engine.pool2_workspace(2, 64, 64, 0, rgb.device)
+    with pytest.raises(_ffi.StainlibHipError):
+        engine.pool2_sample(rgb, 0, ws[: ws.numel() // 2])               # workspace too small
+    with pytest.raises(_ffi.StainlibHipError):
+        engine.pool2_sample(rgb, 13, ws)                                  # density out of range
+    mom = engine.pool2_sample(rgb, 0, ws)
+    state = engine.pool2_begin(mom, 0)
+    hist = torch.zeros((_ffi.POOL2_HIST_WORDS,), dtype=torch.int64, device="cuda")
+    with pytest.raises(_ffi.StainlibHipError):
+        engine.pool2_hist(0, 0, 1, (2, 64, 64), 0, state, ws, hist)      # the sample is histogrammed on a grid only
+    with pytest.raises(_ffi.StainlibHipError):
+        engine.pool2_hist(1, 2, 1, (2, 64, 64), 0, state, ws, hist)      # unknown key set
