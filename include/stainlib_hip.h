@@ -384,8 +384,9 @@ SL_API int sl_pool_resolve(double* state, int keyset, const unsigned long long* 
  *     sl_pool2_hist(0, ANGLE, 0)               -> all-reduce hist (SL_POOL2_HIST_WORDS uint64)  -> sl_pool2_bands(ANGLE)
  *     sl_pool2_hist(0, CONC, 0)                -> all-reduce                              -> sl_pool2_bands(CONC)
  *     sl_pool2_sweep  (THE full sweep)         -> all-reduce totals16 (16 doubles)        -> sl_pool2_exact
- *     for keyset in (ANGLE, CONC):  three times:  sl_pool2_hist(1, keyset, 1) -> all-reduce -> sl_pool2_step
- *         (13 bits of the ordered binary32 key per level: two levels settle every bracket that does not straddle zero; a settled
+ *     for keyset in (ANGLE, CONC):  SL_POOL2_LEVELS times:  sl_pool2_hist(1, keyset, 1) -> all-reduce -> sl_pool2_step
+ *         (11 bits of the ordered binary32 key per level: two levels settle a bracket of up to 2^22 values, the third every one that does not
+ *          straddle zero; a settled
  *          key set turns the remaining passes and steps into no-ops)
  * on one stream; state[SL_POOL_M / _MAXC / _STATUS / _MISS] as for sl_pool_*;
  * state[SL_POOL2_WHY] != 0 says the sample gave no usable estimate (the sweep then returns at once and the chain ends in a miss).
@@ -395,6 +396,7 @@ SL_API int sl_pool_resolve(double* state, int keyset, const unsigned long long* 
 #define SL_POOL2_STATE_DOUBLES 256
 #define SL_POOL2_TAIL_SLOTS 32
 #define SL_POOL2_GRID_BINS 8192
+#define SL_POOL2_WINDOW_BINS 2048 /* bins per target a window pass (mode 1) uses of the SL_POOL2_GRID_BINS */
 /* a histogram buffer: 4 x SL_POOL2_TAIL_SLOTS tail words, then 2 x SL_POOL2_GRID_BINS bins; every pass WRITES it whole */
 #define SL_POOL2_HIST_WORDS (4 * SL_POOL2_TAIL_SLOTS + 2 * SL_POOL2_GRID_BINS)
 #define SL_POOL2_WHY 33
@@ -411,6 +413,10 @@ SL_API int sl_pool2_sweep(const uint8_t* rgb, int n, int h, int w, const SlParam
                    void* workspace, size_t workspace_bytes, double* totals16_out, void* stream);
 SL_API int sl_pool2_exact(const double* totals16_reduced, double* state, void* stream);
 SL_API int sl_pool2_step(double* state, int keyset, const unsigned long long* hist_reduced, void* stream);
+/* the whole chain above on ONE process (no all-reduce between the steps), enqueued by one call; state as above */
+#define SL_POOL2_LEVELS 3
+SL_API int sl_pool2_local(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int sample_log2, void* workspace,
+                   size_t workspace_bytes, double* state, void* stream);
 
 #ifdef __cplusplus
 }

@@ -38,6 +38,8 @@ constexpr double kP2Z = 6.0;             // bracket half-width in standard devia
 constexpr uint32_t kBitTissue = 1u << 24, kBitValid = 1u << 25, kBitAng = 1u << 26, kBitConc = 1u << 27;
 constexpr int kP2TailSlots = SL_POOL2_TAIL_SLOTS;
 constexpr int kP2GridBins = SL_POOL2_GRID_BINS;
+constexpr int kP2WinBits = 11;
+constexpr int kP2WinBins = SL_POOL2_WINDOW_BINS;   // bins per target of a window pass (11 key bits per level: two levels settle a bracket of up to 2^22 values)
 constexpr int kTailWords = 4 * kP2TailSlots;
 constexpr double kQScale = 1048576.0;    // fixed-point scale of the fourth-moment sums riding in the uint64 histogram buffer
 
@@ -58,6 +60,7 @@ enum {
 };
 static_assert(kMk * 8 + sizeof(MergedConc) <= SL_POOL2_STATE_DOUBLES * 8, "");
 static_assert(kSw + 24 <= kNa, "");
+static_assert(kP2WinBins == (1 << kP2WinBits) && kP2WinBins % 1024 == 0 && kP2WinBins <= kP2GridBins, "");
 
 // why a route was declined (state[SL_POOL2_WHY]; 0 = not declined)
 enum { kWhyNoEstimate = 1, kWhyTilt = 2, kWhyBracket = 3, kWhyBox = 4, kWhyConc = 5 };
@@ -78,7 +81,7 @@ struct P2Layout {
     uint32_t c_priv;         // candidate list: blocks each wave of the sweep owns before it turns to the shared pool
     uint32_t s_cap, c_cap;
     int hist_wgs;            // workgroups of a grid-mode list pass (its partial histograms live in the workspace)
-    size_t hdr, partials, hpart, tpart, s_counts, s_entries, c_counts, c_entries, total;
+    size_t hdr, partials, hpart, tpart, local, s_counts, s_entries, c_counts, c_entries, total;
 };
 
 P2Layout p2_layout(int n, int h, int w, int slog) {
@@ -110,7 +113,8 @@ P2Layout p2_layout(int n, int h, int w, int slog) {
     L.hist_wgs = mg < 512 ? mg : 512;
     L.hpart = up(L.partials + sizeof(double) * 16 * (size_t)mg);
     L.tpart = up(L.hpart + 4 * (size_t)(2 * kP2GridBins) * L.hist_wgs);
-    L.s_counts = up(L.tpart + 8 * 4 * (size_t)L.hist_wgs);
+    L.local = up(L.tpart + 8 * 4 * (size_t)L.hist_wgs);               // sl_pool2_local: two 16-double vectors and one histogram buffer
+    L.s_counts = up(L.local + 256 + 8 * (size_t)SL_POOL2_HIST_WORDS);
     L.s_entries = up(L.s_counts + 4 * (size_t)L.s_cap);
     L.c_counts = up(L.s_entries + (4 * (size_t)L.s_cap << kP2SampleBlkLog2));
     L.c_entries = up(L.c_counts + 4 * (size_t)L.c_cap);
@@ -275,7 +279,11 @@ __global__ __launch_bounds__(kP2ListThreads) void k_p2_hist(P2HistArgs a) {
     s_tab.fill();
     const double* st = a.state;
     if (MODE == 1 && ((int)st[kDone] & (1 << KEYSET))) return;        // uniform: the key set is settled (k_p2_gsum skips alike)
-    for (int i = threadIdx.x; i < 2 * kP2GridBins; i += NT) s_h[i] = 0;
+    // bins in use per target: a grid or a window of single keys (sh = 0) fills all kP2GridBins, a coarser window kP2WinBins of them
+    uint32_t nbt[2];
+    for (int t = 0; t < 2; ++t) nbt[t] = (MODE == 0 || (int)st[kSh + t] == 0) ? (uint32_t)kP2GridBins : (uint32_t)kP2WinBins;
+    for (int t = 0; t < 2; ++t)
+        for (uint32_t i = threadIdx.x; i < nbt[t]; i += NT) s_h[t * kP2GridBins + i] = 0;
     if (threadIdx.x < 4) s_tail[threadIdx.x] = 0;
     __syncthreads();
     const TabView tab = view_of(s_tab);
@@ -331,7 +339,7 @@ __global__ __launch_bounds__(kP2ListThreads) void k_p2_hist(P2HistArgs a) {
             } else {
                 const uint32_t o = f2ord(k[t]);
                 if (o < wlo[t]) { if (t == 0) ++nb0; else ++nb1; }
-                else if (((o - wlo[t]) >> wsh[t]) < (uint32_t)kP2GridBins) atomicAdd(&s_h[t * kP2GridBins + ((o - wlo[t]) >> wsh[t])], 1u);
+                else if (((o - wlo[t]) >> wsh[t]) < nbt[t]) atomicAdd(&s_h[t * kP2GridBins + ((o - wlo[t]) >> wsh[t])], 1u);
             }
         }
     };
@@ -368,7 +376,8 @@ __global__ __launch_bounds__(kP2ListThreads) void k_p2_hist(P2HistArgs a) {
     if (lane == 0) { atomicAdd(&s_tail[0], nb0); atomicAdd(&s_tail[1], nb1); atomicAdd(&s_tail[2], w2); atomicAdd(&s_tail[3], w3); }
     __syncthreads();
     uint32_t* dst = a.part + (size_t)blockIdx.x * (2 * kP2GridBins);
-    for (int i = tid; i < 2 * kP2GridBins; i += NT) dst[i] = s_h[i];
+    for (int t = 0; t < 2; ++t)
+        for (uint32_t i = tid; i < nbt[t]; i += NT) dst[t * kP2GridBins + i] = s_h[t * kP2GridBins + i];
     if (tid < 4) a.tpart[(size_t)blockIdx.x * 4 + tid] = s_tail[tid];
 }
 
@@ -378,9 +387,16 @@ constexpr int kGsumSlices = 16;
 __global__ __launch_bounds__(256) void k_p2_gsum(const uint32_t* part, const unsigned long long* tpart, int nwg, unsigned long long* hist,
                                                 const double* st, int done_bit) {
     if (done_bit && ((int)st[kDone] & done_bit)) return;       // the pass did not run: hist stays zero
-    const int i = blockIdx.x * 256 + threadIdx.x;               // one bin per thread
+    const int i = blockIdx.x * 256 + threadIdx.x;               // one bin per thread: target i / kP2GridBins
     const int per = (nwg + kGsumSlices - 1) / kGsumSlices;
     const int g0 = blockIdx.y * per, g1 = min(nwg, g0 + per);
+    if (blockIdx.x == 0 && threadIdx.x < 4) {
+        unsigned long long v = 0;
+        for (int gg = g0; gg < g1; ++gg) v += tpart[(size_t)gg * 4 + threadIdx.x];
+        if (v) atomicAdd(&hist[4 * blockIdx.y + threadIdx.x], v);
+    }
+    // (block-uniform: 256 bins never straddle the bins a coarse window leaves unused)
+    if (done_bit && (int)st[kSh + i / kP2GridBins] != 0 && (i % kP2GridBins) >= kP2WinBins) return;
     unsigned long long t = 0;
     int g = g0;
     for (; g + 8 <= g1; g += 8) {
@@ -392,11 +408,6 @@ __global__ __launch_bounds__(256) void k_p2_gsum(const uint32_t* part, const uns
     }
     for (; g < g1; ++g) t += part[(size_t)g * (2 * kP2GridBins) + i];
     if (t) atomicAdd(&hist[kTailWords + i], t);
-    if (blockIdx.x == 0 && threadIdx.x < 4) {
-        unsigned long long v = 0;
-        for (int gg = g0; gg < g1; ++gg) v += tpart[(size_t)gg * 4 + threadIdx.x];
-        if (v) atomicAdd(&hist[4 * blockIdx.y + threadIdx.x], v);
-    }
 }
 
 static_assert(kGsumSlices <= kP2TailSlots, "");
@@ -853,14 +864,15 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_p2_sweep(P2SweepArgs a) {
 // ------------------------------------------------------------------------------------------
 // decision step after F: the exact eigenvectors and the plane check (ts_verify), ranks and grids of the angular stage
 // ------------------------------------------------------------------------------------------
-// the first window of a target: the keys from lo to hi in kP2GridBins bins of 2^sh consecutive binary32 values
+// the first window of a target: the keys from lo to hi in kP2WinBins bins of 2^sh consecutive binary32 values
 __device__ __forceinline__ void p2_set_window(double* st, int t, double lo, double hi) {
     const uint32_t olo = f2ord((float)lo);
     uint32_t ohi = f2ord((float)hi);
     if (ohi < olo) ohi = olo;
     const unsigned long long span = (unsigned long long)(ohi - olo) + 1ull;
-    int sh = 0;
-    while (((span + (1ull << sh) - 1ull) >> sh) > (unsigned long long)kP2GridBins) ++sh;
+    int sh = 0;                                                  // single keys when kP2GridBins of them span the bracket, else kP2WinBins coarse bins
+    if (span > (unsigned long long)kP2GridBins)
+        while (((span + (1ull << sh) - 1ull) >> sh) > (unsigned long long)kP2WinBins) ++sh;
     st[kWinLo + t] = (double)olo;
     st[kSh + t] = (double)sh;
 }
@@ -868,9 +880,11 @@ __device__ __forceinline__ void p2_set_window(double* st, int t, double lo, doub
 __global__ void k_p2_exact(const double* tot, double* st) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const double pct = st[kPct];
-    double Vd[6];
-    float Vf[6];
-    const int status = eigvecs_from_moments(tot, Vd, Vf);
+    double Vd[6] = {0, 0, 0, 0, 0, 0};
+    float Vf[6] = {0, 0, 0, 0, 0, 0};
+    // (a declined route swept nothing: its totals are zeros and say nothing about the slide -- a miss, not "no tissue")
+    const bool declined = (int)st[kWhy] != 0;
+    const int status = declined ? (int)SL_TILE_OK : eigvecs_from_moments(tot, Vd, Vf);
     st[kStatus] = (double)status;
     st[kT] = tot[0]; st[kNpx] = tot[12];
     st[kOvf] = tot[13];
@@ -962,7 +976,8 @@ __global__ __launch_bounds__(1024) void k_p2_step(double* st, const unsigned lon
     bool exact = true;
     for (int t = 0; t < 2; ++t) {
         const unsigned long long* h = hist + kTailWords + kP2GridBins * t;
-        p2_scan_build(S, h, kP2GridBins, tid);
+        const int nb = (int)st[kSh + t] == 0 ? kP2GridBins : kP2WinBins;        // bins of this target's window
+        p2_scan_build(S, h, nb, tid);
         const unsigned long long below = p2_tail(hist, t);
         const double kd = st[kK + t];
         const long long kg = (long long)(kd < 0 ? 0 : (kd > N - 1.0 ? N - 1.0 : kd));
@@ -970,18 +985,18 @@ __global__ __launch_bounds__(1024) void k_p2_step(double* st, const unsigned lon
         const uint32_t lo = (uint32_t)st[kWinLo + t];
         const int sh = (int)st[kSh + t];
         const long long kc = kg - (long long)sub[t];
-        const long long bin = N >= 1.0 && kc >= 0 ? p2_scan_locate(S, h, kP2GridBins, kc, below, tid) : -1;
-        if (bin < 0 || bin >= kP2GridBins) { if (tid == 0) s_miss = 1; continue; }          // uniform
+        const long long bin = N >= 1.0 && kc >= 0 ? p2_scan_locate(S, h, nb, kc, below, tid) : -1;
+        if (bin < 0 || bin >= nb) { if (tid == 0) s_miss = 1; continue; }          // uniform
         if (sh == 0) {
-            const long long bin1 = p2_scan_locate(S, h, kP2GridBins, kg1 - (long long)sub[t], below, tid);
+            const long long bin1 = p2_scan_locate(S, h, nb, kg1 - (long long)sub[t], below, tid);
             if (tid == 0) {
-                if (bin1 < 0 || bin1 >= kP2GridBins) s_miss = 1;
+                if (bin1 < 0 || bin1 >= nb) s_miss = 1;
                 else { s_res[2 * t] = ord2f(lo + (uint32_t)bin); s_res[2 * t + 1] = ord2f(lo + (uint32_t)bin1); }
                 s_nwlo[t] = (double)lo; s_nsh[t] = 0;
             }
         } else {
             exact = false;
-            if (tid == 0) { s_nwlo[t] = (double)lo + (double)((unsigned long long)bin << sh); s_nsh[t] = sh > 13 ? sh - 13 : 0; }
+            if (tid == 0) { s_nwlo[t] = (double)lo + (double)((unsigned long long)bin << sh); s_nsh[t] = sh > kP2WinBits ? sh - kP2WinBits : 0; }
         }
     }
     __syncthreads();
@@ -1196,4 +1211,33 @@ extern "C" int sl_pool2_step(double* state, int keyset, const unsigned long long
     if (!state || !hist_reduced || (keyset != SL_KEYSET_ANGLE && keyset != SL_KEYSET_CONC)) return SL_ERR_BADARG;
     hipLaunchKernelGGL(k_p2_step, dim3(1), dim3(1024), 0, (hipStream_t)stream, state, hist_reduced, keyset);
     return launch_status();
+}
+
+// The whole chain on ONE process (no collective between the steps): the ~45 launches enqueued by one call -- issued from Python one by one
+// they take the host longer than a 512-tile slide takes the device.
+extern "C" int sl_pool2_local(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int sample_log2, void* workspace,
+                              size_t workspace_bytes, double* state, void* stream) {
+    SlParams p;
+    P2Layout L;
+    int rc = p2_check(rgb, n, h, w, params, sample_log2, workspace, workspace_bytes, p, L);
+    if (rc) return rc;
+    if (!state) return SL_ERR_BADARG;
+    uint8_t* ws = (uint8_t*)workspace;
+    double* mom = (double*)(ws + L.local);
+    double* tot = mom + 16;
+    unsigned long long* hist = (unsigned long long*)(ws + L.local + 256);
+    if ((rc = sl_pool2_sample(rgb, n, h, w, params, sample_log2, workspace, workspace_bytes, mom, stream))) return rc;
+    if ((rc = sl_pool2_begin(mom, params, sample_log2, state, stream))) return rc;
+    for (int keyset = 0; keyset < 2; ++keyset) {
+        if ((rc = sl_pool2_hist(0, keyset, 0, n, h, w, params, sample_log2, state, workspace, workspace_bytes, hist, stream))) return rc;
+        if ((rc = sl_pool2_bands(state, keyset, hist, stream))) return rc;
+    }
+    if ((rc = sl_pool2_sweep(rgb, n, h, w, params, sample_log2, state, workspace, workspace_bytes, tot, stream))) return rc;
+    if ((rc = sl_pool2_exact(tot, state, stream))) return rc;
+    for (int keyset = 0; keyset < 2; ++keyset)
+        for (int level = 0; level < SL_POOL2_LEVELS; ++level) {
+            if ((rc = sl_pool2_hist(1, keyset, 1, n, h, w, params, sample_log2, state, workspace, workspace_bytes, hist, stream))) return rc;
+            if ((rc = sl_pool2_step(state, keyset, hist, stream))) return rc;
+        }
+    return SL_OK;
 }

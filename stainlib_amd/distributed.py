@@ -266,7 +266,8 @@ class PooledSlideStatistics:
             engine.pool_resolve(state, keyset, wb, params=params)
         return state
 
-    MERGED_LEVELS = 3            # window levels enqueued per key set by the one-sweep chain (13 key bits each)
+    MERGED_LEVELS = 3            # window levels enqueued per key set by the one-sweep chain (11 key bits each; SL_POOL2_LEVELS)
+    one_call = True              # on one process the chain is enqueued by sl_pool2_local (False: step by step, as on several ranks)
 
     @staticmethod
     def sample_log2_for(n_pixels: int) -> int:
@@ -311,6 +312,9 @@ class PooledSlideStatistics:
                 ws.update(key=(n_local, h, w, slog, dev), buf=buf)
             ws = {"buf": buf}
         ws = ws["buf"]
+        if not coll and self.one_call:       # one process: the chain enqueued by ONE call into the library (the same kernels in the same order)
+            self._merged_ws = ws
+            return engine.pool2_local(tiles_local, slog, ws, params=params)
         shape = (n_local, h, w)
         hists = torch.empty((2 + 2 * self.MERGED_LEVELS, _ffi.POOL2_HIST_WORDS), dtype=torch.int64, device=dev)   # every pass writes its buffer whole
 
@@ -467,10 +471,13 @@ class SlideNormalizer:
             Mt, mct = self._targets(dev)
             got = None
             for chain in ((stats.enqueue_merged, stats.enqueue) if self.merged else (stats.enqueue,)):
-                state = chain(tiles_local, n_tiles_total=n_tiles_total, ws=self._pool2_ws if chain == stats.enqueue_merged else None)
-                M_s = state[_ffi.POOL_M:_ffi.POOL_M + 6].reshape(2, 3)
-                maxC_s = state[_ffi.POOL_MAXC:_ffi.POOL_MAXC + 2]
-                out = engine.normalize_apply(tiles_local, M_s.expand(n, 2, 3).contiguous(), maxC_s.expand(n, 2).contiguous(), Mt, mct, out=out)
+                def run(chain=chain):
+                    st_ = chain(tiles_local, n_tiles_total=n_tiles_total, ws=self._pool2_ws if chain == stats.enqueue_merged else None)
+                    M_ = st_[_ffi.POOL_M:_ffi.POOL_M + 6].reshape(2, 3)
+                    mc_ = st_[_ffi.POOL_MAXC:_ffi.POOL_MAXC + 2]
+                    o_ = engine.normalize_apply(tiles_local, M_.expand(n, 2, 3).contiguous(), mc_.expand(n, 2).contiguous(), Mt, mct, out=out)
+                    return st_, M_, mc_, o_
+                state, M_s, maxC_s, out = run()
                 got = stats.finish(state)
                 if got is not None:
                     break

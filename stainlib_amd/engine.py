@@ -532,6 +532,17 @@ def pool2_exact(totals16, state):
     _ffi.check(_ffi.lib().sl_pool2_exact(_ptr(totals16), _ptr(state), _stream()), "sl_pool2_exact")
 
 
+def pool2_local(rgb, sample_log2, ws, state=None, params=None):
+    """The whole one-sweep chain on ONE process, enqueued by one call (sl_pool2_local).  Returns the state tensor."""
+    n, h, w = _check_tiles(rgb)
+    p = params if params is not None else _ffi.default_params()
+    if state is None:
+        state = torch.empty((_ffi.POOL2_STATE_DOUBLES,), dtype=torch.float64, device=rgb.device)
+    _ffi.check(_ffi.lib().sl_pool2_local(_ptr(rgb), n, h, w, C.byref(p), int(sample_log2), _ptr(ws), ws.numel(), _ptr(state), _stream()),
+               "sl_pool2_local")
+    return state
+
+
 def pool2_step(state, keyset, hist_reduced):
     """One level of the exact selection on the candidates (see sl_pool2_step)."""
     _ffi.check(_ffi.lib().sl_pool2_step(_ptr(state), int(keyset), _ptr(hist_reduced), _stream()), "sl_pool2_step")

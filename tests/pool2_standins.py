@@ -16,7 +16,7 @@ import torch
 
 from stainlib_amd import distributed as sd
 
-NB, TW = 8192, 128
+NB, TW, WB, WBITS = 8192, 128, 2048, 11           # grid bins, tail words, window bins (of the NB a target owns), key bits per level
 K_T, K_NPX, K_VD, K_VF, K_K, K_G, K_TS, K_NS, K_SLOG, K_BRK, K_BR, K_WLO, K_RES, K_SH, K_DONE, K_LEVEL = \
     10, 11, 12, 18, 24, 26, 30, 31, 32, 60, 100, 108, 110, 114, 120, 121
 K_VH, K_MH, K_L = 34, 140, 150                         # (K_MH, K_L: private to the stand-ins -- the sample's stain matrix, the thresholds)
@@ -140,7 +140,7 @@ def install(all_tiles, break_it=False):
         for t in range(2):
             o, wlo, sh = f2ord(ks[t]).astype(np.int64), int(state[K_WLO + t]), int(state[K_SH + t])
             b = (o - wlo) >> sh
-            rows.append(np.bincount(b[(o >= wlo) & (b < NB)], minlength=NB))
+            rows.append(np.bincount(b[(o >= wlo) & (b < (NB if sh == 0 else WB))], minlength=NB))    # single keys: NB of them; coarse bins: WB
             below.append(int((o < wlo).sum()))
         return put(hist, rows, below, int(sel.sum()))
 
@@ -204,7 +204,7 @@ def install(all_tiles, break_it=False):
     def set_window(state, t, lo, hi):
         olo, ohi = int(f2ord(np.float32(lo))), int(f2ord(np.float32(hi)))
         span, sh = max(ohi, olo) - olo + 1, 0
-        while ((span + (1 << sh) - 1) >> sh) > NB:
+        while span > NB and ((span + (1 << sh) - 1) >> sh) > WB:
             sh += 1
         state[K_WLO + t], state[K_SH + t] = float(olo), float(sh)
 
@@ -250,7 +250,7 @@ def install(all_tiles, break_it=False):
             k1 = min(k + 1, N - 1)
             wlo, sh = int(state[K_WLO + t]), int(state[K_SH + t])
             b, b1 = rank_bins(h[TW + NB * t:TW + NB * (t + 1)], int(h[t]), [k - sub[t], k1 - sub[t]])
-            if b < 0 or b >= NB or k - sub[t] < 0:
+            if b < 0 or b >= (NB if sh == 0 else WB) or k - sub[t] < 0:
                 bad = True
                 new.append((wlo, sh))
                 continue
@@ -261,7 +261,7 @@ def install(all_tiles, break_it=False):
                 new.append((wlo, 0))
             else:
                 exact = False
-                new.append((wlo + (b << sh), max(sh - 13, 0)))
+                new.append((wlo + (b << sh), max(sh - WBITS, 0)))
         miss, level = int(state[_ffi.POOL_MISS]), int(state[K_LEVEL])
         if bad or (not exact and level >= 2):
             state[_ffi.POOL_MISS], state[K_DONE] = float(miss | bit), 3.0

@@ -21,6 +21,10 @@ def _both_chains(dev, n_tiles_total=None):
     from stainlib_amd.distributed import PooledSlideStatistics
     st = PooledSlideStatistics(group=False)
     new = st.finish(st.enqueue_merged(dev, n_tiles_total=n_tiles_total))
+    st.one_call = False                                  # the same chain step by step (how several ranks run it): the same state
+    new2 = st.finish(st.enqueue_merged(dev, n_tiles_total=n_tiles_total))
+    assert (new is None) == (new2 is None) and (new is None or (np.array_equal(new[0], new2[0]) and np.array_equal(new[1], new2[1])))
+    st.one_call = True
     path_new, miss, why = list(st.last_path), st.last_miss, st.last_why
     old = st.finish(st.enqueue(dev, n_tiles_total=n_tiles_total))
     return new, old, path_new, miss, why
@@ -93,6 +97,7 @@ def test_one_sweep_chain_falls_back_when_its_estimate_does_not_hold(monkeypatch)
     big = synth_tiles(40, 512, 512, seed=9)
     want = PooledSlideStatistics(group=False)(big, merged=False)
     real_bands = engine.pool2_bands
+    monkeypatch.setattr(PooledSlideStatistics, "one_call", False)      # step by step, so that a step can be tampered with from here
 
     def tilted(state, keyset, hist):
         real_bands(state, keyset, hist)

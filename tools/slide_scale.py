@@ -60,6 +60,35 @@ for n in sizes:
           f"one sampled pass {t_sa:.2f}  apply {t_ap:.2f}", flush=True)
     print(f"pooled slide of {n:6d} tiles: {ms:9.2f} ms -> {n / ms:8.1f} k tiles/s   statistics {ms_stats:8.2f} ms (moments sweep {ms_mom:7.2f}) "
           f"apply {ms - ms_stats:8.2f} ms   paths {sn.last_path}", flush=True)
+    # the same slide through the three-sweep chain of rounds 3-5 (the fallback), and the steps of the one-sweep chain (event ms)
+    sn3 = SlideNormalizer(nrm, group=False, mode="pooled", merged=False)
+    sn3.transform_shard(rgb, out=out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        sn3.transform_shard(rgb, out=out)
+    torch.cuda.synchronize()
+    ms3 = (time.perf_counter() - t0) / reps * 1e3
+    print(f"      three-sweep chain (merged=False): {ms3:9.2f} ms -> {n / ms3:8.1f} k tiles/s   paths {sn3.last_path}", flush=True)
+    pst = PooledSlideStatistics(group=False)
+    s_new = pst.enqueue_merged(rgb)
+    slog = int(s_new[32].item())
+    ws2 = engine.pool2_workspace(n, 1024, 1024, slog, rgb.device)
+    hist = torch.zeros((_ffi.POOL2_HIST_WORDS,), dtype=torch.int64, device="cuda")
+    shape = (n, 1024, 1024)
+    prm = engine.make_params()
+    s_tmp = s_new.clone()
+    s_tmp[120] = 0.0
+    t_s1 = ev(lambda: engine.pool2_sample(rgb, slog, ws2, params=prm))
+    t_h = [ev(lambda k=k: engine.pool2_hist(0, k, 0, shape, slog, s_new, ws2, hist, params=prm)) for k in (0, 1)]
+    t_sw = ev(lambda: engine.pool2_sweep(rgb, slog, s_new, ws2, params=prm))
+    t_c = [ev(lambda k=k: engine.pool2_hist(1, k, 1, shape, slog, s_tmp, ws2, hist, params=prm)) for k in (0, 1)]
+    t_chain = ev(lambda: pst.enqueue_merged(rgb))
+    sv = s_new.cpu().numpy()
+    print(f"      one-sweep chain (event ms): whole {t_chain:.3f} = sample {t_s1:.3f} + sample histograms {t_h[0]:.3f} {t_h[1]:.3f} + SWEEP {t_sw:.3f} + "
+          f"candidate passes {t_c[0]:.3f} {t_c[1]:.3f} per level (two levels each) + decision steps;  sample 1 in {1 << slog} sub-rows, listed "
+          f"{100 * sv[96] / max(sv[10], 1):.2f} % of the tissue (angle) {100 * sv[97] / (n * 1048576):.2f} % of the pixels (concentrations), workspace {ws2.numel() / 2**20:.0f} MiB", flush=True)
+    del ws2
     # per-tile mode on the same tiles, for comparison (chunks of 512 through the fused kernel)
     if n >= 512:
         ws = engine.Workspace()
