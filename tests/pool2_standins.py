@@ -294,5 +294,6 @@ def install(all_tiles, break_it=False):
             if miss or int(state[_ffi.POOL_STATUS]):
                 poison(state)
 
+    sd.PooledSlideStatistics.one_call = False          # step by step also on one rank (sl_pool2_local is the device's)
     engine.pool2_workspace, engine.pool2_sample, engine.pool2_begin, engine.pool2_hist = pool2_workspace, pool2_sample, pool2_begin, pool2_hist
     engine.pool2_bands, engine.pool2_sweep, engine.pool2_exact, engine.pool2_step = pool2_bands, pool2_sweep, pool2_exact, pool2_step
