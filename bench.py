@@ -695,13 +695,40 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax[0])
         ranks = placement(a.tiles * a.steps / t_mine)
+        pooled = None
+        if a.slide_pooled:
+            # configs[4] without a GPU: the product's one-sweep pooled chain (PooledSlideStatistics.enqueue_merged: its collective sequence,
+            # the rank-independent sample density, agreement without a broadcast) on this many ranks, the device steps replaced by the numpy
+            # stand-ins of tests/pool2_standins.py; and the shard arithmetic of the real slide (100 000 tiles over the ranks)
+            import numpy as np
+            from oracle import stain_oracle as so
+            from stainlib_amd import distributed as sd
+            from tests import pool2_standins
+            spans = [sd.shard_range(100000, r, world) for r in range(world)]
+            tiles = [so.synth_tile(96, 128, 700 + s) for s in range(46)] + [np.full((96, 128, 3), 255, np.uint8)] * 2
+            pool2_standins.install(tiles)
+            lo, hi = sd.shard_range(len(tiles), rank, world)
+            stats = sd.PooledSlideStatistics()
+            got = stats.finish(stats.enqueue_merged(torch.from_numpy(np.stack(tiles[lo:hi])), n_tiles_total=len(tiles)))
+            vec = torch.tensor(([1.0] + list(got[0].reshape(-1)) + list(got[1])) if got is not None else [0.0] * 9, dtype=torch.float64)
+            same = True
+            if dist_on:
+                vlo, vhi = vec.clone(), vec.clone()
+                dist.all_reduce(vlo, op=dist.ReduceOp.MIN)
+                dist.all_reduce(vhi, op=dist.ReduceOp.MAX)
+                same = bool(torch.equal(vlo, vhi))
+            pooled = {"tiles": len(tiles), "local_tiles_of_rank0": hi - lo, "settled": got is not None, "selection_paths": list(stats.last_path),
+                      "ranks_agree_bitwise": same, "M_slide": [float(x) for x in vec[1:7]], "maxC_slide": [float(x) for x in vec[7:9]],
+                      "shard_sizes_of_100000_tiles": [b - a_ for a_, b in spans],
+                      "shards_contiguous": bool(spans[0][0] == 0 and spans[-1][1] == 100000 and all(spans[i][1] == spans[i + 1][0] for i in range(world - 1)))}
         if rank == 0:
             print(json.dumps({"metric": "DRY RUN -- launcher / rendezvous / placement logic only, no kernels ran", "dry_run": True,
                               "value": round(world * a.tiles * a.steps / elapsed, 1), "unit": "tiles/s (of a sleeping stand-in)",
                               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 4),
                               "distributed": {"backend": (dist.get_backend() if dist_on else None),
                                               "world_size": (dist.get_world_size() if dist_on else 1),
-                                              "per_rank_tiles_per_s": [r["tiles_per_s"] for r in ranks], "ranks": ranks}}))
+                                              "per_rank_tiles_per_s": [r["tiles_per_s"] for r in ranks], "ranks": ranks,
+                                              "slide_pooled": pooled}}))
         if dist_on:
             barrier()
             dist.destroy_process_group()

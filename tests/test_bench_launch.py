@@ -38,6 +38,35 @@ def test_gpus_2_without_a_launcher_starts_two_ranks():
         assert c0[1] < c1[0] or c1[1] < c0[0], (c0, c1)            # disjoint core slices
 
 
+def test_world_8_dry_run_of_the_pooled_slide_mode():
+    """Round-5 review, item 7: the first real 8-GPU run should not be the first time eight ranks meet.  `bench.py --gpus 8
+    --slide-pooled` on the CPU (SL_BENCH_DRY=1, gloo): launcher, rendezvous of eight ranks, eight disjoint core slices, the shard
+    arithmetic of the 100 000-tile slide, and the product's one-sweep pooled chain with its collectives on eight ranks (device steps:
+    the numpy stand-ins of tests/pool2_standins.py) -- the ranks agree to the bit and match the reference on the concatenated slide."""
+    import numpy as np
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--steps", "2", "--warmup", "1", "--slide-pooled"], cwd=ROOT,
+                       env=_clean_env(SL_BENCH_DRY="1", SL_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    line = _line(r.stdout)
+    d = line["distributed"]
+    assert line["dry_run"] is True and line["n_gpus"] == 8 and d["backend"] == "gloo" and d["world_size"] == 8
+    assert [x["rank"] for x in d["ranks"]] == list(range(8)) and [x["device"] for x in d["ranks"]] == list(range(8))
+    cores = [x["cores"] for x in d["ranks"]]
+    if all(c is not None for c in cores) and len(os.sched_getaffinity(0)) >= 8:
+        spans = sorted(cores)
+        assert all(spans[i][1] < spans[i + 1][0] for i in range(7)), spans              # eight disjoint core slices
+    sp = d["slide_pooled"]
+    assert sp["shards_contiguous"] and sum(sp["shard_sizes_of_100000_tiles"]) == 100000 and set(sp["shard_sizes_of_100000_tiles"]) == {12500}
+    assert sp["settled"] and sp["ranks_agree_bitwise"] and sp["selection_paths"] == ["merged", "merged"] and sp["tiles"] == 48
+    sys.path.insert(0, ROOT)
+    from oracle import stain_oracle as so
+    tiles = [so.synth_tile(96, 128, 700 + s) for s in range(46)] + [np.full((96, 128, 3), 255, np.uint8)] * 2
+    tall = np.concatenate(tiles, axis=0)
+    M_ref = so.macenko_stain_matrix(tall)
+    np.testing.assert_allclose(np.asarray(sp["M_slide"]).reshape(2, 3), M_ref, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(sp["maxC_slide"], np.percentile(so.get_concentrations(tall, M_ref), 99, axis=0), rtol=2e-6)
+
+
 def test_more_gpus_than_the_box_has_is_refused():
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "64", "--steps", "1", "--warmup", "0"], cwd=ROOT, env=_clean_env(),
                        capture_output=True, text=True, timeout=600)
