@@ -1006,8 +1006,9 @@ def main():
                                  "-4 bracket missed, -5 lists predicted full",
                         "interleaved_ms_per_launch": {"three_sweep (two_sweep=1)": round(ab[0], 4), "automatic (default)": round(ab[1], 4),
                                                       "every tile tries (two_sweep=2)": round(ab[2], 4)},
-                        "note": "automatic: on its first tile only the workgroup launched second on its CU tries (phase 0 streams nothing: with both "
-                                "workgroups of a CU in it at the start of a launch the chip idles); results are identical in every mode (tests)"}
+                        "note": "automatic: every workgroup tries on its tile; one whose tile declined skips the attempt on its next three tiles "
+                                "(the back-off); on real tissue the attempt mostly declines after the sample's eigen-solve (+2-3 % against "
+                                "two_sweep=1 there); results are identical in every mode (tests)"}
 
         line = {
             "metric": "1024x1024 H&E tiles/sec normalized (Macenko)",

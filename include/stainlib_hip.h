@@ -162,12 +162,19 @@ typedef struct SlParams {
                                    route): 0 (default) = per tile, wherever the sample says it pays (a workgroup whose tile declined skips the attempt on its next
                                    three tiles); 1 = never; 2 = wherever an estimate
                                    exists (tests); 3 = as 2 with the verification forced to fail, 4 = as 2 with the sample's plane tilted
-                                   (tests of the fallback).  Results do not depend on it. */
+                                   (tests of the fallback).  Any other value: SL_ERR_BADARG.  The test modes 2-4 run the merged sweep behind
+                                   the colour-cube mask even under prefilter == 1 (that sweep has no per-pixel form); in the automatic mode
+                                   prefilter == 1 rules the route out.  Results do not depend on it.  On real tissue the automatic mode
+                                   mostly declines after its sample's eigen-solve (+2-3 % against two_sweep = 1 on such batches, -6-10 % on
+                                   synthetic ones: DESIGN 4.1). */
     int32_t reserved1;
     int32_t* twosweep_out;      /* NULL (default) or DEVICE pointer to n ints: SL_TWOSWEEP_* per tile (diagnostics).  Written by the fused
                                    schedule of sl_macenko_*; left untouched otherwise. */
 } SlParams;
 
+/* sl_version() == SL_VERSION must be checked BEFORE any other call: sl_default_params writes sizeof(SlParams) of THIS library's
+ * header into the caller's struct -- a caller compiled against a header with a smaller SlParams would be written past its end before
+ * any struct_size check could run (the ctypes binding refuses a library of another version: stainlib_amd/_ffi.py). */
 SL_API int sl_version(void);
 SL_API const char* sl_error_string(int code);
 SL_API void sl_default_params(SlParams* p);

@@ -18,7 +18,8 @@ inline int hip_err(hipError_t e) { return e == hipSuccess ? SL_OK : SL_ERR_HIP_B
 inline int launch_status() { return hip_err(hipGetLastError()); }
 
 // An SlParams handed over by the caller: NULL (defaults) or a struct of THIS header's size (SlParams.struct_size, set by sl_default_params).
-inline bool params_ok(const SlParams* p) { return !p || p->struct_size == (uint32_t)sizeof(SlParams); }
+// (and with its enumerated fields inside their ranges: an unknown two_sweep used to run as "automatic" without a word)
+inline bool params_ok(const SlParams* p) { return !p || (p->struct_size == (uint32_t)sizeof(SlParams) && p->two_sweep >= 0 && p->two_sweep <= 4); }
 
 // Largest index into OpenCV's LabCbrtTab_b whose 8-bit L satisfies L/255.0 < threshold, +1,
 // shifted to the fixed-point scale the kernels compare against (see is_tissue()).

@@ -119,7 +119,7 @@ def test_forced_two_sweep_against_the_reference_goldens(path):
 
 
 def test_real_tissue_and_a_full_grid_in_the_automatic_mode():
-    """A batch that fills the resident grid (the automatic mode lets only the workgroup launched second on a CU try on its first tile):
+    """A batch that fills the resident grid (automatic mode: every workgroup tries, one whose tile declined backs off for three tiles):
     i.i.d. tiles and the real-tissue fixture mirror-tiled; the attempts are reported, nothing fails, and the bytes are the
     three-sweep schedule's."""
     from stainlib_amd import engine
