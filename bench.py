@@ -406,8 +406,8 @@ def secondary_configs(dev, Mt, mct):
         del rgb
     structured["note"] = ("oracle.structured_tile: 'blobs' = nuclei, slow eosin gradients, a lumen, little noise (neighbouring pixels strongly "
                           "correlated); 'white_bg' = 35 % saturated background; 'quantized' = JPEG-like colour ties.  A 12-colour palette "
-                          "image (every order statistic inside a run of ties) leaves the fast path for all of them (one census pass over the tile each): 68 k tiles/s, "
-                          "tools/structured_rate.py")
+                          "image (every order statistic inside a run of ties) leaves the fast path for all of them (one census pass over the tile each): tools/structured_rate.py "
+                          "(timed like this line's timed region since round 6)")
     sec["configs1_structured_512x1024"] = structured
     del out
 

@@ -11,14 +11,21 @@ from tools.synth import synth_tiles  # noqa: E402
 
 
 def med(fn, reps=8):
-    for _ in range(2):
+    """ms per launch, timed like bench.py's timed region: `reps` launches back to back between ONE pair of events on the launch stream,
+    after a spin-up (one launch per host synchronisation, as this tool did until round 5, measures the cold-clock latency of a launch:
+    1.50 ms where the bench reads 1.37)."""
+    for _ in range(6):
         fn()
     torch.cuda.synchronize()
     ts = []
-    for _ in range(reps):
+    for _ in range(3):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1))
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / reps)
     return float(np.median(ts))
 
 
