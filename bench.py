@@ -1031,7 +1031,10 @@ def main():
                        "failed_tiles": n_bad},
             "arithmetic": "per-pixel arithmetic binary32 (optical-density table, lasso, exp2, truncating pack); moment sums, eigen-solve, "
                           "percentile interpolation, trigonometry and per-tile constants binary64; order statistics exact on binary32 keys. "
-                          "The reference is float64 throughout: see parity.prequant_max_rel_err against the north star's 1e-4",
+                          "The reference is float64 throughout: see parity.prequant_max_rel_err against the north star's 1e-4.  What binary64 "
+                          "per-pixel arithmetic would cost: the apply pass's arithmetic on its memory pattern takes 0.910 ms per 512 tiles in "
+                          "binary32 and 1.794 ms in binary64 (1.97 x; tools/kbench_apply_f64.hip, profiles/r06_apply_f64.txt) -- the pass would "
+                          "leave the HBM bound (k_apply: 0.61 ms) for the binary64 issue rate",
             "roofline": {"kernel": dom_name, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic_dom,
                          "traffic_source": traffic_src,
