@@ -105,7 +105,8 @@ def test_vahadane_1024_tiles_fit_and_transform():
         assert (st.cpu().numpy() == 0).all()
         for i, I in enumerate(tiles):
             np.testing.assert_allclose(M[i].cpu().numpy(), fits[i][0], rtol=0, atol=V_ATOL)
-            np.testing.assert_allclose(mc[i].cpu().numpy(), fits[i][1], rtol=2e-5)
+            print(f"vahadane 1024^2 schedule {sched} tile {i}: maxC rel err {np.abs(mc[i].cpu().numpy() / fits[i][1] - 1).max():.1e}")
+            np.testing.assert_allclose(mc[i].cpu().numpy(), fits[i][1], rtol=2e-6)
             Cs = so.get_concentrations(I, fits[i][0]) * (mcto / fits[i][1])
             want = so.truncate_u8(255 * np.exp(-Cs @ Mto)).reshape(I.shape)
             d = np.abs(out[i].cpu().numpy().astype(np.int16) - want.astype(np.int16))
@@ -113,8 +114,8 @@ def test_vahadane_1024_tiles_fit_and_transform():
             print(f"vahadane 1024^2 schedule {sched} tile {i}: {flips} of {d.size} bytes differ ({flips / d.size:.2e}); "
                   f"|dM| {np.abs(M[i].cpu().numpy() - fits[i][0]).max():.1e}")
             # the dictionary agrees with the oracle's to < 1e-7 (its own stopping tolerance), which moves every pixel a little:
-            # measured 10-30 of 3.1 M bytes; the bar is the north star's 1e-4
-            assert d.max() <= 1 and flips <= 1e-4 * d.size
+            # measured 10-30 of 3.1 M bytes; the bar is twice that (round-5 review: it stood at the north star's 1e-4 N = 314)
+            assert d.max() <= 1 and flips <= 64
         outs.append(out)
     assert (outs[0] != outs[1]).float().mean().item() < 1e-4
 
