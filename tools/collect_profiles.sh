@@ -2,7 +2,7 @@
 # Collects every measurement the docs cite into gpurun_out/ (run on the GPU box from the repo root):
 #   make -C tools && /usr/local/graft/bin/gpurun --timeout 1800 -- 'bash tools/collect_profiles.sh r04'
 # then copy gpurun_out/r04_* to profiles/ (tracked); bench.py reads <tag>_pmc_traffic.json from there.
-tag=${1:-r05}
+tag=${1:-r06}
 cd "$GRAFT_REPO_ROOT" || exit 1
 out=$PWD/gpurun_out
 mkdir -p "$out"
@@ -72,8 +72,15 @@ for pass in "v:SQ_INSTS_VALU SQ_INSTS_LDS" "l:SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_AC
 done
 python tools/make_pmc_traffic.py "$tag" "$out" > "$out/${tag}_pmc_traffic.json" 2> /dev/null
 python tools/time_batches.py 2>/dev/null | grep " ms" > "$out/${tag}_batches_mixed.txt"
-# configs[4] at one GPU's shard size, the Lab family's kernels
+# configs[4] at one GPU's shard size; round 6: the kernels of the one-sweep pooled chain (512 tiles and one rank's 12 500), its steps by
+# content class, what binary64 apply arithmetic would cost
 python tools/slide_scale.py 512,2048,12500 2>/dev/null | grep -v amdgpu > "$out/${tag}_slide_scale.txt"
+for n in 512 12500; do
+  rm -rf /tmp/kp; timeout 600 rocprofv3 --kernel-trace -d /tmp/kp -o p -- python tools/pool2_chain.py $n 5 > /dev/null 2>&1
+  python tools/rocpd_stats.py "$(ls /tmp/kp/*/*.db /tmp/kp/*.db 2>/dev/null | head -1)" 2>&1 | grep -v "at::native\|rocclr\|Cijk" > "$out/${tag}_kernel_stats_pooled$n.md"
+done
+(python tools/pool2_check.py 512 1024; python tools/pool2_check.py 12500 1024) 2>/dev/null | grep -v amdgpu > "$out/${tag}_pooled_classes.txt"
+[ -x tools/bin/kbench_apply_f64 ] && timeout 120 tools/bin/kbench_apply_f64 > "$out/${tag}_apply_f64.txt" 2>&1
 timeout 200 python tools/power_classes.py 2>/dev/null | grep -v amdgpu > "$out/${tag}_power_classes.txt"
 python tools/structured_rate.py 2>/dev/null | grep -v amdgpu > "$out/${tag}_structured_rate.txt"
 python tools/cube_ab.py iid white_bg quantized ihc grey_bg blobs 2>/dev/null | grep -v amdgpu > "$out/${tag}_cube_prefilter_ab.txt"
