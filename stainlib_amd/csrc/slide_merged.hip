@@ -29,7 +29,7 @@ using namespace sl;
 
 namespace {
 
-constexpr int kP2ListThreads = 256;      // list passes (64 KB of LDS bins per workgroup)
+constexpr int kP2ListThreads = 1024;     // list passes (64 KB of LDS bins per workgroup: two workgroups = 32 waves per CU; with 256 threads the passes ran at 2 waves per SIMD)
 constexpr int kP2SampleBlkLog2 = 8;      // sample list: blocks of 256 entries (one wave iteration)
 constexpr int kP2CandBlkLog2 = 10;       // candidate list: blocks of 1024 entries owned by one wave (each wave a private run of blocks, then a shared pool)
 constexpr int kP2Stage = 224;            // per-wave LDS staging entries of the sweep (8 waves: 7 KB beside the 64 KB row table)
