@@ -214,6 +214,8 @@ class PooledSlideStatistics:
         self.last_path = []          # per stage of the last call: "merged" (the one-sweep chain), "window" (a sweep per stage) or "radix" (the fallback rounds)
         self.last_miss = 0           # state[POOL_MISS] of the last device-driven chain read back
         self.last_why = 0            # state[POOL2_WHY] of the last one-sweep chain (why the sample gave no estimate)
+        self.sample_log2 = None      # None: the sample density follows the slide's pixel count (sample_log2_for); 0...12: one 64-pixel sub-row in 2^s
+                                     # (tests and experiments; the same on every rank -- the RESULT does not depend on it, only which route settles it)
 
     def enqueue(self, tiles_local: torch.Tensor, ws=None, n_tiles_total: Optional[int] = None) -> torch.Tensor:
         """DEVICE-DRIVEN: enqueue the whole computation (4 full sweeps, 6 sampled passes, the all-reduces between them and the
@@ -304,7 +306,7 @@ class PooledSlideStatistics:
         n_local, h, w, _ = tiles_local.shape
         dev = tiles_local.device
         coll = _coll(world, self.group)
-        slog = self.sample_log2_for(self._agreed_pixels(tiles_local, n_tiles_total, world))
+        slog = self.sample_log2_for(self._agreed_pixels(tiles_local, n_tiles_total, world)) if self.sample_log2 is None else int(self.sample_log2)
         if ws is None or ws.get("key") != (n_local, h, w, slog, dev):
             buf = engine.pool2_workspace(n_local, h, w, slog, dev)
             if ws is not None:               # a caller's cache (a dict): the buffer is reused by its next call with this shape

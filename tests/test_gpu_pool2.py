@@ -179,3 +179,83 @@ def test_pool2_entry_points_refuse_bad_arguments():
         engine.pool2_hist(0, 0, 1, (2, 64, 64), 0, state, ws, hist)      # the sample is histogrammed on a grid only
     with pytest.raises(_ffi.StainlibHipError):
         engine.pool2_hist(1, 2, 1, (2, 64, 64), 0, state, ws, hist)      # unknown key set
+
+
+def random_slides(seed):
+    """The random slides of the test below (label, tiles, threshold, percentile, lambda, forced sample density or None): 1...24 tiles
+    of one random shape (ragged, any remainder modulo 4) whose contents are drawn per tile -- i.i.d. stains, white background, heavy
+    ties, spatially smooth, windows of the real-tissue fixture, all-white tiles."""
+    rng = np.random.RandomState(seed)
+    ihc = np.load(os.path.join(GOLDEN, "tissue_ihc_512.npz"))["input"]
+    while True:
+        n = int(rng.choice([1, 2, 3, 5, 8, 13, 24]))
+        h, w = int(rng.randint(12, 420)), int(rng.randint(16, 420))
+        if rng.rand() < 0.3:
+            w = (w + 63) // 64 * 64                                  # whole sample sub-rows
+        one_kind = rng.choice([None, None, "ihc", "quantized", "blobs"])
+        tiles = []
+        for _ in range(n):
+            kind = one_kind or rng.choice(["iid", "iid", "white_bg", "quantized", "blobs", "ihc", "white"])
+            s = int(rng.randint(1 << 20))
+            if kind == "ihc":
+                y0, x0 = int(rng.randint(0, 512 - h + 1)), int(rng.randint(0, 512 - w + 1))
+                tiles.append(ihc[y0:y0 + h, x0:x0 + w].copy())
+            elif kind == "white":
+                tiles.append(np.full((h, w, 3), 255, np.uint8))
+            else:
+                tiles.append(so.synth_tile(h, w, s) if kind == "iid" else so.structured_tile(kind, h, w, s))
+        thr, pct = float(rng.choice([0.8, 0.8, 0.7, 0.9])), float(rng.choice([99.0, 99.0, 95.0, 99.5]))
+        lam = float(rng.choice([0.01, 0.01, 0.05]))
+        slog = [None, None, 1, 2, 4][int(rng.randint(5))]
+        yield f"seed {seed}: {n} tiles {h}x{w} kinds {one_kind or 'mixed'} thr {thr} pct {pct} lam {lam} slog {slog}", tiles, thr, pct, lam, slog
+
+
+def test_random_slides_through_the_one_sweep_chain_against_three_sweeps_and_the_oracle():
+    """Random slides, extractor settings and sample densities (forced thin samples on small slides are where the estimate is worst and
+    the checks have to work): whenever the one-sweep chain reports a result it is the three-sweep chain's to the last bits and the
+    oracle's on the concatenation; when it reports a miss the caller's result still is.  SL_FUZZ_CASES / SL_FUZZ_SEED: a longer soak."""
+    from stainlib_amd.distributed import PooledSlideStatistics
+    seed = int(os.environ.get("SL_FUZZ_SEED", "606"))
+    cases = int(os.environ.get("SL_FUZZ_CASES", "40"))
+    settled = settled_auto = auto = done = 0
+    why = {}
+    for label, tiles, thr, pct, lam, slog in random_slides(seed):
+        if done >= cases:
+            break
+        tall = np.concatenate(tiles, axis=0)
+        try:
+            if int(so.tissue_mask(tall, thr).sum()) < 500:
+                continue
+            M_ref = so.macenko_stain_matrix(tall, thr, pct)
+        except so.TissueMaskException:
+            continue
+        mc_ref = np.percentile(so.get_concentrations(tall, M_ref, lam), 99, axis=0)
+        if not (mc_ref > 1e-3).all():
+            continue
+        done += 1
+        dev = to_dev(tiles)
+        st = PooledSlideStatistics(group=False, luminosity_threshold=thr, angular_percentile=pct, lasso_lambda=lam)
+        old = st(dev, merged=False)                                   # three sweeps (or the radix rounds behind them)
+        st.sample_log2 = slog
+        new = st.finish(st.enqueue_merged(dev))
+        miss, w_ = st.last_miss, st.last_why
+        st.one_call = False
+        new2 = st.finish(st.enqueue_merged(dev))                      # step by step: the same state
+        assert (new is None) == (new2 is None), label
+        auto += slog is None
+        if new is not None:
+            settled += 1
+            settled_auto += slog is None
+            assert np.array_equal(new[0], new2[0]) and np.array_equal(new[1], new2[1]), label
+            np.testing.assert_allclose(new[0], old[0], rtol=0, atol=1e-13, err_msg=label)
+            np.testing.assert_allclose(new[1], old[1], rtol=1e-13, err_msg=label)
+        else:
+            why[(miss, w_)] = why.get((miss, w_), 0) + 1
+        st.one_call = True
+        got = st(dev)                                                 # what a caller gets, whichever route
+        np.testing.assert_allclose(got[0], old[0], rtol=0, atol=1e-13, err_msg=label)
+        np.testing.assert_allclose(got[1], old[1], rtol=1e-13, err_msg=label)
+        np.testing.assert_allclose(got[0], M_ref, rtol=0, atol=5e-7, err_msg=label)
+        np.testing.assert_allclose(got[1], mc_ref, rtol=5e-7, err_msg=label)
+    print(f"{done} slides: the one-sweep chain settled {settled} ({settled_auto} of {auto} at the automatic density); misses (miss, why): {why}")
+    assert settled_auto >= (3 * auto) // 4
