@@ -392,9 +392,10 @@ SL_API int sl_pool_resolve(double* state, int keyset, const unsigned long long* 
  *     sl_pool2_hist(0, CONC, 0)                -> all-reduce                              -> sl_pool2_bands(CONC)
  *     sl_pool2_sweep  (THE full sweep)         -> all-reduce totals16 (16 doubles)        -> sl_pool2_exact
  *     for keyset in (ANGLE, CONC):  SL_POOL2_LEVELS times:  sl_pool2_hist(1, keyset, 1) -> all-reduce -> sl_pool2_step
- *         (11 bits of the ordered binary32 key per level: two levels settle a bracket of up to 2^22 values, the third every one that does not
- *          straddle zero; a settled
- *          key set turns the remaining passes and steps into no-ops)
+ *         (a radix descent in the ordered binary32 domain, one target per wanted RANK -- k and k + 1 of each of the two order statistics share
+ *          a window until they fall into different bins: SL_POOL2_WINDOW_BINS coarse bins, 11 key bits, per level, the last level
+ *          SL_POOL2_KEY_BINS single keys; two levels settle a bracket of up to 2^23 values, three every bracket; sparse and heavily tied keys
+ *          are settled like dense ones; a settled key set turns the remaining passes and steps into no-ops)
  * on one stream; state[SL_POOL_M / _MAXC / _STATUS / _MISS] as for sl_pool_*;
  * state[SL_POOL2_WHY] != 0 says the sample gave no usable estimate (the sweep then returns at once and the chain ends in a miss).
  * `workspace` (sl_pool2_workspace_bytes, 256-byte aligned) carries the sample list, the candidate list (up to 1/8 of the pixels) and
@@ -403,16 +404,18 @@ SL_API int sl_pool_resolve(double* state, int keyset, const unsigned long long* 
 #define SL_POOL2_STATE_DOUBLES 256
 #define SL_POOL2_TAIL_SLOTS 32
 #define SL_POOL2_GRID_BINS 8192
-#define SL_POOL2_WINDOW_BINS 2048 /* bins per target a window pass (mode 1) uses of the SL_POOL2_GRID_BINS */
-/* a histogram buffer: 4 x SL_POOL2_TAIL_SLOTS tail words, then 2 x SL_POOL2_GRID_BINS bins; every pass WRITES it whole */
-#define SL_POOL2_HIST_WORDS (4 * SL_POOL2_TAIL_SLOTS + 2 * SL_POOL2_GRID_BINS)
+#define SL_POOL2_WINDOW_BINS 2048 /* coarse bins per target of a window pass (mode 1) */
+#define SL_POOL2_KEY_BINS 4096    /* single keys per target at the last level of a window pass: 4 targets x SL_POOL2_KEY_BINS = 2 x SL_POOL2_GRID_BINS */
+/* a histogram buffer: 8 x SL_POOL2_TAIL_SLOTS tail words, then 2 x SL_POOL2_GRID_BINS bins (mode 0: two grids; mode 1: four targets of
+ * SL_POOL2_KEY_BINS); every pass WRITES it whole */
+#define SL_POOL2_HIST_WORDS (8 * SL_POOL2_TAIL_SLOTS + 2 * SL_POOL2_GRID_BINS)
 #define SL_POOL2_WHY 33
 SL_API size_t sl_pool2_workspace_bytes(int n, int h, int w, int sample_log2);
 SL_API int sl_pool2_sample(const uint8_t* rgb, int n, int h, int w, const SlParams* params, int sample_log2, void* workspace,
                     size_t workspace_bytes, double* moments16_out, void* stream);
 SL_API int sl_pool2_begin(const double* moments16_reduced, const SlParams* params, int sample_log2, double* state, void* stream);
-/* which: 0 the sample list (mode 0: a uniform grid), 1 the candidate list (mode 1: a window of SL_POOL2_GRID_BINS bins of 2^sh consecutive
- * binary32 values, position and sh from `state`); hist (SL_POOL2_HIST_WORDS uint64) is written whole */
+/* which: 0 the sample list (mode 0: a uniform grid of SL_POOL2_GRID_BINS bins per order statistic), 1 the candidate list (mode 1: per target a
+ * window of bins of 2^sh consecutive binary32 values, position and sh from `state`); hist (SL_POOL2_HIST_WORDS uint64) is written whole */
 SL_API int sl_pool2_hist(int which, int keyset, int mode, int n, int h, int w, const SlParams* params, int sample_log2, const double* state,
                   void* workspace, size_t workspace_bytes, unsigned long long* hist, void* stream);
 SL_API int sl_pool2_bands(double* state, int keyset, const unsigned long long* hist_reduced, void* stream);

@@ -124,7 +124,7 @@ _SIGNATURES = {
     "sl_pool2_local": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(SlParams), C.c_int, _P, C.c_size_t, _P, _P]),
 }
 POOL_STATE_DOUBLES, POOL_M, POOL_MAXC, POOL_STATUS, POOL_MISS = 64, 0, 6, 8, 9
-POOL2_STATE_DOUBLES, POOL2_HIST_WORDS, POOL2_WHY = 256, 2 * 8192 + 4 * 32, 33
+POOL2_STATE_DOUBLES, POOL2_HIST_WORDS, POOL2_WHY = 256, 2 * 8192 + 8 * 32, 33
 EXPECTED_VERSION = 600     # the SL_VERSION this binding (SlParams, signatures) was written for
 EXPORTS = tuple(_SIGNATURES)
 

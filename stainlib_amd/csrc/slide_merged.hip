@@ -40,7 +40,10 @@ constexpr int kP2TailSlots = SL_POOL2_TAIL_SLOTS;
 constexpr int kP2GridBins = SL_POOL2_GRID_BINS;
 constexpr int kP2WinBits = 11;
 constexpr int kP2WinBins = SL_POOL2_WINDOW_BINS;   // bins per target of a window pass (11 key bits per level: two levels settle a bracket of up to 2^22 values)
-constexpr int kTailWords = 4 * kP2TailSlots;
+constexpr int kP2KeyBins = SL_POOL2_KEY_BINS;      // single keys per target at the last level of a window descent
+constexpr int kP2KeyBits = 12;
+constexpr int kTailPer = 8;               // tail words per slot: [0..3] keys below the window of target u (grid passes: 0, 1), [4] listed entries or q1, [5] q2
+constexpr int kTailWords = kTailPer * kP2TailSlots;
 constexpr double kQScale = 1048576.0;    // fixed-point scale of the fourth-moment sums riding in the uint64 histogram buffer
 
 // ---- the pool2 state (doubles; include/stainlib_hip.h SL_POOL2_*).  [0, 10) as SL_POOL_*.
@@ -54,13 +57,18 @@ enum {
     kSw = 70,             // the sweep's binary32 constants: fgH[3] fgL[3] fn[3] fk1 W[6] kt[2] eps[2] zeta[2] thr[2] = 24
     kNa = 96, kNc = 97, kOvf = 98,
     kBr = 100,            // exact-space: lo end, hi0 (plain cone's lower edge), lo1 (its upper edge), hi end
-    kGridLo = 104, kGridScale = 106, kWinLo = 108, kRes = 110, kSh = 114,
+    kGridLo = 104, kGridScale = 106, kRes = 110,
     kDiag = 116, kDone = 120, kLevel = 121,          // diagnostics: [0] cmax, [1] dn, [2..3] eps seen, ...
-    kMk = 128             // MergedConc (raw bytes)
+    kMk = 128,            // MergedConc (raw bytes)
+    // the windows of the selection on the candidates, per TARGET u = 2 t + j: rank k (j = 0) or k + 1 (j = 1) of pair t (t = 0 / 1: lower / upper
+    // percentile, or stain 1 / 2): first key (ordered-uint domain) and log2 of the keys per bin.  The two targets of a pair share a window until
+    // the two ranks fall into different bins.
+    kWinLo = 240, kSh = 244
 };
-static_assert(kMk * 8 + sizeof(MergedConc) <= SL_POOL2_STATE_DOUBLES * 8, "");
+static_assert(kMk * 8 + sizeof(MergedConc) <= kWinLo * 8 && kSh + 4 <= SL_POOL2_STATE_DOUBLES, "");
 static_assert(kSw + 24 <= kNa, "");
-static_assert(kP2WinBins == (1 << kP2WinBits) && kP2WinBins % 1024 == 0 && kP2WinBins <= kP2GridBins, "");
+static_assert(kP2WinBins == (1 << kP2WinBits) && kP2WinBins % 1024 == 0 && kP2WinBins <= kP2KeyBins, "");
+static_assert(kP2KeyBins == (1 << kP2KeyBits) && kP2KeyBins % 1024 == 0 && 4 * kP2KeyBins == 2 * kP2GridBins, "");
 
 // why a route was declined (state[SL_POOL2_WHY]; 0 = not declined)
 enum { kWhyNoEstimate = 1, kWhyTilt = 2, kWhyBracket = 3, kWhyBox = 4, kWhyConc = 5 };
@@ -113,7 +121,7 @@ P2Layout p2_layout(int n, int h, int w, int slog) {
     L.hist_wgs = mg < 512 ? mg : 512;
     L.hpart = up(L.partials + sizeof(double) * 16 * (size_t)mg);
     L.tpart = up(L.hpart + 4 * (size_t)(2 * kP2GridBins) * L.hist_wgs);
-    L.local = up(L.tpart + 8 * 4 * (size_t)L.hist_wgs);               // sl_pool2_local: two 16-double vectors and one histogram buffer
+    L.local = up(L.tpart + 8 * (size_t)kTailPer * L.hist_wgs);               // sl_pool2_local: two 16-double vectors and one histogram buffer
     L.s_counts = up(L.local + 256 + 8 * (size_t)SL_POOL2_HIST_WORDS);
     L.s_entries = up(L.s_counts + 4 * (size_t)L.s_cap);
     L.c_counts = up(L.s_entries + (4 * (size_t)L.s_cap << kP2SampleBlkLog2));
@@ -252,9 +260,12 @@ __global__ void k_p2_begin(const double* mom, double* st, double pct, double lam
 }
 
 // ------------------------------------------------------------------------------------------
-// list passes: a histogram of the keys of a block list in kP2GridBins bins per target -- on a uniform grid (mode 0) or over a window
-// of kP2GridBins consecutive binary32 values (mode 1: the bins ARE keys).  A histogram buffer is [kTailWords tail words][2 x bins];
-// tail word i (0 below[0], 1 below[1], 2 listed entries or q1, 3 q2) is the sum of its kP2TailSlots copies at [4 slot + i].
+// list passes: a histogram of the keys of a block list -- on a uniform grid of kP2GridBins bins per order statistic (mode 0: the sample),
+// or (mode 1: the candidates) per TARGET u = 2 t + j (rank k / k + 1 of order statistic t) over a window of the ordered binary32 values:
+// kP2WinBins coarse bins of 2^sh keys, or kP2KeyBins single keys (sh = 0: the bins ARE keys); a target whose window is its pair's (the
+// normal case: both ranks in one bin) has no histogram of its own.  A histogram buffer is [kTailWords tail words][2 x kP2GridBins bins =
+// 4 x kP2KeyBins]; tail word i (0..3 keys below the window of target i, 4 listed entries or q1, 5 q2) is the sum of its kP2TailSlots
+// copies at [kTailPer slot + i].
 // The passes touch no global atomic in their loop: the bins are LDS-private per workgroup, written out as partial histograms and
 // added up by k_p2_gsum.  Measured on the way: 8 M uint64 atomics on a 65536-bin global histogram took 0.25 - 1.9 ms by how hot the
 // bins were (a slide's keys are heavily tied: 13 G pixels over at most 16.7 M colours), a 65536-key window with global atomics
@@ -267,7 +278,7 @@ struct P2HistArgs {
     int basis;               // angle: state offset of the binary32 basis (kVhF / kVf); conc: 0 = the box centre's constants, 1 = the exact M
     int fourth;              // angle over the sample: also the fourth-moment sums of the tilt bound
     uint32_t* part;          // grid mode: [gridDim][2 x kP2GridBins] partial histograms
-    unsigned long long* tpart;   // grid mode: [gridDim][4] partial tail words
+    unsigned long long* tpart;   // [gridDim][kTailPer] partial tail words
 };
 
 template <int KEYSET, int MODE>
@@ -275,16 +286,26 @@ __global__ __launch_bounds__(kP2ListThreads) void k_p2_hist(P2HistArgs a) {
     constexpr int NT = kP2ListThreads;
     __shared__ SmallTab s_tab;
     __shared__ uint32_t s_h[2 * kP2GridBins];
-    __shared__ unsigned long long s_tail[4];
+    __shared__ unsigned long long s_tail[kTailPer];
     s_tab.fill();
     const double* st = a.state;
     if (MODE == 1 && ((int)st[kDone] & (1 << KEYSET))) return;        // uniform: the key set is settled (k_p2_gsum skips alike)
-    // bins in use per target: a grid or a window of single keys (sh = 0) fills all kP2GridBins, a coarser window kP2WinBins of them
-    uint32_t nbt[2];
-    for (int t = 0; t < 2; ++t) nbt[t] = (MODE == 0 || (int)st[kSh + t] == 0) ? (uint32_t)kP2GridBins : (uint32_t)kP2WinBins;
-    for (int t = 0; t < 2; ++t)
-        for (uint32_t i = threadIdx.x; i < nbt[t]; i += NT) s_h[t * kP2GridBins + i] = 0;
-    if (threadIdx.x < 4) s_tail[threadIdx.x] = 0;
+    // histograms: mode 0 two grids of kP2GridBins; mode 1 four targets of kP2KeyBins slots (kP2WinBins used by a coarse window, none by a
+    // target that shares its pair's window)
+    constexpr int NU = MODE == 0 ? 2 : 4;
+    constexpr uint32_t kStride = MODE == 0 ? (uint32_t)kP2GridBins : (uint32_t)kP2KeyBins;
+    uint32_t nbt[NU];
+    uint32_t wlo[NU], wsh[NU];
+    for (int u = 0; u < NU; ++u) {
+        wlo[u] = MODE == 0 ? 0u : (uint32_t)st[kWinLo + u]; wsh[u] = MODE == 0 ? 0u : (uint32_t)st[kSh + u];
+        nbt[u] = MODE == 0 ? (uint32_t)kP2GridBins : (wsh[u] == 0 ? (uint32_t)kP2KeyBins : (uint32_t)kP2WinBins);
+    }
+    if (MODE == 1)
+        for (int t = 0; t < 2; ++t)
+            if (wlo[2 * t + 1] == wlo[2 * t] && wsh[2 * t + 1] == wsh[2 * t]) nbt[2 * t + 1] = 0;       // uniform
+    for (int u = 0; u < NU; ++u)
+        for (uint32_t i = threadIdx.x; i < nbt[u]; i += NT) s_h[u * kStride + i] = 0;
+    if (threadIdx.x < kTailPer) s_tail[threadIdx.x] = 0;
     __syncthreads();
     const TabView tab = view_of(s_tab);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -298,14 +319,11 @@ __global__ __launch_bounds__(kP2ListThreads) void k_p2_hist(P2HistArgs a) {
         lasso_consts(st + kM, st[kLam], L);
     }
     float glo[2], gsc[2];
-    uint32_t wlo[2], wsh[2];
-    for (int t = 0; t < 2; ++t) {
-        glo[t] = (float)st[kGridLo + t]; gsc[t] = (float)st[kGridScale + t];
-        wlo[t] = (uint32_t)st[kWinLo + t]; wsh[t] = (uint32_t)st[kSh + t];
-    }
+    for (int t = 0; t < 2; ++t) { glo[t] = (float)st[kGridLo + t]; gsc[t] = (float)st[kGridScale + t]; }
     float nf[3] = {0, 0, 0}, mean[3] = {0, 0, 0};
     if (a.fourth) for (int c = 0; c < 3; ++c) { nf[c] = (float)st[kNh + c]; mean[c] = (float)st[kMean + c]; }
-    unsigned long long nb0 = 0, nb1 = 0, nmatch = 0;
+    unsigned long long nbel[NU], nmatch = 0;
+    for (int u = 0; u < NU; ++u) nbel[u] = 0;
     float q1 = 0.0f, q2 = 0.0f;
     const uint32_t nblk = a.list.cap_blocks;                   // every block carries a count (0: unused)
     const uint32_t B = 1u << a.list.blk_log2;
@@ -331,15 +349,20 @@ __global__ __launch_bounds__(kP2ListThreads) void k_p2_hist(P2HistArgs a) {
         for (int t = 0; t < 2; ++t) {
             if (KEYSET == SL_KEYSET_ANGLE && a.fourth && t == 1) continue;      // the sample's angle histogram serves both percentiles
             if (MODE == 0) {
-                if (k[t] < glo[t]) { if (t == 0) ++nb0; else ++nb1; }
+                if (k[t] < glo[t]) ++nbel[t];
                 else {
                     const uint32_t b = (uint32_t)((k[t] - glo[t]) * gsc[t]);
-                    if (b < (uint32_t)kP2GridBins) atomicAdd(&s_h[t * kP2GridBins + b], 1u);
+                    if (b < (uint32_t)kP2GridBins) atomicAdd(&s_h[t * kStride + b], 1u);
                 }
             } else {
                 const uint32_t o = f2ord(k[t]);
-                if (o < wlo[t]) { if (t == 0) ++nb0; else ++nb1; }
-                else if (((o - wlo[t]) >> wsh[t]) < nbt[t]) atomicAdd(&s_h[t * kP2GridBins + ((o - wlo[t]) >> wsh[t])], 1u);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int u = 2 * t + j;
+                    if (nbt[u] == 0) continue;                       // uniform: the pair's histogram serves this rank too
+                    if (o < wlo[u]) ++nbel[u];
+                    else if (((o - wlo[u]) >> wsh[u]) < nbt[u]) atomicAdd(&s_h[u * kStride + ((o - wlo[u]) >> wsh[u])], 1u);
+                }
             }
         }
     };
@@ -367,18 +390,22 @@ __global__ __launch_bounds__(kP2ListThreads) void k_p2_hist(P2HistArgs a) {
             }
         }
     }
-    nb0 = wave_sum(nb0); nb1 = wave_sum(nb1); nmatch = wave_sum(nmatch);
-    unsigned long long w2 = nmatch, w3 = 0;                      // [2]: entries of this key set on the list
+    for (int u = 0; u < NU; ++u) nbel[u] = wave_sum(nbel[u]);
+    nmatch = wave_sum(nmatch);
+    unsigned long long w4 = nmatch, w5 = 0;                      // [4]: entries of this key set on the list
     if (a.fourth) {
-        w2 = (unsigned long long)(wave_sum((double)q1) * kQScale);
-        w3 = (unsigned long long)(wave_sum((double)q2) * kQScale);
+        w4 = (unsigned long long)(wave_sum((double)q1) * kQScale);
+        w5 = (unsigned long long)(wave_sum((double)q2) * kQScale);
     }
-    if (lane == 0) { atomicAdd(&s_tail[0], nb0); atomicAdd(&s_tail[1], nb1); atomicAdd(&s_tail[2], w2); atomicAdd(&s_tail[3], w3); }
+    if (lane == 0) {
+        for (int u = 0; u < NU; ++u) if (nbel[u]) atomicAdd(&s_tail[u], nbel[u]);
+        atomicAdd(&s_tail[4], w4); atomicAdd(&s_tail[5], w5);
+    }
     __syncthreads();
     uint32_t* dst = a.part + (size_t)blockIdx.x * (2 * kP2GridBins);
-    for (int t = 0; t < 2; ++t)
-        for (uint32_t i = tid; i < nbt[t]; i += NT) dst[t * kP2GridBins + i] = s_h[t * kP2GridBins + i];
-    if (tid < 4) a.tpart[(size_t)blockIdx.x * 4 + tid] = s_tail[tid];
+    for (int u = 0; u < NU; ++u)
+        for (uint32_t i = tid; i < nbt[u]; i += NT) dst[u * kStride + i] = s_h[u * kStride + i];
+    if (tid < kTailPer) a.tpart[(size_t)blockIdx.x * kTailPer + tid] = s_tail[tid];
 }
 
 // the partial histograms of the nwg workgroups of a list pass added up into hist (zeroed by the entry point): block (x, y) adds slice y of
@@ -387,16 +414,20 @@ constexpr int kGsumSlices = 16;
 __global__ __launch_bounds__(256) void k_p2_gsum(const uint32_t* part, const unsigned long long* tpart, int nwg, unsigned long long* hist,
                                                 const double* st, int done_bit) {
     if (done_bit && ((int)st[kDone] & done_bit)) return;       // the pass did not run: hist stays zero
-    const int i = blockIdx.x * 256 + threadIdx.x;               // one bin per thread: target i / kP2GridBins
+    const int i = blockIdx.x * 256 + threadIdx.x;               // one bin per thread (grid passes: statistic i / kP2GridBins; window passes: target i / kP2KeyBins)
     const int per = (nwg + kGsumSlices - 1) / kGsumSlices;
     const int g0 = blockIdx.y * per, g1 = min(nwg, g0 + per);
-    if (blockIdx.x == 0 && threadIdx.x < 4) {
+    if (blockIdx.x == 0 && threadIdx.x < kTailPer) {
         unsigned long long v = 0;
-        for (int gg = g0; gg < g1; ++gg) v += tpart[(size_t)gg * 4 + threadIdx.x];
-        if (v) atomicAdd(&hist[4 * blockIdx.y + threadIdx.x], v);
+        for (int gg = g0; gg < g1; ++gg) v += tpart[(size_t)gg * kTailPer + threadIdx.x];
+        if (v) atomicAdd(&hist[kTailPer * blockIdx.y + threadIdx.x], v);
     }
-    // (block-uniform: 256 bins never straddle the bins a coarse window leaves unused)
-    if (done_bit && (int)st[kSh + i / kP2GridBins] != 0 && (i % kP2GridBins) >= kP2WinBins) return;
+    // (block-uniform: 256 bins never straddle the bins a coarse window leaves unused, or two targets)
+    if (done_bit) {
+        const int u = i / kP2KeyBins;
+        if ((int)st[kSh + u] != 0 && (i % kP2KeyBins) >= kP2WinBins) return;
+        if ((u & 1) && st[kWinLo + u] == st[kWinLo + u - 1] && st[kSh + u] == st[kSh + u - 1]) return;     // shares its pair's histogram
+    }
     unsigned long long t = 0;
     int g = g0;
     for (; g + 8 <= g1; g += 8) {
@@ -413,7 +444,7 @@ __global__ __launch_bounds__(256) void k_p2_gsum(const uint32_t* part, const uns
 static_assert(kGsumSlices <= kP2TailSlots, "");
 __device__ __forceinline__ unsigned long long p2_tail(const unsigned long long* hist, int i) {
     unsigned long long t = 0;
-    for (int s = 0; s < kP2TailSlots; ++s) t += hist[4 * s + i];
+    for (int s = 0; s < kP2TailSlots; ++s) t += hist[kTailPer * s + i];
     return t;
 }
 
@@ -530,7 +561,7 @@ __global__ __launch_bounds__(1024) void k_p2_bands(double* st, const unsigned lo
             // the tilt bound from the sample's own fourth moments (fused_phase0)
             double tau = st[kTau];
             if ((int)st[kSlog] > 0) {
-                const double t1 = (double)p2_tail(hist, 2) / kQScale, t2 = (double)p2_tail(hist, 3) / kQScale;
+                const double t1 = (double)p2_tail(hist, 4) / kQScale, t2 = (double)p2_tail(hist, 5) / kQScale;
                 const double se = fmax(sqrt(t1) / (n * st[kGap]), sqrt(t2) / (n * st[kGap + 1]));
                 tau = fmax(tau, kTiltZ4 * sqrt(kP2Deff) * se);
             }
@@ -870,11 +901,13 @@ __device__ __forceinline__ void p2_set_window(double* st, int t, double lo, doub
     uint32_t ohi = f2ord((float)hi);
     if (ohi < olo) ohi = olo;
     const unsigned long long span = (unsigned long long)(ohi - olo) + 1ull;
-    int sh = 0;                                                  // single keys when kP2GridBins of them span the bracket, else kP2WinBins coarse bins
-    if (span > (unsigned long long)kP2GridBins)
+    int sh = 0;                                                  // single keys when kP2KeyBins of them span the bracket, else kP2WinBins coarse bins
+    if (span > (unsigned long long)kP2KeyBins)
         while (((span + (1ull << sh) - 1ull) >> sh) > (unsigned long long)kP2WinBins) ++sh;
-    st[kWinLo + t] = (double)olo;
-    st[kSh + t] = (double)sh;
+    for (int j = 0; j < 2; ++j) {                                // both ranks of the pair start in the same window
+        st[kWinLo + 2 * t + j] = (double)olo;
+        st[kSh + 2 * t + j] = (double)sh;
+    }
 }
 
 __global__ void k_p2_exact(const double* tot, double* st) {
@@ -951,16 +984,18 @@ __global__ void k_p2_exact(const double* tot, double* st) {
     }
 }
 
-// One level of the exact selection on the candidates: the all-reduced window histogram of both targets -> the bin that holds the wanted
-// rank; a window of single keys (sh = 0) settles the pair of ranks k, k + 1, a coarser one narrows to the bin (13 bits per level: two
-// levels for every bracket that does not straddle zero, where binary32 values are densest; three otherwise).  Settling the angular
-// stage: the stain matrix (macenko_stain_extractor.py:33-44), merged_verify, the windows of the concentration stage; settling that:
-// maxC (normalizer.py:36,47).  A settled key set ignores further calls (and sl_pool2_hist skips its pass).
+// One level of the exact selection on the candidates: the all-reduced window histograms -> for every target (rank k and rank k + 1 of
+// each of the two order statistics) the bin that holds its rank; a window of single keys (sh = 0) settles the target's key, a coarser one
+// narrows its window to the bin (11 key bits per level, the last level kP2KeyBins single keys: three levels settle any bracket).  The two
+// ranks of a pair share window and histogram until they fall into different bins -- from there each descends on its own, so sparse keys
+// (a small slide) and heavily tied ones (few colours) are settled like dense ones.  Settling the angular stage: the stain matrix
+// (macenko_stain_extractor.py:33-44), merged_verify, the windows of the concentration stage; settling that: maxC (normalizer.py:36,47).
+// A settled key set ignores further calls (and sl_pool2_hist skips its pass).
 __global__ __launch_bounds__(1024) void k_p2_step(double* st, const unsigned long long* hist, int keyset) {
     __shared__ P2Scan S;
     __shared__ float s_res[4];
-    __shared__ double s_nwlo[2];
-    __shared__ int s_nsh[2];
+    __shared__ double s_nwlo[4];
+    __shared__ int s_nsh[4];
     __shared__ int s_miss;
     const int tid = threadIdx.x;
     const int bit = keyset == SL_KEYSET_ANGLE ? kMissAngle : kMissConc;
@@ -970,33 +1005,33 @@ __global__ __launch_bounds__(1024) void k_p2_step(double* st, const unsigned lon
     const double N = keyset == SL_KEYSET_ANGLE ? st[kT] : st[kNpx];
     // the pixels that are NOT on the list were proven plain: inside the cone (above the lower bracket, below the upper one) / below both
     // concentration thresholds.  Lower angular pair: ranks count from the list's start; every other pair: shifted by their number.
-    const double n_listed = (double)p2_tail(hist, 2);
+    const double n_listed = (double)p2_tail(hist, 4);
     const double sub[2] = {keyset == SL_KEYSET_ANGLE ? 0.0 : N - n_listed, N - n_listed};
     __syncthreads();
     bool exact = true;
     for (int t = 0; t < 2; ++t) {
-        const unsigned long long* h = hist + kTailWords + kP2GridBins * t;
-        const int nb = (int)st[kSh + t] == 0 ? kP2GridBins : kP2WinBins;        // bins of this target's window
-        p2_scan_build(S, h, nb, tid);
-        const unsigned long long below = p2_tail(hist, t);
         const double kd = st[kK + t];
         const long long kg = (long long)(kd < 0 ? 0 : (kd > N - 1.0 ? N - 1.0 : kd));
-        const long long kg1 = (double)(kg + 1) <= N - 1.0 ? kg + 1 : kg;
-        const uint32_t lo = (uint32_t)st[kWinLo + t];
-        const int sh = (int)st[kSh + t];
-        const long long kc = kg - (long long)sub[t];
-        const long long bin = N >= 1.0 && kc >= 0 ? p2_scan_locate(S, h, nb, kc, below, tid) : -1;
-        if (bin < 0 || bin >= nb) { if (tid == 0) s_miss = 1; continue; }          // uniform
-        if (sh == 0) {
-            const long long bin1 = p2_scan_locate(S, h, nb, kg1 - (long long)sub[t], below, tid);
-            if (tid == 0) {
-                if (bin1 < 0 || bin1 >= nb) s_miss = 1;
-                else { s_res[2 * t] = ord2f(lo + (uint32_t)bin); s_res[2 * t + 1] = ord2f(lo + (uint32_t)bin1); }
-                s_nwlo[t] = (double)lo; s_nsh[t] = 0;
+        const long long rank[2] = {kg, (double)(kg + 1) <= N - 1.0 ? kg + 1 : kg};
+        const bool shared = st[kWinLo + 2 * t + 1] == st[kWinLo + 2 * t] && st[kSh + 2 * t + 1] == st[kSh + 2 * t];     // uniform
+        for (int j = 0; j < 2; ++j) {
+            const int u = 2 * t + j, uh = (shared && j == 1) ? u - 1 : u;       // uh: the target whose histogram holds this rank
+            const unsigned long long* h = hist + kTailWords + kP2KeyBins * uh;
+            const uint32_t lo = (uint32_t)st[kWinLo + u];
+            const int sh = (int)st[kSh + u];
+            const int nb = sh == 0 ? kP2KeyBins : kP2WinBins;
+            if (uh == u) p2_scan_build(S, h, nb, tid);                        // (a shared histogram: the scan of j = 0 is still there)
+            const unsigned long long below = p2_tail(hist, uh);
+            const long long kc = rank[j] - (long long)sub[t];
+            const long long bin = N >= 1.0 && kc >= 0 ? p2_scan_locate(S, h, nb, kc, below, tid) : -1;
+            if (bin < 0 || bin >= nb) { if (tid == 0) s_miss = 1; continue; }      // uniform
+            if (sh == 0) {
+                if (tid == 0) { s_res[u] = ord2f(lo + (uint32_t)bin); s_nwlo[u] = (double)lo; s_nsh[u] = 0; }
+            } else {
+                exact = false;
+                // the bin's 2^sh keys: kP2KeyBins single keys if they fit, else kP2WinBins bins of 2^(sh - 11)
+                if (tid == 0) { s_nwlo[u] = (double)lo + (double)((unsigned long long)bin << sh); s_nsh[u] = sh > kP2KeyBits ? sh - kP2WinBits : 0; }
             }
-        } else {
-            exact = false;
-            if (tid == 0) { s_nwlo[t] = (double)lo + (double)((unsigned long long)bin << sh); s_nsh[t] = sh > kP2WinBits ? sh - kP2WinBits : 0; }
         }
     }
     __syncthreads();
@@ -1017,7 +1052,7 @@ __global__ __launch_bounds__(1024) void k_p2_step(double* st, const unsigned lon
     }
     if (!exact) {
         if (tid == 0) {
-            for (int t = 0; t < 2; ++t) { st[kWinLo + t] = s_nwlo[t]; st[kSh + t] = (double)s_nsh[t]; }
+            for (int u = 0; u < 4; ++u) { st[kWinLo + u] = s_nwlo[u]; st[kSh + u] = (double)s_nsh[u]; }
             st[kLevel] = (double)(level + 1);
         }
         return;

@@ -16,9 +16,9 @@ import torch
 
 from stainlib_amd import distributed as sd
 
-NB, TW, WB, WBITS = 8192, 128, 2048, 11           # grid bins, tail words, window bins (of the NB a target owns), key bits per level
+NB, TW, TP, WB, WBITS, KB, KBITS = 8192, 256, 8, 2048, 11, 4096, 12   # grid bins, tail words (TP per slot), coarse window bins and key bits per level, single keys of a last level
 K_T, K_NPX, K_VD, K_VF, K_K, K_G, K_TS, K_NS, K_SLOG, K_BRK, K_BR, K_WLO, K_RES, K_SH, K_DONE, K_LEVEL = \
-    10, 11, 12, 18, 24, 26, 30, 31, 32, 60, 100, 108, 110, 114, 120, 121
+    10, 11, 12, 18, 24, 26, 30, 31, 32, 60, 100, 240, 110, 244, 120, 121
 K_VH, K_MH, K_L = 34, 140, 150                         # (K_MH, K_L: private to the stand-ins -- the sample's stain matrix, the thresholds)
 
 
@@ -104,11 +104,14 @@ def install(all_tiles, break_it=False):
         return st
 
     def put(hist, rows, below, listed):
+        """rows: two grids of NB bins (the sample) or four targets of KB slots (the candidates; None: the target shares its pair's)"""
         hist.zero_()
-        for t in range(2):
-            hist[TW + NB * t:TW + NB * (t + 1)] = torch.from_numpy(rows[t].astype(np.int64))
-            hist[t] = int(below[t])
-        hist[2] = int(listed)
+        stride = (2 * NB) // len(rows)
+        for u, row in enumerate(rows):
+            if row is not None:
+                hist[TW + stride * u:TW + stride * (u + 1)] = torch.from_numpy(row.astype(np.int64))
+                hist[u] = int(below[u])
+        hist[4] = int(listed)
         return hist
 
     def pool2_hist(which, keyset, mode, shape, slog, state, ws, hist, params=None):
@@ -137,10 +140,14 @@ def install(all_tiles, break_it=False):
             C = conc_keys(od, state[_ffi.POOL_M:_ffi.POOL_M + 6].numpy())
             ks = [C[:, 0], C[:, 1]]
         rows, below = [], []
-        for t in range(2):
-            o, wlo, sh = f2ord(ks[t]).astype(np.int64), int(state[K_WLO + t]), int(state[K_SH + t])
+        for u in range(4):                                   # target u: rank k (even) / k + 1 (odd) of order statistic u // 2
+            o, wlo, sh = f2ord(ks[u // 2]).astype(np.int64), int(state[K_WLO + u]), int(state[K_SH + u])
+            if u & 1 and (wlo, sh) == (int(state[K_WLO + u - 1]), int(state[K_SH + u - 1])):
+                rows.append(None)                            # the pair's histogram serves both ranks
+                below.append(0)
+                continue
             b = (o - wlo) >> sh
-            rows.append(np.bincount(b[(o >= wlo) & (b < (NB if sh == 0 else WB))], minlength=NB))    # single keys: NB of them; coarse bins: WB
+            rows.append(np.bincount(b[(o >= wlo) & (b < (KB if sh == 0 else WB))], minlength=KB))    # single keys: KB of them; coarse bins: WB
             below.append(int((o < wlo).sum()))
         return put(hist, rows, below, int(sel.sum()))
 
@@ -149,7 +156,7 @@ def install(all_tiles, break_it=False):
         out = []
         for r in ranks:
             r = int(r)
-            out.append(-1 if r < below else (int(np.searchsorted(cum, r - below, side="right")) if r - below < cum[-1] else NB))
+            out.append(-1 if r < below else (int(np.searchsorted(cum, r - below, side="right")) if r - below < cum[-1] else len(h)))
         return out
 
     def pool2_bands(state, keyset, hist):
@@ -204,9 +211,10 @@ def install(all_tiles, break_it=False):
     def set_window(state, t, lo, hi):
         olo, ohi = int(f2ord(np.float32(lo))), int(f2ord(np.float32(hi)))
         span, sh = max(ohi, olo) - olo + 1, 0
-        while span > NB and ((span + (1 << sh) - 1) >> sh) > WB:
+        while span > KB and ((span + (1 << sh) - 1) >> sh) > WB:
             sh += 1
-        state[K_WLO + t], state[K_SH + t] = float(olo), float(sh)
+        for j in range(2):                                   # both ranks of the pair start in the same window
+            state[K_WLO + 2 * t + j], state[K_SH + 2 * t + j] = float(olo), float(sh)
 
     def poison(state):
         state[_ffi.POOL_M:_ffi.POOL_M + 6] = float("nan")
@@ -242,33 +250,33 @@ def install(all_tiles, break_it=False):
         h = hist.numpy()
         bit = 1 if keyset == _ffi.KEYSET_ANGLE else 2
         N = int(state[K_T] if keyset == _ffi.KEYSET_ANGLE else state[K_NPX])
-        listed = int(h[2])
+        listed = int(h[4])
         sub = [0 if keyset == _ffi.KEYSET_ANGLE else N - listed, N - listed]
         res, new, exact, bad = [0.0] * 4, [], True, False
-        for t in range(2):
+        for u in range(4):
+            t = u // 2
             k = min(max(int(state[K_K + t]), 0), N - 1)
-            k1 = min(k + 1, N - 1)
-            wlo, sh = int(state[K_WLO + t]), int(state[K_SH + t])
-            b, b1 = rank_bins(h[TW + NB * t:TW + NB * (t + 1)], int(h[t]), [k - sub[t], k1 - sub[t]])
-            if b < 0 or b >= (NB if sh == 0 else WB) or k - sub[t] < 0:
+            r = (min(k + 1, N - 1) if u & 1 else k) - sub[t]
+            wlo, sh = int(state[K_WLO + u]), int(state[K_SH + u])
+            uh = u - 1 if u & 1 and (wlo, sh) == (int(state[K_WLO + u - 1]), int(state[K_SH + u - 1])) else u
+            nb = KB if sh == 0 else WB
+            b, = rank_bins(h[TW + KB * uh:TW + KB * uh + nb], int(h[uh]), [r])
+            if b < 0 or b >= nb or r < 0:
                 bad = True
                 new.append((wlo, sh))
-                continue
-            if sh == 0:
-                if b1 < 0 or b1 >= NB:
-                    bad = True
-                res[2 * t], res[2 * t + 1] = ord2f(wlo + b), ord2f(wlo + min(max(b1, 0), NB - 1))
+            elif sh == 0:
+                res[u] = ord2f(wlo + b)
                 new.append((wlo, 0))
             else:
                 exact = False
-                new.append((wlo + (b << sh), max(sh - WBITS, 0)))
+                new.append((wlo + (b << sh), sh - WBITS if sh > KBITS else 0))
         miss, level = int(state[_ffi.POOL_MISS]), int(state[K_LEVEL])
         if bad or (not exact and level >= 2):
             state[_ffi.POOL_MISS], state[K_DONE] = float(miss | bit), 3.0
             return poison(state)
         if not exact:
-            for t in range(2):
-                state[K_WLO + t], state[K_SH + t] = float(new[t][0]), float(new[t][1])
+            for u in range(4):
+                state[K_WLO + u], state[K_SH + u] = float(new[u][0]), float(new[u][1])
             state[K_LEVEL] = float(level + 1)
             return
         state[K_RES:K_RES + 4] = torch.tensor(res, dtype=torch.float64)

@@ -251,6 +251,7 @@ def test_random_slides_through_the_one_sweep_chain_against_three_sweeps_and_the_
             np.testing.assert_allclose(new[1], old[1], rtol=1e-13, err_msg=label)
         else:
             why[(miss, w_)] = why.get((miss, w_), 0) + 1
+            print(f"  miss {miss} why {w_}: {label}")
         st.one_call = True
         got = st(dev)                                                 # what a caller gets, whichever route
         np.testing.assert_allclose(got[0], old[0], rtol=0, atol=1e-13, err_msg=label)
