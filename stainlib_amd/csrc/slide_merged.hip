@@ -20,6 +20,7 @@
 // whole slide are those of the candidates at shifted ranks: results never depend on the sample, only whether this route succeeds
 // does (state[SL_POOL_MISS] != 0: the caller takes the three-sweep chain of slide.hip).  Every decision is taken on the device from
 // all-reduced data: every rank reaches the same state without a broadcast, and nothing is read back before the end.
+#include <type_traits>
 #include "stats_kernels.hpp"
 #include "sl_host.hpp"
 #include <cmath>
@@ -282,7 +283,8 @@ struct P2HistArgs {
 };
 
 template <int KEYSET, int MODE>
-__global__ __launch_bounds__(kP2ListThreads) void k_p2_hist(P2HistArgs a) {
+// (two workgroups per CU: 2 x 70 KB of LDS, 64 VGPRs)
+__global__ __launch_bounds__(kP2ListThreads, 8) void k_p2_hist(P2HistArgs a) {
     constexpr int NT = kP2ListThreads;
     __shared__ SmallTab s_tab;
     __shared__ uint32_t s_h[2 * kP2GridBins];
@@ -322,12 +324,15 @@ __global__ __launch_bounds__(kP2ListThreads) void k_p2_hist(P2HistArgs a) {
     for (int t = 0; t < 2; ++t) { glo[t] = (float)st[kGridLo + t]; gsc[t] = (float)st[kGridScale + t]; }
     float nf[3] = {0, 0, 0}, mean[3] = {0, 0, 0};
     if (a.fourth) for (int c = 0; c < 3; ++c) { nf[c] = (float)st[kNh + c]; mean[c] = (float)st[kMean + c]; }
-    unsigned long long nbel[NU], nmatch = 0;
+    uint32_t nbel[NU], nmatch = 0;                              // per lane: well below 2^32
     for (int u = 0; u < NU; ++u) nbel[u] = 0;
     float q1 = 0.0f, q2 = 0.0f;
     const uint32_t nblk = a.list.cap_blocks;                   // every block carries a count (0: unused)
     const uint32_t B = 1u << a.list.blk_log2;
-    auto one = [&](uint32_t e) {
+    // SPLIT: some target has a window of its own (its pair's two ranks fell into different bins) -- rare; the usual pass is the
+    // straight-line two-histogram code (a uniform branch per entry cost the eight entries in flight their overlap: +35 % per pass)
+    auto one = [&](uint32_t e, auto split_tag) {
+        constexpr bool SPLIT = decltype(split_tag)::value;
         if ((e & a.need) != a.need) return;
         ++nmatch;
         const float ox = tab.odf(e & 255u), oy = tab.odf((e >> 8) & 255u), oz = tab.odf((e >> 16) & 255u);
@@ -357,9 +362,9 @@ __global__ __launch_bounds__(kP2ListThreads) void k_p2_hist(P2HistArgs a) {
             } else {
                 const uint32_t o = f2ord(k[t]);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < (SPLIT ? 2 : 1); ++j) {
                     const int u = 2 * t + j;
-                    if (nbt[u] == 0) continue;                       // uniform: the pair's histogram serves this rank too
+                    if (SPLIT && nbt[u] == 0) continue;              // uniform: the pair's histogram serves this rank too
                     if (o < wlo[u]) ++nbel[u];
                     else if (((o - wlo[u]) >> wsh[u]) < nbt[u]) atomicAdd(&s_h[u * kStride + ((o - wlo[u]) >> wsh[u])], 1u);
                 }
@@ -369,6 +374,7 @@ __global__ __launch_bounds__(kP2ListThreads) void k_p2_hist(P2HistArgs a) {
     // the counts of this workgroup's blocks are fetched a batch at a time (one dependent load per block was a latency chain of
     // ~1.5 us x blocks: most of a pass over a list with many unused blocks)
     __shared__ uint32_t s_cnt[NT];
+    auto blocks = [&](auto split_tag) {
     for (uint32_t b0 = blockIdx.x; b0 < nblk; b0 += gridDim.x * NT) {
         __syncthreads();
         {
@@ -386,19 +392,22 @@ __global__ __launch_bounds__(kP2ListThreads) void k_p2_hist(P2HistArgs a) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) { const uint32_t i = i0 + u * 64; e[u] = i < cnt ? as_global(src)[i] : 0u; }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) one(e[u]);
+                for (int u = 0; u < 8; ++u) one(e[u], split_tag);
             }
         }
     }
-    for (int u = 0; u < NU; ++u) nbel[u] = wave_sum(nbel[u]);
-    nmatch = wave_sum(nmatch);
-    unsigned long long w4 = nmatch, w5 = 0;                      // [4]: entries of this key set on the list
+    };
+    if (MODE == 1 && (nbt[NU - 1] != 0 || nbt[1] != 0)) blocks(std::true_type{});      // uniform
+    else blocks(std::false_type{});
+    unsigned long long nbw[NU];
+    for (int u = 0; u < NU; ++u) nbw[u] = wave_sum((unsigned long long)nbel[u]);
+    unsigned long long w4 = wave_sum((unsigned long long)nmatch), w5 = 0;      // [4]: entries of this key set on the list
     if (a.fourth) {
         w4 = (unsigned long long)(wave_sum((double)q1) * kQScale);
         w5 = (unsigned long long)(wave_sum((double)q2) * kQScale);
     }
     if (lane == 0) {
-        for (int u = 0; u < NU; ++u) if (nbel[u]) atomicAdd(&s_tail[u], nbel[u]);
+        for (int u = 0; u < NU; ++u) if (nbw[u]) atomicAdd(&s_tail[u], nbw[u]);
         atomicAdd(&s_tail[4], w4); atomicAdd(&s_tail[5], w5);
     }
     __syncthreads();
