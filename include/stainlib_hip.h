@@ -184,6 +184,10 @@ SL_API void sl_default_params(SlParams* p);
  * with the device current on which the operator will be launched (same partition mode); a workspace sized under another
  * device may be refused with SL_ERR_WORKSPACE, never overrun. */
 SL_API size_t sl_workspace_bytes(int op, int n_tiles, int h, int w);
+/* sl_workspace_bytes is the maximum over every SlParams (a workspace of that size serves any call of the op at this batch shape).
+ * What ONE call needs -- the schedule its SlParams (NULL: the defaults) select: the one-launch-per-phase schedule has no angular
+ * candidate list, 28 % less per tile -- is sl_workspace_bytes_for; the entry points check against this figure.  0: bad arguments. */
+SL_API size_t sl_workspace_bytes_for(int op, int n_tiles, int h, int w, const SlParams* params);
 
 /* MacenkoStainExtractor.get_stain_matrix (extraction/macenko_stain_extractor.py:7-44)
  * + get_concentrations (utils/stain_utils.py:69-78) + np.percentile(C, 99, axis=0)

@@ -74,6 +74,7 @@ _SIGNATURES = {
     "sl_error_string": (C.c_char_p, [C.c_int]),
     "sl_default_params": (None, [C.POINTER(SlParams)]),
     "sl_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "sl_workspace_bytes_for": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(SlParams)]),
     "sl_macenko_fit": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(SlParams), _P, _P, _P, _P, C.c_size_t, _P]),
     "sl_vahadane_fit": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(SlParams), _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "sl_normalize_apply": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_double, _P, _P]),

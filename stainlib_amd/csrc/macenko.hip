@@ -402,15 +402,31 @@ extern "C" size_t sl_workspace_bytes(int op, int n_tiles, int h, int w) {
     }
 }
 
+// What the call these SlParams select needs: one plan, not the maximum over all of them.
+extern "C" size_t sl_workspace_bytes_for(int op, int n_tiles, int h, int w, const SlParams* params) {
+    if (n_tiles <= 0 || h <= 0 || w <= 0 || !params_ok(params)) return 0;
+    const long P = (long)h * w;
+    const int schedule = params ? params->schedule : 0, fmin = params ? params->fused_min_tiles : 0;
+    switch (op) {
+        case SL_OP_MACENKO_FIT:
+        case SL_OP_MACENKO_TRANSFORM:
+            return plan_macenko(n_tiles, P, schedule, fmin).total;
+        case SL_OP_VAHADANE_FIT:
+        case SL_OP_VAHADANE_TRANSFORM:
+            return make_layout(n_tiles, P, kMethodVahadane, schedule, fmin).total;
+        default:
+            return sl_workspace_bytes(op, n_tiles, h, w);
+    }
+}
+
 extern "C" int sl_macenko_fit(const uint8_t* rgb, int n, int h, int w, const SlParams* params, double* M_out,
                               double* maxC_out, int32_t* status, void* workspace, size_t workspace_bytes,
                               void* stream) {
     if (!params_ok(params)) return SL_ERR_BADARG;
     const long P = (long)h * w;
     const MacenkoPlan pl = (n > 0 && h > 0 && w > 0) ? plan_macenko(n, P, params ? params->schedule : 0, params ? params->fused_min_tiles : 0) : MacenkoPlan{};
-    // the documented requirement, not this plan's own need (a schedule may need less: the per-phase one has no angular list): a workspace
-    // smaller than sl_workspace_bytes() is refused whatever SlParams selects
-    int rc = check_common(rgb, n, h, w, workspace, workspace_bytes, (n > 0 && h > 0 && w > 0) ? sl_workspace_bytes(SL_OP_MACENKO_TRANSFORM, n, h, w) : 0);
+    // this plan's own need: sl_workspace_bytes_for(op, n, h, w, params) (sl_workspace_bytes(), the maximum over every SlParams, always suffices)
+    int rc = check_common(rgb, n, h, w, workspace, workspace_bytes, pl.total);
     if (rc) return rc;
     SlParams p;
     sl_default_params(&p);
@@ -429,9 +445,8 @@ extern "C" int sl_macenko_transform(const uint8_t* rgb, uint8_t* out, int n, int
     if (!params_ok(params)) return SL_ERR_BADARG;
     const long P = (long)h * w;
     const MacenkoPlan pl = (n > 0 && h > 0 && w > 0) ? plan_macenko(n, P, params ? params->schedule : 0, params ? params->fused_min_tiles : 0) : MacenkoPlan{};
-    // the documented requirement, not this plan's own need (a schedule may need less: the per-phase one has no angular list): a workspace
-    // smaller than sl_workspace_bytes() is refused whatever SlParams selects
-    int rc = check_common(rgb, n, h, w, workspace, workspace_bytes, (n > 0 && h > 0 && w > 0) ? sl_workspace_bytes(SL_OP_MACENKO_TRANSFORM, n, h, w) : 0);
+    // this plan's own need: sl_workspace_bytes_for(op, n, h, w, params) (sl_workspace_bytes(), the maximum over every SlParams, always suffices)
+    int rc = check_common(rgb, n, h, w, workspace, workspace_bytes, pl.total);
     if (rc) return rc;
     if (!out || !M_tgt || !maxC_tgt) return SL_ERR_BADARG;
     SlParams p;

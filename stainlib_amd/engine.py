@@ -64,19 +64,25 @@ class Workspace:
     def __init__(self):
         self.buf = None
 
-    def get(self, op: int, n: int, h: int, w: int, device) -> torch.Tensor:
-        need = int(_ffi.lib().sl_workspace_bytes(op, n, h, w))
+    def get(self, op: int, n: int, h: int, w: int, device, params=None) -> torch.Tensor:
+        need = _ws_need(op, n, h, w, params)
         if self.buf is None or self.buf.numel() < need or self.buf.device != device:
             self.buf = torch.empty(max(need, 256), dtype=torch.uint8, device=device)
         return self.buf
 
 
-def _scratch(ws, op, n, h, w, device) -> torch.Tensor:
+def _ws_need(op, n, h, w, params=None) -> int:
+    """what THIS call needs (sl_workspace_bytes_for: the schedule its SlParams select), not the maximum over every SlParams"""
+    import ctypes as C
+    return int(_ffi.lib().sl_workspace_bytes_for(op, n, h, w, C.byref(params) if params is not None else None))
+
+
+def _scratch(ws, op, n, h, w, device, params=None) -> torch.Tensor:
     """The workspace of one call: the caller's Workspace, or a block of torch's caching allocator owned by the current
     stream for the duration of the call's kernels (freed blocks are reused on the same stream only after them)."""
     if ws is not None:
-        return ws.get(op, n, h, w, device)
-    need = int(_ffi.lib().sl_workspace_bytes(op, n, h, w))
+        return ws.get(op, n, h, w, device, params)
+    need = _ws_need(op, n, h, w, params)
     return torch.empty(max(need, 256), dtype=torch.uint8, device=device)
 
 
@@ -136,7 +142,7 @@ def _fit(fn_name, op, rgb, params, ws, with_sweeps=False):
     M = torch.empty((n, 2, 3), dtype=torch.float64, device=dev)
     maxC = torch.empty((n, 2), dtype=torch.float64, device=dev)
     status = torch.empty((n,), dtype=torch.int32, device=dev)
-    wsb = _scratch(ws, op, n, h, w, dev)
+    wsb = _scratch(ws, op, n, h, w, dev, p)
     fn = getattr(_ffi.lib(), fn_name)
     if with_sweeps:
         sweeps = torch.empty((n,), dtype=torch.int32, device=dev)
@@ -170,7 +176,7 @@ def _transform(fn_name, op, rgb, M_tgt, maxC_tgt, params, out, ws):
     M = torch.empty((n, 2, 3), dtype=torch.float64, device=dev)
     maxC = torch.empty((n, 2), dtype=torch.float64, device=dev)
     status = torch.empty((n,), dtype=torch.int32, device=dev)
-    wsb = _scratch(ws, op, n, h, w, dev)
+    wsb = _scratch(ws, op, n, h, w, dev, p)
     code = getattr(_ffi.lib(), fn_name)(_ptr(rgb), _ptr(out), n, h, w, C.byref(p), _ptr(M_tgt), _ptr(maxC_tgt),
                                         _ptr(M), _ptr(maxC), _ptr(status), _ptr(wsb), wsb.numel(), _stream())
     _ffi.check(code, fn_name)

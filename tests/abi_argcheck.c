@@ -52,11 +52,30 @@ int main(void) {
         EXPECT(sl_macenko_transform(rgb, out, n, h, w, &p, 0, d2, 0, 0, 0, ws, need, 0), SL_ERR_BADARG);
         EXPECT(sl_macenko_transform(rgb, out, n, h, w, &p, d6, 0, 0, 0, 0, ws, need, 0), SL_ERR_BADARG);
         EXPECT(sl_macenko_transform(rgb, out, -1, h, w, &p, d6, d2, 0, 0, 0, ws, need, 0), SL_ERR_BADARG);
-        EXPECT(sl_macenko_transform(rgb, out, n, h, w, &p, d6, d2, 0, 0, 0, ws, need - 256, 0), SL_ERR_WORKSPACE);
+        /* what THIS call needs (the plan its SlParams select) is checked, not the maximum over every SlParams */
+        const size_t mine = sl_workspace_bytes_for(SL_OP_MACENKO_TRANSFORM, n, h, w, &p);
+        EXPECT(mine > 0 && mine <= need && mine % 256 == 0, 1);
+        EXPECT(sl_macenko_transform(rgb, out, n, h, w, &p, d6, d2, 0, 0, 0, ws, mine - 256, 0), SL_ERR_WORKSPACE);
+        EXPECT(sl_workspace_bytes_for(SL_OP_VAHADANE_TRANSFORM, n, h, w, &p) <= needv, 1);
         EXPECT(sl_vahadane_transform(rgb, out, n, h, w, &p, d6, d2, 0, 0, 0, 0, needv, 0), SL_ERR_WORKSPACE);
         EXPECT(sl_vahadane_transform(rgb, 0, n, h, w, &p, d6, d2, 0, 0, 0, ws, needv, 0), SL_ERR_BADARG);
     }
+    p.schedule = 1;
+    {   /* the one-launch-per-phase schedule has no angular candidate list: less than the fused one at the same batch */
+        const size_t per_phase = sl_workspace_bytes_for(SL_OP_MACENKO_TRANSFORM, 512, 1024, 1024, &p);
+        p.schedule = 2;
+        EXPECT(per_phase < sl_workspace_bytes_for(SL_OP_MACENKO_TRANSFORM, 512, 1024, 1024, &p), 1);
+        EXPECT(sl_workspace_bytes_for(SL_OP_MACENKO_TRANSFORM, 512, 1024, 1024, &p) <= sl_workspace_bytes(SL_OP_MACENKO_TRANSFORM, 512, 1024, 1024), 1);
+    }
     p.schedule = 0;
+    EXPECT(sl_workspace_bytes_for(SL_OP_MACENKO_TRANSFORM, n, h, w, 0), sl_workspace_bytes_for(SL_OP_MACENKO_TRANSFORM, n, h, w, &p));
+    EXPECT(sl_workspace_bytes_for(SL_OP_MACENKO_TRANSFORM, 0, h, w, &p), 0);
+    EXPECT(sl_workspace_bytes_for(SL_OP_HED_AUGMENT, n, h, w, 0), sl_workspace_bytes(SL_OP_HED_AUGMENT, n, h, w));
+    {
+        SlParams bad = p;
+        bad.struct_size = 8;
+        EXPECT(sl_workspace_bytes_for(SL_OP_MACENKO_TRANSFORM, n, h, w, &bad), 0);
+    }
     /* SlParams.struct_size: set by sl_default_params; a struct of another size (a caller built against another header) is refused by
      * every entry point that takes one, before anything else is looked at */
     EXPECT(p.struct_size == sizeof(SlParams), 1);
