@@ -14,8 +14,9 @@
 //   F   sl_pool2_sweep    THE full sweep: exact moment sums + every pixel that is not PROVEN plain (inside the angular cone and below
 //       both concentration thresholds, whatever exact plane and stain matrix the bounds leave possible) appended raw to a block list
 //       -> all-reduce (16 doubles) -> sl_pool2_exact: exact eigenvectors, the plane check (ts_verify's conditions), ranks
-//   R   per key set: sl_pool2_hist(candidates, grid) -> all-reduce -> sl_pool2_pick -> sl_pool2_hist(candidates, window)
-//       -> all-reduce -> sl_pool2_resolve: the exact order statistics of the binary32 keys, the stain matrix (merged_verify), maxC
+//   R   per key set, up to SL_POOL2_LEVELS times: sl_pool2_hist(candidates, window) -> all-reduce -> sl_pool2_step: a radix descent
+//       in the ordered binary32 domain, one target per wanted rank (k and k + 1 of each order statistic share a window until they fall
+//       into different bins) -> the exact order statistics of the binary32 keys, the stain matrix (merged_verify), maxC
 // Non-candidates are proven to lie strictly inside (hi0, lo1) / below L_i under the EXACT basis, so the order statistics of the
 // whole slide are those of the candidates at shifted ranks: results never depend on the sample, only whether this route succeeds
 // does (state[SL_POOL_MISS] != 0: the caller takes the three-sweep chain of slide.hip).  Every decision is taken on the device from
