@@ -367,6 +367,11 @@ __device__ __forceinline__ void window_sweep(const uint8_t* src, int P, int c0, 
 
 template <int KEYSET, bool ALIGNED>
 __global__ __launch_bounds__(kSweepThreads, 4) void k_slide_window(SlideArgs a, unsigned long long* hist) {
+    // Device-driven chain: a stage that already ended in a miss (or a slide without tissue) has poisoned M -- every concentration key
+    // would be the same NaN pattern, one window bin taking a global atomic per pixel: 3.3 s for 256 tiles of 1024^2 (measured, round 6:
+    // a slide of four tiles repeated, whose angular keys tie beyond the 65 536-key window).  Nothing to select: the window stays empty,
+    // sl_pool_resolve reports the miss, the caller takes the radix rounds.
+    if (a.dyn && ((int)a.dyn[kPoolMiss] != 0 || (int)a.dyn[kPoolStatus] != SL_TILE_OK)) return;      // uniform
     args_from_pool_state<KEYSET>(a);
     __shared__ RowTab s_tab;
     s_tab.fill_b();

@@ -260,3 +260,44 @@ def test_random_slides_through_the_one_sweep_chain_against_three_sweeps_and_the_
         np.testing.assert_allclose(got[1], mc_ref, rtol=5e-7, err_msg=label)
     print(f"{done} slides: the one-sweep chain settled {settled} ({settled_auto} of {auto} at the automatic density); misses (miss, why): {why}")
     assert settled_auto >= (3 * auto) // 4
+
+
+def test_three_sweep_chain_does_not_sweep_for_a_stage_that_already_missed():
+    """The fallback chain (sl_pool_*): once a stage has reported a miss the stain matrix in the state is poisoned -- the concentration
+    window sweep behind it used to run on NaN keys, one window bin taking a global atomic per pixel (3.3 s per 256 tiles of 1024^2,
+    found in round 6 with a slide of four tiles repeated).  The window sweeps now leave at once on such a state: the window stays
+    empty, sl_pool_resolve keeps the miss, the caller takes the radix rounds -- and still gets the reference's numbers."""
+    import time
+    from stainlib_amd import _ffi, engine
+    from stainlib_amd.distributed import PooledSlideStatistics
+    rgb = to_dev([so.synth_tile(256, 256, 3 + s) for s in range(6)])
+    st = PooledSlideStatistics(group=False)
+    state = st.enqueue(rgb).clone()
+    assert float(state[_ffi.POOL_MISS]) == 0.0
+    for field, value in ((_ffi.POOL_MISS, 1.0), (_ffi.POOL_STATUS, float(_ffi.TILE_EMPTY_MASK))):
+        s2 = state.clone()
+        s2[field] = value
+        for keyset in (_ffi.KEYSET_ANGLE, _ffi.KEYSET_CONC):
+            buf = torch.zeros((2 * 65536 + 2,), dtype=torch.int64, device="cuda")
+            engine.pool_window(rgb, keyset, s2, buf)
+            assert int(buf.abs().sum()) == 0
+    buf = torch.zeros((2 * 65536 + 2,), dtype=torch.int64, device="cuda")
+    engine.pool_window(rgb, _ffi.KEYSET_CONC, state, buf)
+    assert int(buf.sum()) > 0                                         # (a live state: the sweep does run)
+    # end to end on a slide whose angular keys tie far beyond the window (four tiles, repeated): whatever route, quickly, the same numbers
+    four = [so.structured_tile("quantized", 256, 256, 20 + s) for s in range(4)]
+    tied = to_dev(four * 24)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    got = st(tied, merged=False)
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 2.0, "the three-sweep chain stalled on a tied slide"
+    print("tied slide, three-sweep chain and its fallbacks: paths", st.last_path)
+    tall = np.concatenate(four * 24, axis=0)
+    M_ref = so.macenko_stain_matrix(tall)
+    np.testing.assert_allclose(got[0], M_ref, rtol=0, atol=5e-7)
+    np.testing.assert_allclose(got[1], np.percentile(so.get_concentrations(tall, M_ref), 99, axis=0), rtol=5e-7)
+    new = st(tied)
+    assert st.last_path == ["merged", "merged"]
+    np.testing.assert_allclose(new[0], got[0], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(new[1], got[1], rtol=1e-13)

@@ -67,6 +67,17 @@ except Exception as e:  # noqa: BLE001
     print("no tissue fixture:", e)
 slides["smooth"] = lambda: smooth_tiles(n, side)
 
+
+def structured(kind):
+    """four structured tiles of the oracle's generator (heavy ties, saturated background), cycled"""
+    from oracle import stain_oracle as so
+    four = np.stack([so.structured_tile(kind, side, side, 20 + s) for s in range(4)])
+    return torch.as_tensor(four, device="cuda")[torch.arange(n, device="cuda") % 4].contiguous()
+
+
+for kind in ("quantized", "palette12", "white_bg"):
+    slides[kind] = lambda kind=kind: structured(kind)
+
 for name, make in slides.items():
     rgb = make()
     st = PooledSlideStatistics(group=False)
