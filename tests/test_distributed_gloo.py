@@ -691,3 +691,21 @@ def test_one_sweep_pooled_chain_reports_a_miss_and_the_caller_falls_back_on_two_
         assert np.array_equal(M, res[0][3]) and np.array_equal(maxC, res[0][4])
         np.testing.assert_allclose(M, M_ref, rtol=0, atol=2e-6)
         assert np.array_equal(M_s, M)
+
+
+def test_sample_density_of_the_one_sweep_chain_is_a_function_of_the_slide_alone():
+    """sample_log2_for: the whole slide up to 4 Mpx, then a sample that grows like pixels^(2/3) (one 64-pixel sub-row in 2^s) -- a pure
+    function of the agreed pixel count, so that every rank picks the same density without a collective; the forced density of the
+    tests (PooledSlideStatistics.sample_log2) overrides it on the instance only."""
+    from stainlib_amd.distributed import PooledSlideStatistics as S
+    assert [S.sample_log2_for(n) for n in (1, 1 << 20, 1 << 22)] == [0, 0, 0]
+    assert S.sample_log2_for((1 << 22) + 1) == S.sample_log2_for(5_000_000) == 3
+    assert S.sample_log2_for(512 << 20) == 6 and S.sample_log2_for(12_500 << 20) == 7 and S.sample_log2_for(100_000 << 20) == 8
+    last = 0
+    for e in range(0, 41):
+        s = S.sample_log2_for(1 << e)
+        assert 0 <= s <= 12 and s >= last                         # monotone, within what sl_pool2_* accept
+        last = s
+    a, b = S(group=False), S(group=False)
+    a.sample_log2 = 4
+    assert b.sample_log2 is None and S(group=False).sample_log2 is None
