@@ -15,4 +15,4 @@ from .normalization.normalizer import (ExtractiveStainNormalizer, MacenkoNormali
 from .utils.stain_utils import LuminosityStandardizer  # noqa: F401
 from .utils.excepts import InvalidRangeError, TissueMaskException  # noqa: F401
 
-__version__ = "0.5.0"
+__version__ = "0.6.0"
