@@ -281,6 +281,7 @@ struct P2HistArgs {
     int fourth;              // angle over the sample: also the fourth-moment sums of the tilt bound
     uint32_t* part;          // grid mode: [gridDim][2 x kP2GridBins] partial histograms
     unsigned long long* tpart;   // [gridDim][kTailPer] partial tail words
+    unsigned long long* hist;    // the pass's output buffer: zeroed here by workgroup 0 (k_p2_gsum, the next kernel on the stream, adds into it)
 };
 
 template <int KEYSET, int MODE>
@@ -290,9 +291,12 @@ __global__ __launch_bounds__(kP2ListThreads, 8) void k_p2_hist(P2HistArgs a) {
     __shared__ SmallTab s_tab;
     __shared__ uint32_t s_h[2 * kP2GridBins];
     __shared__ unsigned long long s_tail[kTailPer];
+    // (a memset node per pass was eight more launches per chain: ~30 us of a 512-tile slide's 2 ms)
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < SL_POOL2_HIST_WORDS; i += NT) a.hist[i] = 0ull;
     s_tab.fill();
     const double* st = a.state;
-    if (MODE == 1 && ((int)st[kDone] & (1 << KEYSET))) return;        // uniform: the key set is settled (k_p2_gsum skips alike)
+    if (MODE == 1 && ((int)st[kDone] & (1 << KEYSET))) return;        // uniform: the key set is settled (k_p2_gsum skips alike: hist stays zero)
     // histograms: mode 0 two grids of kP2GridBins; mode 1 four targets of kP2KeyBins slots (kP2WinBins used by a coarse window, none by a
     // target that shares its pair's window)
     constexpr int NU = MODE == 0 ? 2 : 4;
@@ -1200,7 +1204,7 @@ extern "C" int sl_pool2_hist(int which, int keyset, int mode, int n, int h, int 
     a.part = (uint32_t*)(ws + L.hpart);
     a.tpart = (unsigned long long*)(ws + L.tpart);
     hipStream_t s = (hipStream_t)stream;
-    SL_HIP_TRY(hipMemsetAsync(hist, 0, sizeof(unsigned long long) * SL_POOL2_HIST_WORDS, s));
+    a.hist = hist;
     const dim3 g((unsigned)blocks), b(kP2ListThreads);
     if (keyset == SL_KEYSET_ANGLE) {
         if (mode == 0) hipLaunchKernelGGL((k_p2_hist<SL_KEYSET_ANGLE, 0>), g, b, 0, s, a);
