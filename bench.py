@@ -425,6 +425,18 @@ def secondary_configs(dev, Mt, mct):
         sn.transform_shard(rgb, out=out)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / reps * 1e3
+    # the same chain + apply pass replayed from a HIP graph (SlideNormalizer(graph=True): captured once per buffer pair)
+    sng = SlideNormalizer(n, group=False, mode="pooled", graph=True)
+    out_g = torch.empty_like(rgb)
+    sng.transform_shard(rgb, out=out_g)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        sng.transform_shard(rgb, out=out_g)
+    torch.cuda.synchronize()
+    ms_g = (time.perf_counter() - t0) / reps * 1e3
+    graph_same = bool(torch.equal(out_g, out))
+    del out_g, sng
     small = rgb[:8]
     Mp, cp = PooledSlideStatistics(group=False)(small)
     tall = np.concatenate(list(small.cpu().numpy()), axis=0)
@@ -432,6 +444,8 @@ def secondary_configs(dev, Mt, mct):
     co = np.percentile(so.get_concentrations(tall, Mo), 99, axis=0)
     sec["pooled_slide_512x1024"] = {
         "ms_per_slide": round(ms, 4), "tiles_per_s": round(512 / ms * 1e3, 1), "selection_paths": list(sn.last_path),
+        "graph_replay": {"ms_per_slide": round(ms_g, 4), "tiles_per_s": round(512 / ms_g * 1e3, 1), "bytes_identical_to_eager": graph_same,
+                         "note": "SlideNormalizer(graph=True): the chain's ~50 launches and the apply pass captured once per (tiles, out) buffer pair, replayed per slide"},
         "parity_8_tile_slide": {"M_max_abs_err": float(np.abs(Mp - Mo).max()), "maxC_max_rel_err": float(np.abs(cp / co - 1).max())},
         "note": "device-driven, ONE statistics sweep since round 6 (sl_pool2_*: a pixel sample's estimate, the moments sweep that also collects the raw candidates of all four order statistics, exact selection on the candidate list; falls back to the three-sweep chain of round 3 when a check of the estimate fails -- selection_paths says which ran), the apply pass enqueued behind it, ONE read-back at the end (wall clock, not event time)"}
     del rgb, out

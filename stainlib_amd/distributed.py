@@ -435,16 +435,24 @@ class SlideNormalizer:
     """Slide-level Macenko/Vahadane normalisation over a sharded set of tiles (see module docstring).
 
     mode="median" (default): per-tile fits, all-gather, element-wise median.  mode="pooled": the exact statistics
-    of the concatenated slide (Macenko only)."""
+    of the concatenated slide (Macenko only).
 
-    def __init__(self, normalizer, group=None, mode="median", merged=True):
+    graph=True (pooled mode on ONE process: no collective sits between the steps): the one-sweep chain and the apply pass behind it --
+    some fifty launches -- are captured into a HIP graph the first time a (tiles buffer, out buffer) pair is seen and REPLAYED on every
+    later call with the same buffers (a pipeline that refills fixed staging buffers): 512 tiles 1.92 -> 1.84 ms, 128 tiles 0.79 -> 0.77.
+    The read-back after the replay is the same one; a replay that ends in a miss falls back exactly like the eager chain.  `out` is
+    allocated once and reused when the caller passes none."""
+
+    def __init__(self, normalizer, group=None, mode="median", merged=True, graph=False):
         if mode not in ("median", "pooled"):
             raise ValueError("mode must be 'median' or 'pooled'")
         self.normalizer = normalizer          # a fitted stainlib_amd ExtractiveStainNormalizer
         self.group = group
         self.mode = mode
         self.merged = merged                  # pooled mode: the one-sweep chain first (PooledSlideStatistics.enqueue_merged)
+        self.graph = graph
         self._pool2_ws = {}                   # its workspace, kept between calls
+        self._graphed = None                  # (key, engine.Graphed, pinned tensors) of the last captured chain
 
     def _targets(self, device):
         """The normalizer's 8 target doubles for the apply pass: its cached device tensors where it has them (uploaded once per fit; as
@@ -472,7 +480,34 @@ class SlideNormalizer:
             # mask, when TissueMaskException leaves this function.
             Mt, mct = self._targets(dev)
             got = None
-            for chain in ((stats.enqueue_merged, stats.enqueue) if self.merged else (stats.enqueue,)):
+            chains = (stats.enqueue_merged, stats.enqueue) if self.merged else (stats.enqueue,)
+            _, world = _world(self.group)
+            if self.graph and self.merged and stats.one_call and not _coll(world, self.group):
+                # the captured chain: same buffers as last time -> replay; else capture (one warm-up run, one run under capture)
+                import numpy as np
+                tgt_key = (np.asarray(self.normalizer.stain_matrix_target, dtype=np.float64).tobytes(),
+                           np.asarray(self.normalizer.maxC_target, dtype=np.float64).tobytes())          # (host values: no device read-back for the key)
+                if out is None:
+                    out = self._graphed[2]["out"] if (self._graphed and self._graphed[2]["out"].shape == tiles_local.shape
+                                                      and self._graphed[2]["out"].device == dev) else torch.empty_like(tiles_local)
+                key = (tiles_local.data_ptr(), out.data_ptr(), tuple(tiles_local.shape), n_tiles_total, str(dev), stats.thr, stats.pct, stats.lam, tgt_key)
+                if self._graphed is None or self._graphed[0] != key:
+                    keep = {"out": out, "tiles": tiles_local,
+                            "Mt": torch.as_tensor(Mt, dtype=torch.float64, device=dev).reshape(2, 3).clone(),
+                            "mct": torch.as_tensor(mct, dtype=torch.float64, device=dev).reshape(2).clone()}
+
+                    def captured():
+                        st_ = stats.enqueue_merged(tiles_local, n_tiles_total=n_tiles_total, ws=self._pool2_ws)
+                        M_ = st_[_ffi.POOL_M:_ffi.POOL_M + 6].reshape(2, 3)
+                        mc_ = st_[_ffi.POOL_MAXC:_ffi.POOL_MAXC + 2]
+                        engine.normalize_apply(tiles_local, M_.expand(n, 2, 3).contiguous(), mc_.expand(n, 2).contiguous(), keep["Mt"], keep["mct"], out=out)
+                        return st_, M_, mc_
+                    self._graphed = None                       # (the old graph goes before its buffers do)
+                    self._graphed = (key, engine.Graphed(captured), keep)
+                state, M_s, maxC_s = self._graphed[1].replay()
+                got = stats.finish(state)
+                chains = chains[1:]                            # a miss: the three-sweep chain, eagerly
+            for chain in (chains if got is None else ()):
                 def run(chain=chain):
                     st_ = chain(tiles_local, n_tiles_total=n_tiles_total, ws=self._pool2_ws if chain == stats.enqueue_merged else None)
                     M_ = st_[_ffi.POOL_M:_ffi.POOL_M + 6].reshape(2, 3)

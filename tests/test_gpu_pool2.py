@@ -301,3 +301,42 @@ def test_three_sweep_chain_does_not_sweep_for_a_stage_that_already_missed():
     assert st.last_path == ["merged", "merged"]
     np.testing.assert_allclose(new[0], got[0], rtol=0, atol=1e-13)
     np.testing.assert_allclose(new[1], got[1], rtol=1e-13)
+
+
+def test_slide_normalizer_replays_the_captured_chain_on_refilled_buffers():
+    """SlideNormalizer(graph=True): the one-sweep chain + the apply pass captured into a HIP graph on the first call with a (tiles, out)
+    buffer pair and replayed afterwards.  A pipeline refills the SAME buffers with the next slide: every replay must give that slide's
+    statistics and bytes, identical to the eager chain's (the counters of the chain are zeroed by a kernel: captured hipMemsetAsync nodes
+    did not stay ordered with the kernels around them -- replays lost candidate blocks)."""
+    import stainlib_amd as sl
+    from stainlib_amd.distributed import SlideNormalizer
+    from tools.synth import synth_tiles
+    n = sl.MacenkoNormalizer()
+    n.fit(so.synth_tile(128, 128, 1001, so.M_TRUE_TGT))
+    eager, graphed = SlideNormalizer(n, group=False, mode="pooled"), SlideNormalizer(n, group=False, mode="pooled", graph=True)
+    buf = synth_tiles(24, 512, 512, seed=1)
+    out_g = torch.empty_like(buf)
+    captures = 0
+    for rep, seed in enumerate((1, 2, 3, 2, 4)):
+        buf.copy_(synth_tiles(24, 512, 512, seed=seed))              # the next slide, in place
+        want_out, want_M, want_mc, _ = eager.transform_shard(buf)
+        before = graphed._graphed[1] if graphed._graphed else None
+        got_out, got_M, got_mc, _ = graphed.transform_shard(buf, out=out_g)
+        captures += graphed._graphed[1] is not before
+        assert got_out.data_ptr() == out_g.data_ptr() and graphed.last_path == ["merged", "merged"]
+        assert torch.equal(got_M, want_M) and torch.equal(got_mc, want_mc), (rep, seed)
+        assert torch.equal(got_out, want_out), (rep, seed)
+    assert captures == 1                                             # captured once, replayed four times
+    # another buffer: captured again; no `out`: allocated once and reused
+    other = synth_tiles(24, 512, 512, seed=5)
+    o1 = graphed.transform_shard(other)[0]
+    o2 = graphed.transform_shard(other)[0]
+    assert o1.data_ptr() == o2.data_ptr() and torch.equal(o2, eager.transform_shard(other)[0])
+    # a slide without tissue: reported like the reference, from a replay too; the tiles come back unchanged
+    white = torch.full((4, 128, 128, 3), 255, dtype=torch.uint8, device="cuda")
+    for _ in range(2):
+        with pytest.raises(sl.TissueMaskException):
+            graphed.transform_shard(white)
+    # a refit changes the targets: a new capture, the new bytes
+    n.fit(so.synth_tile(128, 128, 1002, so.M_TRUE_TGT * np.array([[1.0, 0.9, 1.1]])))
+    assert torch.equal(graphed.transform_shard(other)[0], SlideNormalizer(n, group=False, mode="pooled").transform_shard(other)[0])

@@ -30,6 +30,17 @@ for n in sizes:
         sn.transform_shard(rgb, out=out)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / reps * 1e3
+    ms_g = None
+    if n <= 2048:                                           # the same from a HIP graph (captured once per buffer pair)
+        sng = SlideNormalizer(nrm, group=False, mode="pooled", graph=True)
+        sng.transform_shard(rgb, out=out)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            sng.transform_shard(rgb, out=out)
+        torch.cuda.synchronize()
+        ms_g = (time.perf_counter() - t0) / reps * 1e3
+        del sng
     # stage split: statistics alone, apply alone
     st = PooledSlideStatistics(group=False)
     torch.cuda.synchronize()
@@ -60,6 +71,8 @@ for n in sizes:
           f"one sampled pass {t_sa:.2f}  apply {t_ap:.2f}", flush=True)
     print(f"pooled slide of {n:6d} tiles: {ms:9.2f} ms -> {n / ms:8.1f} k tiles/s   statistics {ms_stats:8.2f} ms (moments sweep {ms_mom:7.2f}) "
           f"apply {ms - ms_stats:8.2f} ms   paths {sn.last_path}", flush=True)
+    if ms_g is not None:
+        print(f"      replayed from a HIP graph (SlideNormalizer(graph=True)): {ms_g:9.2f} ms -> {n / ms_g:8.1f} k tiles/s", flush=True)
     # the same slide through the three-sweep chain of rounds 3-5 (the fallback), and the steps of the one-sweep chain (event ms)
     sn3 = SlideNormalizer(nrm, group=False, mode="pooled", merged=False)
     sn3.transform_shard(rgb, out=out)
