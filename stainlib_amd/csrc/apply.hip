@@ -83,7 +83,7 @@ extern "C" int sl_tissue_mask(const uint8_t* rgb, int n, int h, int w, double lu
     if (P > (1L << 30)) return SL_ERR_BADARG;
     const int parts = parts_for(P);
     hipStream_t s = (hipStream_t)stream;
-    if (counts) SL_HIP_TRY(hipMemsetAsync(counts, 0, sizeof(int64_t) * (size_t)n, s));
+    if (counts) zero_async(counts, sizeof(int64_t) * (size_t)n, s);
     hipLaunchKernelGGL(k_tissue_mask, dim3((unsigned)((long)n * parts)), dim3(kWG), 0, s, rgb, (int)P, parts,
                        y_limit_for_threshold(luminosity_threshold), mask_out, (unsigned long long*)counts);
     return launch_status();

@@ -38,6 +38,20 @@ int max_resident_grid() {
     return 2 * cus;
 }
 
+// Zeroes as a KERNEL (zero_async): captured into a HIP graph, hipMemsetAsync nodes did not stay ordered with the kernels around them on
+// this ROCm (round 6: replays of the pooled chain zeroed block counts after the sweep had begun to write them) -- every counter an
+// entry point clears before a kernel adds into it goes through here, so that the calls stay capture-safe (engine.Graphed).
+static __global__ __launch_bounds__(256) void k_zero_words(uint32_t* p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0u;
+}
+void zero_async(void* p, size_t bytes, hipStream_t s) {                   // p 4-byte aligned, bytes a multiple of 4
+    const size_t words = bytes / 4;
+    if (!words) return;
+    size_t blocks = (words + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_zero_words, dim3((unsigned)blocks), dim3(256), 0, s, (uint32_t*)p, words);
+}
+
 }  // namespace sl
 
 extern "C" int sl_version(void) { return SL_VERSION; }

@@ -249,7 +249,7 @@ extern "C" int sl_hed_augment(const uint8_t* rgb, uint8_t* out, int n, int h, in
     hc.log2_base = skimage_mode == SL_HED_EXPERIMENTAL_LOG10 ? 3.321928094887362 : 1.4426950408889634;
     hipStream_t s = (hipStream_t)stream;
     unsigned long long* sums = (unsigned long long*)workspace;
-    SL_HIP_TRY(hipMemsetAsync(sums, 0, sizeof(unsigned long long) * (size_t)n, s));
+    zero_async(sums, sizeof(unsigned long long) * (size_t)n, s);
     const int parts = parts_for(P);
     const dim3 grid((unsigned)((long)n * parts)), block(kWG);
     const bool al = aligned4(rgb, P) && aligned4(out, P);
@@ -278,7 +278,7 @@ extern "C" int sl_hed_augment_f64(const double* rgb, double* out, int n, int h, 
     hc.log2_base = 0.0;
     hipStream_t s = (hipStream_t)stream;
     double* sums = (double*)workspace;
-    SL_HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * (size_t)n, s));
+    zero_async(sums, sizeof(double) * (size_t)n, s);
     const int parts = parts_for(P);
     const dim3 grid((unsigned)((long)n * parts)), block(kWG);
     if (skimage_mode == SL_HED_SKIMAGE_018) hipLaunchKernelGGL((k_hed_f64<0>), grid, block, 0, s, rgb, out, (int)P, parts, sigma, bias, hc, sums);

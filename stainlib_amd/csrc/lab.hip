@@ -532,7 +532,7 @@ int lab_check(const void* rgb, const void* out, int n, int h, int w, const void*
 
 // the two statistics sweeps shared by the entry points below (and k_lab_pre between them: the tile's brightness table)
 int lab_statistics(const uint8_t* rgb, int n, long P, int standardize, int want_ab, double thr, LabScratch* sc, hipStream_t s) {
-    SL_HIP_TRY(hipMemsetAsync(sc, 0, sizeof(LabScratch) * (size_t)n, s));
+    zero_async(sc, sizeof(LabScratch) * (size_t)n, s);
     LabTileTabs* tt = lab_tabs_of(sc, n);
     const int parts = lab_parts(n, P);
     const dim3 grid((unsigned)((long)n * parts)), block(kLabWG);
@@ -603,7 +603,7 @@ extern "C" int sl_lab_merge(const void* I1, const void* I2, const void* I3, int 
 extern "C" int sl_od_to_rgb(const double* od, size_t n_values, uint8_t* rgb_out, int32_t* negative_flag, void* stream) {
     if (!od || !rgb_out || n_values == 0) return SL_ERR_BADARG;
     hipStream_t s = (hipStream_t)stream;
-    if (negative_flag) SL_HIP_TRY(hipMemsetAsync(negative_flag, 0, sizeof(int32_t), s));
+    if (negative_flag) zero_async(negative_flag, sizeof(int32_t), s);
     const size_t blocks = (n_values + kLabWG - 1) / kLabWG;
     hipLaunchKernelGGL(k_od_to_rgb, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(kLabWG), 0, s, od, n_values, rgb_out, negative_flag);
     return launch_status();

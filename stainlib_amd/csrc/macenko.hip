@@ -283,7 +283,7 @@ int run_fused(int method, const uint8_t* rgb, uint8_t* out, int n, long P, const
     while (((long)a.cl_lines * kClusterPx << a.cl_scale_log2) < P && a.cl_scale_log2 < 30) ++a.cl_scale_log2;
     a.ts_out = p.twosweep_out;
     a.next_tile = (unsigned long long*)(ws + L.off_next);
-    if (n > L.grid && hipMemsetAsync(a.next_tile, 0, sizeof(unsigned long long), s) != hipSuccess) return launch_status();
+    if (n > L.grid) zero_async(a.next_tile, sizeof(unsigned long long), s);
     const bool al = aligned4(rgb, P) && (!out || aligned4(out, P));
     ProfScope ps(p.profile, out ? SL_PROF_FUSED_TRANSFORM : SL_PROF_FUSED_FIT, n, s);
     // (the twelve instantiations of k_fused live in three translation units of their own -- fused_macenko.hip, fused_macenko_wide.hip,

@@ -29,6 +29,9 @@ uint32_t y_limit_for_threshold(double luminosity_threshold);
 // resident persistent-sweep workgroups of the current device (2 per CU; see common.hip)
 int max_resident_grid();
 
+// zeroes `bytes` (a multiple of 4) at the 4-byte aligned p with a kernel on s: see common.hip (hipMemsetAsync is not capture-safe here)
+void zero_async(void* p, size_t bytes, hipStream_t s);
+
 // workspace of the Lab family (lab.hip)
 size_t lab_workspace_bytes(int n_tiles);
 

@@ -132,21 +132,6 @@ P2Layout p2_layout(int n, int h, int w, int slog) {
     return L;
 }
 
-// Zeroes of the chain's counters, as a kernel: captured into a HIP graph, hipMemsetAsync nodes did not stay ordered with the kernels
-// around them on this ROCm (replays of the chain lost candidate blocks: counts zeroed after the sweep had begun to write them).
-__global__ __launch_bounds__(256) void k_p2_zero(uint32_t* p0, size_t n0, uint32_t* p1, size_t n1) {
-    const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x, step = (size_t)gridDim.x * 256;
-    for (size_t i = i0; i < n0; i += step) p0[i] = 0u;
-    for (size_t i = i0; i < n1; i += step) p1[i] = 0u;
-}
-void p2_zero(void* p0, size_t bytes0, void* p1, size_t bytes1, hipStream_t s) {
-    const size_t words = (bytes0 > bytes1 ? bytes0 : bytes1) / 4;
-    size_t blocks = (words + 255) / 256;
-    if (blocks < 1) blocks = 1;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_p2_zero, dim3((unsigned)blocks), dim3(256), 0, s, (uint32_t*)p0, bytes0 / 4, (uint32_t*)p1, bytes1 / 4);
-}
-
 // ------------------------------------------------------------------------------------------
 // S1: the sample
 // ------------------------------------------------------------------------------------------
@@ -1160,7 +1145,7 @@ extern "C" int sl_pool2_sample(const uint8_t* rgb, int n, int h, int w, const Sl
     if (!moments16_out) return SL_ERR_BADARG;
     hipStream_t s = (hipStream_t)stream;
     uint8_t* ws = (uint8_t*)workspace;
-    p2_zero(ws, 256, nullptr, 0, s);
+    zero_async(ws, 256, s);                                     // (a kernel: see common.hip)
     P2SampleArgs a;
     a.rgb = rgb; a.P = h * w; a.parts = L.parts; a.n_items = L.n_items; a.slog = sample_log2; a.bpi = L.bpi;
     a.ylimf = (float)y_limit_for_threshold(p.luminosity_threshold) - 2048.0f;
@@ -1248,7 +1233,8 @@ extern "C" int sl_pool2_sweep(const uint8_t* rgb, int n, int h, int w, const SlP
     if (!state || !totals16_out) return SL_ERR_BADARG;
     hipStream_t s = (hipStream_t)stream;
     uint8_t* ws = (uint8_t*)workspace;
-    p2_zero(ws + 64, 64, ws + L.c_counts, 4 * (size_t)L.c_cap, s);
+    zero_async(ws + 64, 64, s);
+    zero_async(ws + L.c_counts, 4 * (size_t)L.c_cap, s);
     P2SweepArgs a;
     a.rgb = rgb; a.P = h * w; a.parts = L.parts; a.n_items = L.n_items;
     a.ylimf = (float)y_limit_for_threshold(p.luminosity_threshold) - 2048.0f;
