@@ -120,7 +120,11 @@ P2Layout p2_layout(int n, int h, int w, int slog) {
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     L.hdr = 0;
     L.partials = 256;
-    L.hist_wgs = mg < 512 ? mg : 512;
+    // workgroups of a list pass (each leaves a 64 KB partial histogram for k_p2_gsum): one per CU up to 2^30 pixels, two beyond -- measured,
+    // chain alone, 256 against 512: 32 tiles 0.45 -> 0.41 ms, 128 tiles 0.62 -> 0.57, 512 tiles 1.20 -> 1.16, 1 024 tiles 1.99 -> 1.98,
+    // 2 048 tiles 4.00 -> 4.05, 12 500 tiles 21.7 -> 22.7
+    const int want_wgs = (long)n * P <= (1L << 30) ? 256 : 512;
+    L.hist_wgs = mg < want_wgs ? mg : want_wgs;
     L.hpart = up(L.partials + sizeof(double) * 16 * (size_t)mg);
     L.tpart = up(L.hpart + 4 * (size_t)(2 * kP2GridBins) * L.hist_wgs);
     L.local = up(L.tpart + 8 * (size_t)kTailPer * L.hist_wgs);               // sl_pool2_local: two 16-double vectors and one histogram buffer
