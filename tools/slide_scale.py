@@ -22,9 +22,11 @@ out_all = torch.empty_like(rgb_all)
 for n in sizes:
     rgb, out = rgb_all[:n], out_all[:n]
     sn = SlideNormalizer(nrm, group=False, mode="pooled")
-    sn.transform_shard(rgb, out=out)
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < 0.25:             # spin-up: the clocks ramp for ~25 ms, and a 512-tile slide is 2 ms
+        sn.transform_shard(rgb, out=out)
     torch.cuda.synchronize()
-    reps = 3 if n <= 2048 else 2
+    reps = 20 if n <= 512 else (5 if n <= 2048 else 2)
     t0 = time.perf_counter()
     for _ in range(reps):
         sn.transform_shard(rgb, out=out)
@@ -43,6 +45,7 @@ for n in sizes:
         del sng
     # stage split: statistics alone, apply alone
     st = PooledSlideStatistics(group=False)
+    st(rgb)                                                 # (untimed: the allocator may have to fetch the chain's workspace for this shape afresh)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     M, mc = st(rgb)
