@@ -218,6 +218,7 @@ def test_random_slides_through_the_one_sweep_chain_against_three_sweeps_and_the_
     seed = int(os.environ.get("SL_FUZZ_SEED", "606"))
     cases = int(os.environ.get("SL_FUZZ_CASES", "40"))
     settled = settled_auto = auto = done = 0
+    worst_mc = 0.0
     why = {}
     for label, tiles, thr, pct, lam, slog in random_slides(seed):
         if done >= cases:
@@ -257,7 +258,11 @@ def test_random_slides_through_the_one_sweep_chain_against_three_sweeps_and_the_
         np.testing.assert_allclose(got[0], old[0], rtol=0, atol=1e-13, err_msg=label)
         np.testing.assert_allclose(got[1], old[1], rtol=1e-13, err_msg=label)
         np.testing.assert_allclose(got[0], M_ref, rtol=0, atol=5e-7, err_msg=label)
-        np.testing.assert_allclose(got[1], mc_ref, rtol=5e-7, err_msg=label)
+        # (1e-6, not the 5e-7 of the fixed slides: maxC is an order statistic of binary32 concentrations -- a three-term dot product whose
+        #  terms may cancel -- against the oracle's binary64 ones; worst of 4 500 random slides: 5.0011e-7, a 242 x 192 pair at threshold 0.7)
+        np.testing.assert_allclose(got[1], mc_ref, rtol=1e-6, err_msg=label)
+        worst_mc = max(worst_mc, float(np.abs(got[1] / mc_ref - 1.0).max()))
+    print(f"worst |maxC / maxC_oracle - 1| {worst_mc:.2e}")
     print(f"{done} slides: the one-sweep chain settled {settled} ({settled_auto} of {auto} at the automatic density); misses (miss, why): {why}")
     assert settled_auto >= (3 * auto) // 4
 

@@ -274,7 +274,11 @@ def test_random_tiles_through_the_vahadane_fit_against_the_converged_oracle():
         # DIFFERENT stationary point with a clearly lower objective than the oracle's (seed 23, case 184: 0.2021 against 0.2048 on a
         # 37 x 33 window).  That passes the certificate; its distance from the oracle's point says nothing.
         better_basin = obj(M) < obj(Mo) - 1e-6
-        if obj(M) > obj(Mo) + 1e-9 or (float(Mo[0] @ Mo[1]) < 0.98 and err >= 1e-5 and not better_basin):
+        # ... and a flat direction shows in separated atoms too: the same objective to 1e-10 with the minimisers 1.9e-5 apart (seed 90210,
+        # case 106 of a 600-case soak: a 148 x 35 window of real tissue, lambda 0.2, objectives 0.06122795770 / 0.06122795768) -- the
+        # descent stops at dl_tol = 1e-9 wherever the valley's floor lets it.  Below 1e-4 with equal objectives that is the same optimum.
+        flat = abs(obj(M) - obj(Mo)) <= 1e-10 and err < 1e-4
+        if obj(M) > obj(Mo) + 1e-9 or (float(Mo[0] @ Mo[1]) < 0.98 and err >= 1e-5 and not better_basin and not flat):
             failures.append((label, obj(M), obj(Mo), err, int(sweeps[0])))
             continue
         worst = worst if better_basin else max(worst, err)
